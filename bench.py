@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the ACM decode hot path on MI355X.
+
+One "step" = one pass of the hot path (amplitude-table unpack -> juggle_block
+synthesis -> 16-bit write-out: one acmhip_plan_launch) over one batch of
+synthetic ACM streams whose staged form is already resident in HBM.  Default
+workload = BASELINE.json configs[1]: 1024 mono streams, acm_level 7, acm_rows
+16, 1000 blocks each (2.097 Gsamples per GPU per step).  With --gpus N every
+rank decodes its own 1024 streams (independent streams: no data-path
+collective, weak scaling); `value` is the whole-job Msamples/s.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) including
+  roofline     - achieved algorithmic HBM GB/s of the fused kernel
+                 (4 B/sample: 2 B staged index in + 2 B PCM out) against 8 TB/s,
+                 from HIP events recorded on the launch stream
+  cpu_baseline - the same decode on the host cores (the real reference if the
+                 prebuilt oracle/_ref is present, else our oracle port), on a
+                 bounded sample of the same workload, rank 0 / N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_SAMPLE = 4   # 2 B idx16 read + 2 B PCM16 written
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1024)
+    ap.add_argument("--level", type=int, default=7)
+    ap.add_argument("--rows", type=int, default=16)
+    ap.add_argument("--blocks", type=int, default=1000)
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the level-9/level-11 side measurements")
+    ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, budget_s):
+    """Decode file images of the workload on the host, one thread, until the budget is used."""
+    import oracle_api as O
+    files = batch.files
+    if not files:
+        return None
+    kind = "reference" if O.have_ref() else "port"
+    words = 0
+    t0 = time.perf_counter()
+    n = 0
+    if kind == "reference":
+        lib = O.ref_lib()
+        buf = (C.c_uint8 * 16384)()
+        for f in files:
+            s = O.LibacmStream(lib, f.tobytes())
+            while True:                                   # acmtool's decode loop (acmtool.c:274-291)
+                rc = lib.acm_read_loop(s.h, buf, 8192, 0, 2, 1)
+                if rc <= 0:
+                    break
+                words += rc // 2
+            s.close()
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    else:
+        for f in files:
+            w, _ = O.Oracle.decode_discard(f)
+            words += w
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    # fill-only share with the port (gives the CPU "synth" stage = total - fill)
+    t1 = time.perf_counter()
+    fw = 0
+    for f in files[:max(1, n // 4)]:
+        o = O.Oracle(f.tobytes())
+        while o.lib().acmo_fill_next_block(o.h, None, None, None) == 1:
+            fw += o.getter("block_len")
+        o.close()
+    dt_fill = time.perf_counter() - t1
+    return {
+        "value": round(words / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+        "sample": "%d of the workload's streams (%.1f Msamples), whole decode path incl. bit parsing, 1 thread, %.1f s"
+                  % (n, words / 1e6, dt),
+        "fill_only_msamples_s": round(fw / dt_fill / 1e6, 2) if dt_fill > 0 else None,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def time_plan(dev, plan, bufs, steps, warmup, barrier):
+    """W warm-up + K timed launches; returns (wall seconds incl. sync brackets, device ms from HIP events)."""
+    d_idx, d_hdr, d_pcm = bufs
+    for _ in range(warmup):
+        plan.launch(d_idx, d_hdr, d_pcm)
+    dev.sync()
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = plan.time(d_idx, d_hdr, d_pcm, reps=steps)    # events on the launch stream; blocks until done
+    dev.sync()
+    barrier()
+    return time.perf_counter() - t0, ev_ms
+
+
+def side_measure(dev, capi, workload, level, rows, blocks, streams, steps):
+    """kernel-only rate of another configuration (north_star quotes level 9; stress config is level 11)"""
+    b = workload.build_uniform(streams, level, rows, blocks, seed0=1 << 20)
+    bufs = b.upload(dev)
+    plan = capi.Plan(dev, b.descs)
+    _, ms = time_plan(dev, plan, bufs, steps, 2, lambda: None)
+    plan.destroy()
+    for p in bufs:
+        dev.free(p)
+    rate = b.samples * steps / (ms * 1e-3)
+    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks,
+            "msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
+            "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from libacm_amd import capi, workload
+    if capi.device_count() <= 0:
+        raise SystemExit("bench.py: no HIP device - the hot path has no CPU fallback")
+    dev = capi.Device(local)
+
+    sync_t = torch.zeros(1, device="cuda:%d" % local) if world > 1 else None
+
+    def barrier():
+        if dist is not None:
+            dist.all_reduce(sync_t)          # RCCL barrier (control only: no data-path collective)
+            torch.cuda.synchronize()
+
+    # ---- stage the workload (untimed): synth -> host bit parsing -> HBM ----
+    keep = 0 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 512)
+    t0 = time.perf_counter()
+    batch = workload.build_uniform(args.streams, args.level, args.rows, args.blocks, channels=args.channels,
+                                   seed0=rank * args.streams, keep_files=keep)
+    t_stage = time.perf_counter() - t0
+    bufs = batch.upload(dev)
+    plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
+    stats = plan.stats()
+
+    wall, ev_ms = time_plan(dev, plan, bufs, args.steps, args.warmup, barrier)
+
+    # max over ranks of the bracketed wall time
+    if dist is not None:
+        t = torch.tensor([wall], device="cuda:%d" % local, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t.item())
+        s = torch.tensor([float(batch.samples)], device="cuda:%d" % local, dtype=torch.float64)
+        dist.all_reduce(s)
+        total_samples = float(s.item())
+    else:
+        wall_max, total_samples = wall, float(batch.samples)
+
+    value = total_samples * args.steps / wall_max / 1e6
+    ms_per_step = wall_max / args.steps * 1e3
+    launch_ms = ev_ms / args.steps                         # average duration of one launch (rank 0's own events)
+    achieved = batch.samples * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "decoded PCM Msamples/sec over a batch of ACM streams (hot path on HBM-resident staged input)",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: %d synthetic mono streams per GPU, acm_level %d, acm_rows %d, "
+                               "%d blocks each" % (args.streams, args.level, args.rows, args.blocks),
+                   "streams_per_gpu": args.streams, "acm_level": args.level, "acm_rows": args.rows,
+                   "blocks_per_stream": args.blocks, "channels": args.channels,
+                   "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
+                   "kernel": "stagewise" if args.stagewise else "fused_tile", "tiles": int(stats.tiles),
+                   "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "acm_fused_tile<%d>" % args.level, "launch_ms": round(launch_ms, 4),
+                     "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_extra and not args.stagewise:
+            extra = []
+            for (lv, rw, bl, ns) in ((9, 16, 250, 512), (11, 64, 2, 2048)):
+                try:
+                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(3, args.steps // 2)))
+                except Exception as e:   # a side measurement must never sink the headline line
+                    extra.append({"level": lv, "error": str(e)[:200]})
+            out["other_levels_kernel_only"] = extra
+        if not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:200]}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    plan.destroy()
+    for p in bufs:
+        dev.free(p)
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

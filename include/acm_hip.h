@@ -1,0 +1,217 @@
+/*
+ * acm_hip.h - C ABI of the MI355X-native ACM block-synthesis hot path.
+ *
+ * This is the boundary a maintainer of the reference would bind to replace the
+ * data-parallel half of decode_block()/acm_read() (INTEGRATION.md shows the
+ * patch).  Plain C: pointers, sizes, PODs; no C++ or torch types.  Every entry
+ * point names the reference code it replaces (paths relative to
+ * /root/reference/src).
+ *
+ * Division of labour (BASELINE.json north_star):
+ *   host   - sequential bitstream reader + the 15 filler parsers
+ *            (decode.c:41-163, 181-502) -> "staged" form: one int16 filler
+ *            index per sample in PCM order + one acmhip_blkhdr per block.
+ *   device - amplitude-table unpack (decode.c:592-600 + set_pos :174-177, i.e.
+ *            value = idx * val), juggle_block subband synthesis (:508-577) and
+ *            16-bit write-out (:617-677) as HIP kernels on gfx950.
+ *
+ * There is no CPU implementation of the device half in this library; every
+ * call fails with ACMHIP_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef ACM_HIP_H
+#define ACM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACMHIP_OK             0
+#define ACMHIP_ERR_NO_DEVICE -101   /* no usable HIP device / runtime */
+#define ACMHIP_ERR_HIP       -102   /* a HIP call failed; see acmhip_last_error() */
+#define ACMHIP_ERR_ARG       -103   /* invalid argument */
+#define ACMHIP_ERR_NOMEM     -104
+
+/* output sample layouts = the four writers of decode.c:617-655 */
+#define ACMHIP_FMT_S16LE 0u
+#define ACMHIP_FMT_S16BE 1u         /* bit 0: big-endian   (bigendianp, decode.c:662) */
+#define ACMHIP_FMT_U16LE 2u         /* bit 1: unsigned     (!sgned,     decode.c:663) */
+#define ACMHIP_FMT_U16BE 3u
+
+/*
+ * Staged block header: the (pwr,val) pair of decode.c:586-589.  On the device
+ * the amplitude table midbuf[i] = i*val (decode.c:592-600) is never built;
+ * value = (int32)((uint32)idx * val).  pwr is kept for the host (range check
+ * of hazard H1) and for diagnostics.
+ */
+typedef struct acmhip_blkhdr {
+	uint32_t val;            /* 0..65535 */
+	uint32_t pwr;            /* 0..15 */
+} acmhip_blkhdr;
+
+/*
+ * Hazard H1: a filler index outside [-2^pwr, 2^pwr) makes the
+ * reference read an amplitude-table entry left behind by an EARLIER block
+ * (decode.c:809-810: the table is never cleared).  The host parser resolves
+ * those samples itself and ships them as patches: "sample `sample` of this
+ * stream's staged array has the unpacked value `value`, whatever idx*val says".
+ */
+typedef struct acmhip_patch {
+	uint64_t sample;         /* index into the stream's staged samples (0 = first staged sample) */
+	int32_t  value;
+	uint32_t stream;         /* index into the acmhip_stream_desc array */
+} acmhip_patch;
+
+/*
+ * One stream (or one window of a stream) to synthesise.  The staged samples of
+ * a stream are contiguous in PCM order: sample m = row*cols + col, rows
+ * running on across block boundaries (block b owns rows [b*rows, (b+1)*rows)).
+ * The synthesis history of decode.c:803-812 (wrapbuf) is not stored anywhere:
+ * it is a pure function of the two staged rows that precede a row
+ * (SURVEY.md 7.1), so a window that starts at row_begin > 0 only needs the
+ * staged rows row_begin-2.. to be present.  Rows before row 0 are zeros
+ * (decode.c:812, util.c:241).
+ */
+typedef struct acmhip_stream_desc {
+	uint64_t idx_off;        /* int16 units from d_idx to staged row 0; multiple of 8 */
+	uint64_t hdr_off;        /* acmhip_blkhdr units from d_hdr to the header of block 0 */
+	uint64_t pcm_off;        /* int16 units from d_pcm to where sample (row_begin, 0) goes; multiple of 8 */
+	uint64_t n_emit;         /* samples to write, starting at row_begin*cols (<= (nrows-row_begin)*cols) */
+	uint32_t level;          /* acm_level 0..15 */
+	uint32_t rows;           /* acm_rows  1..4095 */
+	uint32_t nrows;          /* staged rows present = staged blocks * rows */
+	uint32_t row_begin;      /* first row to emit */
+} acmhip_stream_desc;
+
+typedef struct acmhip_device acmhip_device;   /* one HIP device + the stream work is queued on */
+typedef struct acmhip_plan acmhip_plan;       /* device-resident launch tables for a fixed set of stream descs */
+
+/* which kernel family a plan may use */
+#define ACMHIP_PLAN_AUTO      0u    /* fused tile kernel where it applies, stage-wise kernels elsewhere */
+#define ACMHIP_PLAN_STAGEWISE 1u    /* force the generic stage-wise kernels (bring-up / cross-check) */
+
+const char *acmhip_last_error(void);          /* thread-local text of the last failure */
+int  acmhip_device_count(void);               /* usable HIP devices, 0 if none (never fails) */
+
+/* hip_stream: a hipStream_t to queue on (e.g. the caller's framework stream), or NULL for a private one */
+int  acmhip_device_open(int ordinal, void *hip_stream, acmhip_device **out);
+void acmhip_device_close(acmhip_device *dev);
+int  acmhip_device_sync(acmhip_device *dev);
+void *acmhip_device_stream(acmhip_device *dev);   /* the hipStream_t in use */
+
+/* memory plumbing so that plain C programs need no HIP headers */
+int  acmhip_malloc(acmhip_device *dev, size_t bytes, void **dptr);
+int  acmhip_free(acmhip_device *dev, void *dptr);
+int  acmhip_host_alloc(size_t bytes, void **hptr);            /* pinned */
+int  acmhip_host_free(void *hptr);
+int  acmhip_upload(acmhip_device *dev, void *dptr, const void *hptr, size_t bytes);    /* async on the device stream */
+int  acmhip_download(acmhip_device *dev, void *hptr, const void *dptr, size_t bytes);  /* async on the device stream */
+
+/*
+ * Build the launch tables for `n` streams (+ optional H1 patches).  Streams may
+ * mix levels/rows/lengths freely.  Replaces nothing in the reference (it has
+ * no batching); it is what lets one launch cover thousands of decode_block()s.
+ */
+int  acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *streams, size_t n,
+			const acmhip_patch *patches, size_t npatches, unsigned flags,
+			acmhip_plan **out);
+void acmhip_plan_destroy(acmhip_plan *plan);
+
+/*
+ * THE hot path.  Queues unpack + juggle_block + write-out for every stream of
+ * the plan: replaces decode.c:592-600 (table), :174-177 (lookup), :528-577
+ * (juggle_block), :657-677 (output_values).  d_idx / d_hdr / d_pcm are device
+ * pointers; fmt is ACMHIP_FMT_*.  Asynchronous on the device's stream.
+ */
+int  acmhip_plan_launch(acmhip_plan *plan, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+			int16_t *d_pcm, unsigned fmt);
+
+/* introspection for benchmarks/tests */
+typedef struct acmhip_plan_stats {
+	uint64_t samples;        /* total n_emit */
+	uint64_t tiles;          /* fused-kernel workgroups */
+	uint32_t fused_streams;  /* streams handled by the fused tile kernel */
+	uint32_t stagewise_streams;
+	uint32_t launches;       /* kernel launches per acmhip_plan_launch */
+	uint32_t reserved;
+} acmhip_plan_stats;
+int  acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out);
+
+/*
+ * Time `reps` back-to-back acmhip_plan_launch calls with HIP events recorded on
+ * the launch stream; *ms_total receives the elapsed milliseconds of the whole
+ * bracket (device time, includes launch gaps).  Blocks until done.
+ */
+int  acmhip_plan_time(acmhip_plan *plan, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+		      int16_t *d_pcm, unsigned fmt, int reps, float *ms_total);
+
+/* ------------------------------------------------------------------------
+ * Host half of the path: bit parsing into staged form.
+ * Replaces decode.c:41-163 (bit reader), :181-502 (fillers, fill_block),
+ * :586-589 (block header), :687-752 (headers) for whole in-memory files.
+ * ---------------------------------------------------------------------- */
+typedef struct acm_stage_info {
+	uint32_t level, rows, cols;
+	uint32_t channels;       /* in effect (after force_chans) */
+	uint32_t hdr_channels;   /* as written in the header */
+	uint32_t rate;
+	uint32_t total_values;
+	uint32_t wavc;
+	uint32_t blocks;         /* blocks completely parsed into the staging arrays */
+	int32_t  end_status;     /* 0 = clean end (EOF at a block/column boundary or total_values reached);
+	                            ACM_ERR_* = what acm_read would have returned after those blocks */
+	uint64_t npatches;       /* H1 patches produced */
+	uint64_t header_bytes;   /* 14 or 42 */
+} acm_stage_info;
+
+/* header only (decode.c:712-752 + channel forcing :795-798); returns ACM_OK or ACM_ERR_NOT_ACM */
+int  acm_stage_probe(const uint8_t *data, size_t len, int force_chans, acm_stage_info *info);
+
+/*
+ * Parse every block that acm_read() would decode (stops after the block that
+ * covers total_values, at a clean EOF, or at the first error) into
+ *   idx[b*block_len + row*cols + col]  (row-major, PCM order) and hdr[b].
+ * max_blocks bounds the arrays; patches (may be NULL when max_patches == 0)
+ * receive H1 fix-ups with .stream = 0.  Returns ACM_OK (details in *info) or
+ * ACM_ERR_NOT_ACM / ACMHIP_ERR_ARG.
+ */
+int  acm_stage_file(const uint8_t *data, size_t len, int force_chans,
+		    int16_t *idx, acmhip_blkhdr *hdr, size_t max_blocks,
+		    acmhip_patch *patches, size_t max_patches, acm_stage_info *info);
+
+/* ------------------------------------------------------------------------
+ * Batch front end (no reference counterpart; BASELINE.json "batch-of-files").
+ * Decodes n in-memory ACM files on ONE device: threaded host staging ->
+ * pinned buffers -> H2D -> acmhip_plan_launch -> D2H.
+ * ---------------------------------------------------------------------- */
+typedef struct acm_batch_item {
+	const uint8_t *data;     /* in:  file image */
+	size_t   len;            /* in */
+	int16_t *pcm;            /* in:  caller buffer for total_values words (may be NULL: decode and discard) */
+	size_t   pcm_cap;        /* in:  capacity of pcm in 16-bit words */
+	uint64_t words;          /* out: words actually decoded (<= total_values) */
+	int32_t  status;         /* out: ACM_OK, or the ACM_ERR_* that ended the stream / rejected the file */
+	uint32_t level, rows, channels, rate, total_values;   /* out */
+} acm_batch_item;
+
+typedef struct acm_batch_opts {
+	int      force_chans;
+	unsigned fmt;            /* ACMHIP_FMT_* */
+	int      threads;        /* host staging threads, 0 = hardware concurrency */
+	unsigned plan_flags;     /* ACMHIP_PLAN_* */
+} acm_batch_opts;
+
+typedef struct acm_batch_timing {
+	double stage_s, h2d_s, kernel_s, d2h_s, total_s;
+	uint64_t samples;
+} acm_batch_timing;
+
+int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,
+		      const acm_batch_opts *opts, acm_batch_timing *timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

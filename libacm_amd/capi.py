@@ -1,0 +1,347 @@
+"""ctypes binding of libacm_hip.so (include/acm_hip.h + include/libacm.h).
+
+Thin plumbing for tests, bench.py and the multi-GPU front end.  Nothing here
+computes: staging is done by the library's host parser, synthesis by its HIP
+kernels.  There is no CPU synthesis fallback - without a usable HIP device
+Device() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+FMT_S16LE, FMT_S16BE, FMT_U16LE, FMT_U16BE = 0, 1, 2, 3
+PLAN_AUTO, PLAN_STAGEWISE = 0, 1
+ERR_NO_DEVICE = -101
+
+
+class BlkHdr(C.Structure):
+    _fields_ = [("val", C.c_uint32), ("pwr", C.c_uint32)]
+
+
+class Patch(C.Structure):
+    _fields_ = [("sample", C.c_uint64), ("value", C.c_int32), ("stream", C.c_uint32)]
+
+
+class StreamDesc(C.Structure):
+    _fields_ = [("idx_off", C.c_uint64), ("hdr_off", C.c_uint64), ("pcm_off", C.c_uint64),
+                ("n_emit", C.c_uint64), ("level", C.c_uint32), ("rows", C.c_uint32),
+                ("nrows", C.c_uint32), ("row_begin", C.c_uint32)]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("tiles", C.c_uint64), ("fused_streams", C.c_uint32),
+                ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class StageInfo(C.Structure):
+    _fields_ = [("level", C.c_uint32), ("rows", C.c_uint32), ("cols", C.c_uint32),
+                ("channels", C.c_uint32), ("hdr_channels", C.c_uint32), ("rate", C.c_uint32),
+                ("total_values", C.c_uint32), ("wavc", C.c_uint32), ("blocks", C.c_uint32),
+                ("end_status", C.c_int32), ("npatches", C.c_uint64), ("header_bytes", C.c_uint64)]
+
+
+class BatchItem(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("pcm", C.c_void_p), ("pcm_cap", C.c_size_t),
+                ("words", C.c_uint64), ("status", C.c_int32), ("level", C.c_uint32), ("rows", C.c_uint32),
+                ("channels", C.c_uint32), ("rate", C.c_uint32), ("total_values", C.c_uint32)]
+
+
+class BatchOpts(C.Structure):
+    _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint)]
+
+
+class BatchTiming(C.Structure):
+    _fields_ = [("stage_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double),
+                ("d2h_s", C.c_double), ("total_s", C.c_double), ("samples", C.c_uint64)]
+
+
+# every symbol include/acm_hip.h declares (checked by tests/test_abi.py)
+ACMHIP_SYMBOLS = [
+    "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
+    "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
+    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
+    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
+    "acm_batch_decode",
+]
+# the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
+LIBACM_SYMBOLS = [
+    "acm_open_decoder", "acm_read", "acm_close", "acm_open_file", "acm_info", "acm_seekable", "acm_bitrate",
+    "acm_rate", "acm_channels", "acm_raw_total", "acm_raw_tell", "acm_pcm_total", "acm_pcm_tell",
+    "acm_time_total", "acm_time_tell", "acm_read_loop", "acm_seek_pcm", "acm_seek_time", "acm_strerror",
+]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_build.LIB, "libacm_hip.so")
+
+
+def lib():
+    """Load libacm_hip.so (building it if the tree is newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build_hip()
+    L = C.CDLL(path)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.acmhip_last_error.restype = C.c_char_p
+    L.acmhip_device_open.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.acmhip_device_close.argtypes = [vp]
+    L.acmhip_device_close.restype = None
+    L.acmhip_device_sync.argtypes = [vp]
+    L.acmhip_device_stream.argtypes = [vp]
+    L.acmhip_device_stream.restype = vp
+    L.acmhip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.acmhip_free.argtypes = [vp, vp]
+    L.acmhip_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.acmhip_host_free.argtypes = [vp]
+    L.acmhip_upload.argtypes = [vp, vp, vp, sz]
+    L.acmhip_download.argtypes = [vp, vp, vp, sz]
+    L.acmhip_plan_create.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
+    L.acmhip_plan_destroy.argtypes = [vp]
+    L.acmhip_plan_destroy.restype = None
+    L.acmhip_plan_launch.argtypes = [vp, vp, vp, vp, C.c_uint]
+    L.acmhip_plan_get_stats.argtypes = [vp, C.POINTER(PlanStats)]
+    L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
+    L.acm_stage_probe.argtypes = [vp, sz, C.c_int, C.POINTER(StageInfo)]
+    L.acm_stage_file.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp, sz, C.POINTER(StageInfo)]
+    L.acm_batch_decode.argtypes = [vp, C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(BatchTiming)]
+    _lib = L
+    return L
+
+
+class AcmHipError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise AcmHipError("%s failed (%d): %s" % (what, rc, lib().acmhip_last_error().decode(errors="replace")))
+
+
+def device_count():
+    return lib().acmhip_device_count()
+
+
+# --------------------------------------------------------------------------- host staging
+class Staged:
+    """One file in staged form: idx (int16, PCM order), hdr (uint32[blocks,2] = val,pwr), patches, info."""
+
+    def __init__(self, idx, hdr, patches, info):
+        self.idx, self.hdr, self.patches, self.info = idx, hdr, patches, info
+
+    @property
+    def block_len(self):
+        return self.info.rows * self.info.cols
+
+    @property
+    def words(self):
+        """words an acm_read_loop() caller would get (whole blocks, total_values cut, channel rounding)"""
+        pos, bl, tot, ch = 0, self.block_len, self.info.total_values, self.info.channels
+        for _ in range(self.info.blocks):
+            if pos >= tot:
+                break
+            take = min(bl, tot - pos)
+            if ch > 1:
+                take -= take % ch
+            pos += take
+            if take != bl:
+                break
+        return pos
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def probe(data, force_chans=0):
+    a = _as_u8(data)
+    info = StageInfo()
+    rc = lib().acm_stage_probe(a.ctypes.data, a.size, force_chans, C.byref(info))
+    return rc, info
+
+
+def stage_file(data, force_chans=0, idx_out=None, hdr_out=None):
+    """Host bit parsing of a whole file image -> Staged (raises on a non-ACM file)."""
+    a = _as_u8(data)
+    rc, info = probe(a, force_chans)
+    if rc != 0:
+        raise ValueError("not an ACM stream (%d)" % rc)
+    bl = info.rows * info.cols
+    need = (info.total_values + bl - 1) // bl
+    idx = idx_out if idx_out is not None else np.zeros(need * bl, dtype=np.int16)
+    hdr = hdr_out if hdr_out is not None else np.zeros((need, 2), dtype=np.uint32)
+    assert idx.size >= need * bl and hdr.shape[0] >= need
+    info2 = StageInfo()
+    rc = lib().acm_stage_file(a.ctypes.data, a.size, force_chans, idx.ctypes.data, hdr.ctypes.data, need,
+                              None, 0, C.byref(info2))
+    if rc != 0:
+        raise ValueError("acm_stage_file failed (%d)" % rc)
+    patches = None
+    if info2.npatches:
+        patches = (Patch * info2.npatches)()
+        rc = lib().acm_stage_file(a.ctypes.data, a.size, force_chans, idx.ctypes.data, hdr.ctypes.data, need,
+                                  patches, info2.npatches, C.byref(info2))
+    return Staged(idx[:info2.blocks * bl], hdr[:info2.blocks], patches, info2)
+
+
+# --------------------------------------------------------------------------- device
+class Device:
+    def __init__(self, ordinal=0, hip_stream=None):
+        self.h = C.c_void_p()
+        rc = lib().acmhip_device_open(ordinal, hip_stream, C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise AcmHipError("acmhip_device_open(%d) failed (%d): %s"
+                              % (ordinal, rc, lib().acmhip_last_error().decode(errors="replace")))
+
+    def close(self):
+        if self.h:
+            lib().acmhip_device_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        _check(lib().acmhip_device_sync(self.h), "acmhip_device_sync")
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().acmhip_malloc(self.h, nbytes, C.byref(p)), "acmhip_malloc")
+        return p.value
+
+    def free(self, ptr):
+        if ptr:
+            _check(lib().acmhip_free(self.h, ptr), "acmhip_free")
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().acmhip_upload(self.h, dptr, arr.ctypes.data, arr.nbytes), "acmhip_upload")
+        self.sync()          # pageable numpy memory: finish before the array can go away
+
+    def download(self, arr, dptr):
+        _check(lib().acmhip_download(self.h, arr.ctypes.data, dptr, arr.nbytes), "acmhip_download")
+        self.sync()
+
+
+class Plan:
+    def __init__(self, dev, descs, patches=None, flags=PLAN_AUTO):
+        self.dev = dev
+        n = len(descs)
+        arr = (StreamDesc * max(n, 1))(*descs)
+        np_ = len(patches) if patches is not None else 0
+        self.h = C.c_void_p()
+        _check(lib().acmhip_plan_create(dev.h, arr, n, patches if np_ else None, np_, flags, C.byref(self.h)),
+               "acmhip_plan_create")
+
+    def launch(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE):
+        _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
+
+    def time(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE, reps=1):
+        ms = C.c_float()
+        _check(lib().acmhip_plan_time(self.h, d_idx, d_hdr, d_pcm, fmt, reps, C.byref(ms)), "acmhip_plan_time")
+        return ms.value
+
+    def stats(self):
+        st = PlanStats()
+        _check(lib().acmhip_plan_get_stats(self.h, C.byref(st)), "acmhip_plan_get_stats")
+        return st
+
+    def destroy(self):
+        if self.h:
+            lib().acmhip_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _round_up(v, a):
+    return (v + a - 1) // a * a
+
+
+class Arena:
+    """Several staged streams laid out in three host arrays + their descriptors (whole-stream decode)."""
+
+    def __init__(self, staged_list, windows=None):
+        """windows: optional per-stream (row_begin, n_emit) to decode only a slice"""
+        idx_tot = hdr_tot = pcm_tot = 0
+        self.descs, self.patch_list = [], []
+        lay = []
+        for i, s in enumerate(staged_list):
+            bl = s.block_len
+            n = s.info.blocks * bl
+            row_begin, n_emit = (0, s.words) if windows is None else windows[i]
+            d = StreamDesc(idx_off=idx_tot, hdr_off=hdr_tot, pcm_off=pcm_tot, n_emit=n_emit,
+                           level=s.info.level, rows=s.info.rows, nrows=s.info.blocks * s.info.rows,
+                           row_begin=row_begin)
+            self.descs.append(d)
+            lay.append((idx_tot, hdr_tot, pcm_tot, n, n_emit))
+            if s.patches is not None:
+                for p in s.patches:
+                    self.patch_list.append(Patch(p.sample, p.value, i))
+            idx_tot += _round_up(max(n, 1), 64)
+            hdr_tot += max(s.info.blocks, 1)
+            pcm_tot += _round_up(max(n_emit, 1), 64)
+        self.idx = np.zeros(idx_tot, dtype=np.int16)
+        self.hdr = np.zeros((hdr_tot, 2), dtype=np.uint32)
+        self.pcm_words = pcm_tot
+        self.layout = lay
+        for s, (io, ho, po, n, ne) in zip(staged_list, lay):
+            self.idx[io:io + n] = s.idx[:n]
+            self.hdr[ho:ho + s.info.blocks] = s.hdr[:s.info.blocks]
+        self.patches = (Patch * len(self.patch_list))(*self.patch_list) if self.patch_list else None
+
+
+def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False):
+    """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream."""
+    ar = Arena(staged_list, windows)
+    d_idx = dev.malloc(ar.idx.nbytes)
+    d_hdr = dev.malloc(ar.hdr.nbytes)
+    d_pcm = dev.malloc(ar.pcm_words * 2)
+    try:
+        dev.upload(d_idx, ar.idx)
+        dev.upload(d_hdr, ar.hdr)
+        plan = Plan(dev, ar.descs, ar.patches, flags)
+        plan.launch(d_idx, d_hdr, d_pcm, fmt)
+        out = np.zeros(ar.pcm_words, dtype=np.uint16)
+        dev.download(out, d_pcm)
+        st = plan.stats()
+        plan.destroy()
+    finally:
+        dev.free(d_idx)
+        dev.free(d_hdr)
+        dev.free(d_pcm)
+    res = [out[po:po + ne].copy() for (_, _, po, _, ne) in ar.layout]
+    return (res, st) if return_stats else res
+
+
+def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO):
+    """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming)."""
+    n = len(files)
+    bufs = [_as_u8(f) for f in files]
+    infos = [probe(b, force_chans) for b in bufs]
+    outs = [np.zeros(i.total_values if rc == 0 else 0, dtype=np.uint16) for rc, i in infos]
+    items = (BatchItem * max(n, 1))()
+    for k in range(n):
+        items[k].data = bufs[k].ctypes.data
+        items[k].len = bufs[k].size
+        items[k].pcm = outs[k].ctypes.data if outs[k].size else None
+        items[k].pcm_cap = outs[k].size
+    opts = BatchOpts(force_chans, fmt, threads, flags)
+    tm = BatchTiming()
+    _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
+    return [(items[k].status, outs[k][:items[k].words]) for k in range(n)], tm

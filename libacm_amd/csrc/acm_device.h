@@ -1,0 +1,64 @@
+/*
+ * acm_device.h - structures shared between the launch planner (host) and the
+ * HIP kernels.  Internal; the public boundary is include/acm_hip.h.
+ */
+#ifndef ACM_DEVICE_H
+#define ACM_DEVICE_H
+
+#include <stdint.h>
+
+#include "acm_hip.h"
+
+/* per-stream record as the kernels see it */
+struct AcmDevStream {
+	uint64_t idx_off;      /* int16 units to staged row 0 */
+	uint64_t hdr_off;      /* blkhdr units to block 0 */
+	uint64_t pcm_off;      /* int16 units to the first emitted sample */
+	uint64_t n_emit;       /* samples to emit from row_begin*cols */
+	uint64_t scratch_off;  /* stage-wise path: int32 units into the scratch planes */
+	uint32_t level;
+	uint32_t rows;
+	uint32_t nrows;        /* staged rows present */
+	uint32_t row_begin;    /* first emitted row */
+	uint32_t halo_row;     /* first staged row the kernels read: max(row_begin-2, 0) */
+	uint32_t pad;
+};
+
+/* one workgroup of the fused kernel: `T` payload rows starting at row0 */
+struct AcmTile {
+	uint32_t stream;
+	uint32_t row0;
+};
+
+/* resolved H1 patch for the stage-wise path: scratch[dst] = value */
+struct AcmDevPatch {
+	uint64_t dst;
+	int32_t value;
+	uint32_t pad;
+};
+
+/* fused-kernel geometry (must match acm_kernels.hip) */
+#define ACM_K1_MIN_LEVEL 5
+#define ACM_K1_MAX_LEVEL 11
+#define ACM_K1_THREADS   256
+static inline uint32_t acm_k1_tile_elems(uint32_t level) { return level >= 11 ? 32768u : 16384u; }
+static inline uint32_t acm_k1_tile_rows(uint32_t level) { return acm_k1_tile_elems(level) >> level; }   /* incl. 2 halo rows */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
+int acmk_launch_fused(uint32_t level, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
+int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
+		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);
+int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);
+int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
+		      uint32_t level, uint32_t k, const int32_t *d_in, int32_t *d_out, void *stream);
+int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
+		     const int32_t *d_x, int16_t *d_pcm, unsigned fmt, void *stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

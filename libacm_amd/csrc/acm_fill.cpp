@@ -1,0 +1,402 @@
+/*
+ * acm_fill.cpp - sequential bitstream reader + filler parsers -> staged form.
+ * See acm_fill.h.  Reference behaviour being reproduced: /root/reference/src/decode.c
+ * (line numbers below refer to it).
+ */
+#include "acm_fill.h"
+
+#include <string.h>
+
+namespace acmfill {
+
+namespace {
+
+/* One read_func call per refill; the first empty read becomes a single
+ * virtual zero byte (:41-67).  Returns 0 or ACM_ERR_READ_ERR. */
+int pull_chunk(ACMStream *s)
+{
+	if (s->file_eof)
+		return 0;
+	s->buf_start_ofs += s->buf_size;
+	int got = 0;
+	if (s->io.read_func)
+		got = s->io.read_func(s->buf, 1, (int)s->buf_max, s->io_arg);
+	if (got < 0)
+		return ACM_ERR_READ_ERR;
+	if (got == 0) {
+		s->file_eof = 1;
+		s->buf[0] = 0;
+		s->buf_size = 1;
+	} else {
+		s->buf_size = (unsigned)got;
+	}
+	s->buf_pos = 0;
+	return 0;
+}
+
+/* LSB-first bit cursor; the accumulator lives in registers while a block is
+ * being parsed and is written back to the public struct on exit. */
+struct BitCursor {
+	ACMStream *s;
+	uint32_t acc;
+	unsigned avail;
+
+	explicit BitCursor(ACMStream *st) : s(st), acc(st->bit_data), avail(st->bit_avail) {}
+	void commit() const
+	{
+		s->bit_data = acc;
+		s->bit_avail = avail;
+	}
+
+	/* n <= 31; value or negative error */
+	inline int get(unsigned n)
+	{
+		if (avail >= n) {
+			const int v = (int)(acc & ((1u << n) - 1));
+			acc >>= n;
+			avail -= n;
+			return v;
+		}
+		return get_across(n);
+	}
+
+	/* the accumulator does not hold n bits: take what is there and top up from
+	 * the buffer 32 bits at a time (:108-135), refilling the buffer through
+	 * read_func when fewer than 4 bytes remain (:69-106) */
+	__attribute__((noinline)) int get_across(unsigned n)
+	{
+		const uint32_t low = acc;
+		const unsigned have = avail;
+		const unsigned need = n - have;
+		uint32_t word;
+		unsigned wbits;
+		const unsigned left = s->buf_size - s->buf_pos;
+
+		if (left >= 4) {
+			const unsigned char *p = s->buf + s->buf_pos;
+			word = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+			wbits = 32;
+			s->buf_pos += 4;
+		} else {
+			word = 0;
+			wbits = 0;
+			for (unsigned i = 0; i < left; i++, wbits += 8)
+				word |= (uint32_t)s->buf[s->buf_pos + i] << wbits;
+			const int rc = pull_chunk(s);
+			if (rc < 0)
+				return rc;              /* accumulator untouched, as in the reference */
+			while (wbits < 32 && s->buf_pos != s->buf_size) {
+				word |= (uint32_t)s->buf[s->buf_pos++] << wbits;
+				wbits += 8;
+			}
+			acc = word;                     /* the old partial bits are dropped even on failure */
+			avail = wbits;
+			if (wbits < need)
+				return ACM_ERR_UNEXPECTED_EOF;
+		}
+		const int v = (int)(low | ((word & ((1u << need) - 1)) << have));
+		acc = word >> need;
+		avail = wbits - need;
+		return v;
+	}
+
+	/* reads where running dry is a legal end of stream (:154-163) */
+	inline int get_or_end(unsigned n)
+	{
+		const int v = get(n);
+		return v == ACM_ERR_UNEXPECTED_EOF ? kCleanEof : v;
+	}
+};
+
+/* largest |index| a filler code can produce; 0xFFFF marks the invalid codes (:480-489) */
+inline unsigned code_reach(unsigned code)
+{
+	static const uint16_t reach[32] = {
+		0, 0xFFFF, 0xFFFF, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384,
+		32768, 1, 1, 1, 2, 2, 2, 3, 3, 0xFFFF, 4, 4, 0xFFFF, 5, 0xFFFF, 0xFFFF
+	};
+	return reach[code];
+}
+
+#define TAKE(var, n) do { const int t_ = bc.get(n); if (t_ < 0) return t_; (var) = (unsigned)t_; } while (0)
+
+/* symbol tables of the k-fillers (:168-171) */
+const int8_t kSign1[2] = { -1, 1 };
+const int8_t kNear2[4] = { -2, -1, 1, 2 };
+const int8_t kFar2[4] = { -3, -2, 2, 3 };
+const int8_t kWide3[8] = { -4, -3, -2, -1, 1, 2, 3, 4 };
+
+/*
+ * One column.  `col` points at idx[0*cols + c]; consecutive rows are `pitch`
+ * apart.  Mirrors the per-filler bit grammar of :181-476; returns 1 or <0.
+ */
+int parse_column(BitCursor &bc, unsigned code, unsigned rows, int16_t *col, size_t pitch)
+{
+	unsigned r = 0, b;
+
+	if (code == 0) {                                        /* all zero, no payload */
+		for (; r < rows; r++, col += pitch)
+			*col = 0;
+		return 1;
+	}
+	if (code >= 3 && code <= 16) {                          /* fixed-width offset binary */
+		const int mid = 1 << (code - 1);
+		for (; r < rows; r++, col += pitch) {
+			TAKE(b, code);
+			*col = (int16_t)((int)b - mid);
+		}
+		return 1;
+	}
+
+	switch (code) {
+	case 17: case 20: case 23: case 26: {                   /* "0" = two zeros, "10" = zero, "11.." = value */
+		const int tail = (code == 17) ? 1 : (code == 26) ? 3 : 2;
+		while (r < rows) {
+			TAKE(b, 1);
+			if (!b) {
+				col[0] = 0;
+				if (++r >= rows)
+					break;                  /* the second zero would be row `rows` */
+				col[pitch] = 0;
+				++r;
+				col += 2 * pitch;
+				continue;
+			}
+			TAKE(b, 1);
+			int v = 0;
+			if (b) {
+				if (code == 23) {               /* 110s | 111ff */
+					TAKE(b, 1);
+					if (!b) {
+						TAKE(b, 1);
+						v = kSign1[b];
+					} else {
+						TAKE(b, 2);
+						v = kFar2[b];
+					}
+				} else {
+					TAKE(b, (unsigned)tail);
+					v = (code == 17) ? kSign1[b] : (code == 20) ? kNear2[b] : kWide3[b];
+				}
+			}
+			*col = (int16_t)v;
+			col += pitch;
+			++r;
+		}
+		return 1;
+	}
+	case 18: case 21: case 24: case 27: {                   /* "0" = zero, "1.." = value */
+		for (; r < rows; r++, col += pitch) {
+			TAKE(b, 1);
+			int v = 0;
+			if (b) {
+				if (code == 24) {               /* 10s | 11ff */
+					TAKE(b, 1);
+					if (!b) {
+						TAKE(b, 1);
+						v = kSign1[b];
+					} else {
+						TAKE(b, 2);
+						v = kFar2[b];
+					}
+				} else if (code == 18) {
+					TAKE(b, 1);
+					v = kSign1[b];
+				} else if (code == 21) {
+					TAKE(b, 2);
+					v = kNear2[b];
+				} else {
+					TAKE(b, 3);
+					v = kWide3[b];
+				}
+			}
+			*col = (int16_t)v;
+		}
+		return 1;
+	}
+	case 19: case 22: {                                     /* three digits base 3 / base 5 per 5 / 7 bits */
+		const unsigned base = (code == 19) ? 3 : 5, width = (code == 19) ? 5 : 7;
+		const int bias = (int)base / 2;
+		while (r < rows) {
+			TAKE(b, width);
+			if (b >= base * base * base)
+				return ACM_ERR_CORRUPT;
+			for (int k = 0; k < 3 && r < rows; k++, r++, col += pitch) {
+				*col = (int16_t)((int)(b % base) - bias);
+				b /= base;
+			}
+		}
+		return 1;
+	}
+	case 29:                                                /* two digits base 11 per 7 bits */
+		while (r < rows) {
+			TAKE(b, 7);
+			if (b >= 121)
+				return ACM_ERR_CORRUPT;
+			*col = (int16_t)((int)(b % 11) - 5);
+			col += pitch;
+			if (++r >= rows)
+				break;
+			*col = (int16_t)((int)(b / 11) - 5);
+			col += pitch;
+			++r;
+		}
+		return 1;
+	default:                                                /* 1, 2, 25, 28, 30, 31 */
+		return ACM_ERR_CORRUPT;
+	}
+}
+
+#undef TAKE
+
+} // namespace
+
+int32_t TableHistory::stale_value(int idx) const
+{
+	unsigned p = 0;
+	if (idx >= 0) {
+		while (p < 16 && (1 << p) <= idx)       /* smallest p with 2^p > idx */
+			p++;
+	} else {
+		while (p < 16 && (1 << p) < -idx)       /* smallest p with 2^p >= -idx */
+			p++;
+	}
+	const uint32_t v = p < 16 ? val_ge[p] : 0;
+	return (int32_t)((uint32_t)idx * v);
+}
+
+#define HDR(var, n) do { const int t_ = bc.get(n); if (t_ < 0) { bc.commit(); return t_; } (var) = (unsigned)t_; } while (0)
+
+int read_headers(ACMStream *s)
+{
+	BitCursor bc(s);
+	unsigned v, hi;
+
+	HDR(v, 24);
+	if (v == 0x564157) {                                    /* "WAV" (:685) */
+		HDR(v, 8);
+		if (v != 'C') {
+			bc.commit();
+			return ACM_ERR_NOT_ACM;
+		}
+		unsigned w[12];
+		for (int i = 0; i < 12; i++)
+			HDR(w[i], 16);
+		/* only "V1.0" and the 28 in word 6 are checked (:699-706) */
+		if (w[0] != 0x3156 || w[1] != 0x302E || w[6] != 28) {
+			bc.commit();
+			return ACM_ERR_NOT_ACM;
+		}
+		s->wavc_file = 1;
+		HDR(v, 24);
+	}
+	bc.commit();
+	if (v != ACM_ID)
+		return ACM_ERR_NOT_ACM;
+	s->info.acm_id = v;
+	HDR(s->info.acm_version, 8);
+	bc.commit();
+	if (s->info.acm_version != 1)
+		return ACM_ERR_NOT_ACM;
+	HDR(s->total_values, 16);
+	HDR(hi, 16);
+	bc.commit();
+	s->total_values += hi << 16;
+	if (s->total_values == 0)
+		return ACM_ERR_NOT_ACM;
+	HDR(s->info.channels, 16);
+	bc.commit();
+	if (s->info.channels < 1 || s->info.channels > 2)
+		return ACM_ERR_NOT_ACM;
+	s->info.acm_channels = s->info.channels;
+	HDR(s->info.rate, 16);
+	bc.commit();
+	if (s->info.rate < 4096)
+		return ACM_ERR_NOT_ACM;
+	HDR(s->info.acm_level, 4);
+	HDR(s->info.acm_rows, 12);
+	bc.commit();
+	if (s->info.acm_rows == 0)
+		return ACM_ERR_NOT_ACM;
+	return 0;
+}
+
+#undef HDR
+
+int parse_block(ACMStream *s, TableHistory *tab, int16_t *idx, acmhip_blkhdr *hdr, PatchSink *sink)
+{
+	BitCursor bc(s);
+	const unsigned rows = s->info.acm_rows;
+	const unsigned cols = s->info.acm_cols;
+	const size_t mark = (sink && sink->out) ? sink->out->size() : 0;
+	const uint64_t mark_count = sink ? sink->count : 0;
+	int rc;
+
+	const int pwr = bc.get_or_end(4);                       /* :588 */
+	if (pwr < 0) {
+		bc.commit();
+		return pwr;
+	}
+	const int val = bc.get_or_end(16);                      /* :589 */
+	if (val < 0) {
+		bc.commit();
+		return val;
+	}
+	tab->note_block((unsigned)pwr, (uint32_t)val);          /* what the table build of :592-600 leaves behind */
+	hdr->val = (uint32_t)val;
+	hdr->pwr = (uint32_t)pwr;
+	const int lim = 1 << pwr;                               /* valid indices: [-lim, lim) */
+
+	for (unsigned c = 0; c < cols; c++) {
+		const int code = bc.get_or_end(5);              /* :496 */
+		if (code < 0) {
+			rc = code;
+			goto fail;
+		}
+		rc = parse_column(bc, (unsigned)code, rows, idx + c, cols);
+		if (rc < 0)
+			goto fail;
+		/* can this code produce an index outside [-lim, lim)?  linear codes span
+		 * [-reach, reach-1], the others are symmetric +-reach */
+		const int reach = (int)code_reach((unsigned)code);
+		if ((code >= 3 && code <= 16) ? (reach > lim) : (reach >= lim)) {
+			/* hazard H1: the column may hold indices the current table does not cover */
+			const int16_t *p = idx + c;
+			for (unsigned r = 0; r < rows; r++, p += cols) {
+				const int v = *p;
+				if (v >= lim || v < -lim) {
+					if (sink) {
+						if (sink->out)
+							sink->out->push_back(acmhip_patch{
+								sink->base_sample + (uint64_t)r * cols + c,
+								tab->stale_value(v), sink->stream });
+						sink->count++;
+					}
+				}
+			}
+		}
+	}
+	bc.commit();
+	return 1;
+
+fail:
+	bc.commit();
+	if (sink) {
+		if (sink->out)
+			sink->out->resize(mark);
+		sink->count = mark_count;
+	}
+	return rc;
+}
+
+void reset_reader(ACMStream *s)
+{
+	s->file_eof = 0;
+	s->buf_pos = 0;
+	s->buf_size = 0;
+	s->bit_avail = 0;
+	s->bit_data = 0;
+	s->buf_start_ofs = 14;                                  /* util.c:239 uses the plain header length even for WAVC */
+}
+
+} // namespace acmfill

@@ -1,0 +1,436 @@
+/*
+ * acm_hip_api.cpp - device handle, memory plumbing and the launch planner
+ * behind include/acm_hip.h.  The kernels are in acm_kernels.hip.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "acm_device.h"
+#include "acm_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+	set_err("%s: %s", what, hipGetErrorString(e));
+	return ACMHIP_ERR_HIP;
+}
+
+#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+} // namespace
+
+struct acmhip_device {
+	int ordinal;
+	hipStream_t stream;
+	bool own_stream;
+};
+
+/* per level: the fused-kernel tile table, or the stage-wise stream list */
+struct LevelGroup {
+	uint32_t level = 0;
+	AcmTile *d_tiles = nullptr;
+	uint32_t ntiles = 0;
+	uint32_t *d_list = nullptr;
+	uint32_t nlist = 0;
+	uint64_t max_elems = 0;     /* stage-wise: longest plane run in the group */
+	uint64_t max_emit = 0;
+};
+
+struct acmhip_plan {
+	acmhip_device *dev = nullptr;
+	AcmDevStream *d_streams = nullptr;
+	std::vector<LevelGroup> fused, stagewise;
+	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
+	uint32_t n_sw_all = 0;
+	uint64_t sw_max_elems = 0;
+	AcmDevPatch *d_patches = nullptr;
+	uint64_t npatches = 0;
+	int32_t *d_plane[2] = { nullptr, nullptr };
+	uint64_t plane_elems = 0;
+	acmhip_plan_stats stats{};
+};
+
+extern "C" const char *acmhip_last_error(void)
+{
+	return g_err;
+}
+
+extern "C" int acmhip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n;
+}
+
+extern "C" int acmhip_device_open(int ordinal, void *hip_stream, acmhip_device **out)
+{
+	if (!out)
+		return ACMHIP_ERR_ARG;
+	int n = acmhip_device_count();
+	if (n <= 0) {
+		set_err("no usable HIP device (hipGetDeviceCount found none); this library has no CPU synthesis path");
+		return ACMHIP_ERR_NO_DEVICE;
+	}
+	if (ordinal < 0 || ordinal >= n) {
+		set_err("device ordinal %d out of range (have %d)", ordinal, n);
+		return ACMHIP_ERR_ARG;
+	}
+	HIPTRY(hipSetDevice(ordinal));
+	acmhip_device *d = new (std::nothrow) acmhip_device;
+	if (!d)
+		return ACMHIP_ERR_NOMEM;
+	d->ordinal = ordinal;
+	d->own_stream = (hip_stream == nullptr);
+	d->stream = (hipStream_t)hip_stream;
+	if (d->own_stream) {
+		hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			delete d;
+			return hip_fail(e, "hipStreamCreateWithFlags");
+		}
+	}
+	*out = d;
+	return ACMHIP_OK;
+}
+
+extern "C" void acmhip_device_close(acmhip_device *dev)
+{
+	if (!dev)
+		return;
+	(void)hipSetDevice(dev->ordinal);
+	(void)hipStreamSynchronize(dev->stream);
+	if (dev->own_stream)
+		(void)hipStreamDestroy(dev->stream);
+	delete dev;
+}
+
+extern "C" int acmhip_device_sync(acmhip_device *dev)
+{
+	if (!dev)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipStreamSynchronize(dev->stream));
+	return ACMHIP_OK;
+}
+
+extern "C" void *acmhip_device_stream(acmhip_device *dev)
+{
+	return dev ? (void *)dev->stream : nullptr;
+}
+
+extern "C" int acmhip_malloc(acmhip_device *dev, size_t bytes, void **dptr)
+{
+	if (!dev || !dptr)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipSetDevice(dev->ordinal));
+	HIPTRY(hipMalloc(dptr, bytes ? bytes : 16));
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_free(acmhip_device *dev, void *dptr)
+{
+	if (!dev)
+		return ACMHIP_ERR_ARG;
+	if (dptr)
+		HIPTRY(hipFree(dptr));
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_host_alloc(size_t bytes, void **hptr)
+{
+	if (!hptr)
+		return ACMHIP_ERR_ARG;
+	if (acmhip_device_count() <= 0) {
+		set_err("no usable HIP device: cannot allocate pinned host memory");
+		return ACMHIP_ERR_NO_DEVICE;
+	}
+	HIPTRY(hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_host_free(void *hptr)
+{
+	if (hptr)
+		HIPTRY(hipHostFree(hptr));
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_upload(acmhip_device *dev, void *dptr, const void *hptr, size_t bytes)
+{
+	if (!dev)
+		return ACMHIP_ERR_ARG;
+	if (bytes)
+		HIPTRY(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, dev->stream));
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_download(acmhip_device *dev, void *hptr, const void *dptr, size_t bytes)
+{
+	if (!dev)
+		return ACMHIP_ERR_ARG;
+	if (bytes)
+		HIPTRY(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, dev->stream));
+	return ACMHIP_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+
+namespace {
+
+template <typename T>
+int to_device(acmhip_device *dev, const std::vector<T> &v, T **out)
+{
+	*out = nullptr;
+	if (v.empty())
+		return ACMHIP_OK;
+	HIPTRY(hipMalloc((void **)out, v.size() * sizeof(T)));
+	HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->stream));
+	/* the host vector dies with the caller: finish the copy now (plan build is not the hot path) */
+	HIPTRY(hipStreamSynchronize(dev->stream));
+	return ACMHIP_OK;
+}
+
+bool fused_ok(const acmhip_stream_desc &s)
+{
+	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL;
+}
+
+} // namespace
+
+extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
+{
+	if (!plan)
+		return;
+	if (plan->dev) {
+		(void)hipSetDevice(plan->dev->ordinal);
+		(void)hipStreamSynchronize(plan->dev->stream);
+	}
+	(void)hipFree(plan->d_streams);
+	for (auto &g : plan->fused)
+		(void)hipFree(g.d_tiles);
+	for (auto &g : plan->stagewise)
+		(void)hipFree(g.d_list);
+	(void)hipFree(plan->d_sw_all);
+	(void)hipFree(plan->d_patches);
+	(void)hipFree(plan->d_plane[0]);
+	(void)hipFree(plan->d_plane[1]);
+	delete plan;
+}
+
+extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *streams, size_t n,
+				  const acmhip_patch *patches, size_t npatches, unsigned flags,
+				  acmhip_plan **out)
+{
+	if (!dev || !out || (n && !streams) || (npatches && !patches) || n > 0xFFFFFFFFull)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipSetDevice(dev->ordinal));
+
+	std::vector<AcmDevStream> ds(n);
+	std::vector<uint8_t> has_patch(n, 0);
+	for (size_t p = 0; p < npatches; p++) {
+		if (patches[p].stream >= n) {
+			set_err("patch %zu names stream %u of %zu", p, patches[p].stream, n);
+			return ACMHIP_ERR_ARG;
+		}
+		has_patch[patches[p].stream] = 1;
+	}
+
+	std::vector<std::vector<AcmTile>> tiles(16);
+	std::vector<std::vector<uint32_t>> lists(16);
+	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
+	std::vector<uint32_t> sw_all;
+	uint64_t plane = 0, sw_max = 0;
+	acmhip_plan_stats st{};
+
+	for (size_t i = 0; i < n; i++) {
+		const acmhip_stream_desc &s = streams[i];
+		if (s.level > 15 || s.rows == 0 || s.rows > 4095 || (s.idx_off & 7) || (s.pcm_off & 7) ||
+		    s.row_begin > s.nrows ||
+		    s.n_emit > ((uint64_t)(s.nrows - s.row_begin) << s.level)) {
+			set_err("stream %zu: invalid descriptor (level %u rows %u nrows %u row_begin %u n_emit %llu idx_off %llu pcm_off %llu)",
+				i, s.level, s.rows, s.nrows, s.row_begin, (unsigned long long)s.n_emit,
+				(unsigned long long)s.idx_off, (unsigned long long)s.pcm_off);
+			return ACMHIP_ERR_ARG;
+		}
+		AcmDevStream &d = ds[i];
+		d.idx_off = s.idx_off;
+		d.hdr_off = s.hdr_off;
+		d.pcm_off = s.pcm_off;
+		d.n_emit = s.n_emit;
+		d.level = s.level;
+		d.rows = s.rows;
+		d.nrows = s.nrows;
+		d.row_begin = s.row_begin;
+		d.halo_row = s.row_begin >= 2 ? s.row_begin - 2 : 0;
+		d.scratch_off = 0;
+		d.pad = 0;
+		st.samples += s.n_emit;
+		if (s.n_emit == 0)
+			continue;
+
+		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s) && !has_patch[i];
+		if (fused) {
+			const uint32_t T = acm_k1_tile_rows(s.level) - 2;
+			const uint64_t cols = 1ull << s.level;
+			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
+			for (uint64_t r = 0; r < emit_rows; r += T)
+				tiles[s.level].push_back(AcmTile{ (uint32_t)i, (uint32_t)(s.row_begin + r) });
+			st.fused_streams++;
+		} else {
+			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
+			d.scratch_off = plane;
+			plane += (elems + 63) & ~63ull;
+			lists[s.level].push_back((uint32_t)i);
+			sw_all.push_back((uint32_t)i);
+			grp_max_elems[s.level] = std::max(grp_max_elems[s.level], elems);
+			grp_max_emit[s.level] = std::max(grp_max_emit[s.level], (uint64_t)s.n_emit);
+			sw_max = std::max(sw_max, elems);
+			st.stagewise_streams++;
+		}
+	}
+
+	/* H1 patches -> plane coordinates */
+	std::vector<AcmDevPatch> dp;
+	for (size_t p = 0; p < npatches; p++) {
+		const AcmDevStream &d = ds[patches[p].stream];
+		const uint64_t first = (uint64_t)d.halo_row << d.level;
+		const uint64_t end = (uint64_t)d.nrows << d.level;
+		if (d.n_emit == 0 || patches[p].sample < first || patches[p].sample >= end)
+			continue;
+		dp.push_back(AcmDevPatch{ d.scratch_off + (patches[p].sample - first), patches[p].value, 0 });
+	}
+
+	acmhip_plan *pl = new (std::nothrow) acmhip_plan;
+	if (!pl)
+		return ACMHIP_ERR_NOMEM;
+	pl->dev = dev;
+	int rc = to_device(dev, ds, &pl->d_streams);
+	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
+		if (!tiles[lv].empty()) {
+			LevelGroup g;
+			g.level = lv;
+			g.ntiles = (uint32_t)tiles[lv].size();
+			rc = to_device(dev, tiles[lv], &g.d_tiles);
+			pl->fused.push_back(g);
+			st.tiles += g.ntiles;
+			st.launches += 1;
+		}
+		if (!lists[lv].empty() && rc == ACMHIP_OK) {
+			LevelGroup g;
+			g.level = lv;
+			g.nlist = (uint32_t)lists[lv].size();
+			g.max_elems = grp_max_elems[lv];
+			g.max_emit = grp_max_emit[lv];
+			rc = to_device(dev, lists[lv], &g.d_list);
+			pl->stagewise.push_back(g);
+			st.launches += lv + 1;          /* stages + emit */
+		}
+	}
+	if (rc == ACMHIP_OK && !sw_all.empty()) {
+		pl->n_sw_all = (uint32_t)sw_all.size();
+		pl->sw_max_elems = sw_max;
+		pl->plane_elems = plane;
+		rc = to_device(dev, sw_all, &pl->d_sw_all);
+		st.launches += 1;                       /* unpack */
+		if (rc == ACMHIP_OK && !dp.empty()) {
+			pl->npatches = dp.size();
+			rc = to_device(dev, dp, &pl->d_patches);
+			st.launches += 1;
+		}
+		for (int b = 0; b < 2 && rc == ACMHIP_OK; b++) {
+			hipError_t e = hipMalloc((void **)&pl->d_plane[b], plane * sizeof(int32_t));
+			if (e != hipSuccess)
+				rc = hip_fail(e, "hipMalloc(stage-wise plane)");
+		}
+	}
+	if (rc != ACMHIP_OK) {
+		acmhip_plan_destroy(pl);
+		return rc;
+	}
+	pl->stats = st;
+	*out = pl;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out)
+{
+	if (!plan || !out)
+		return ACMHIP_ERR_ARG;
+	*out = plan->stats;
+	return ACMHIP_OK;
+}
+
+#define LAUNCHTRY(call) do { int e_ = (call); if (e_ != 0) { \
+	if (e_ > 0) return hip_fail((hipError_t)e_, #call); \
+	set_err("%s: unsupported configuration", #call); return ACMHIP_ERR_ARG; } } while (0)
+
+extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+				  int16_t *d_pcm, unsigned fmt)
+{
+	if (!pl || fmt > 3)
+		return ACMHIP_ERR_ARG;
+	void *st = (void *)pl->dev->stream;
+
+	for (const LevelGroup &g : pl->fused)
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+
+	if (pl->n_sw_all) {
+		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,
+					     d_idx, d_hdr, pl->d_plane[0], st));
+		LAUNCHTRY(acmk_launch_patch(pl->d_patches, pl->npatches, pl->d_plane[0], st));
+		for (const LevelGroup &g : pl->stagewise) {
+			int cur = 0;
+			for (uint32_t k = 0; k < g.level; k++, cur ^= 1)
+				LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
+							    pl->d_plane[cur], pl->d_plane[cur ^ 1], st));
+			LAUNCHTRY(acmk_launch_emit(pl->d_streams, g.d_list, g.nlist, g.max_emit, pl->d_plane[cur],
+						   d_pcm, fmt, st));
+		}
+	}
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_time(acmhip_plan *pl, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+				int16_t *d_pcm, unsigned fmt, int reps, float *ms_total)
+{
+	if (!pl || reps < 1 || !ms_total)
+		return ACMHIP_ERR_ARG;
+	hipEvent_t a, b;
+	HIPTRY(hipEventCreate(&a));
+	HIPTRY(hipEventCreate(&b));
+	HIPTRY(hipEventRecord(a, pl->dev->stream));
+	int rc = ACMHIP_OK;
+	for (int i = 0; i < reps && rc == ACMHIP_OK; i++)
+		rc = acmhip_plan_launch(pl, d_idx, d_hdr, d_pcm, fmt);
+	hipError_t e = hipEventRecord(b, pl->dev->stream);
+	if (e == hipSuccess)
+		e = hipEventSynchronize(b);
+	if (e == hipSuccess)
+		e = hipEventElapsedTime(ms_total, a, b);
+	(void)hipEventDestroy(a);
+	(void)hipEventDestroy(b);
+	if (rc != ACMHIP_OK)
+		return rc;
+	if (e != hipSuccess)
+		return hip_fail(e, "event timing");
+	return ACMHIP_OK;
+}
