@@ -124,9 +124,6 @@ acm_sw_emit(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 constexpr int NT = ACM_K1_THREADS;
 
-/* sign-extended low half of a dword holding two staged int16 indices */
-__device__ __forceinline__ int32_t lo16(int32_t w) { return (int32_t)(int16_t)(uint16_t)((uint32_t)w & 0xFFFFu); }
-
 /* t - 2*z: one VALU op when 25 result bits suffice (level <= 9: the write-out
  * only looks at bits [level, level+16) and every op here is add/shift, so bit
  * i of a result depends on bits <= i of its inputs), else shift+sub. */
@@ -157,6 +154,15 @@ struct StageKind {
 	static constexpr bool N = ((L - 1 - K) % 2) == 0;
 };
 
+/*
+ * LDS layout of the tile: one pad dword after every 64 elements,
+ * addr(m) = m + (m >> 6).  With it every access pattern of every pass is
+ * bank-conflict free for 4-byte accesses: a wave reading residue i of stride
+ * sigma < 64 touches 64/sigma walk segments whose starts are 64*sigma apart -
+ * all on the same banks without the pad, rotated by sigma banks each with it.
+ */
+__device__ __forceinline__ int lds_at(int m) { return m + (m >> 6); }
+
 template <int L, int K0, int G>
 struct PassGeo {
 	static constexpr int COLS = 1 << L;
@@ -165,12 +171,15 @@ struct PassGeo {
 	static constexpr int U = 1 << G;
 	static constexpr int BODY = 2 * U;                      // elements per unrolled body
 	static constexpr int NJ_TOTAL = NELEM / SIGMA;          // walk length of one residue over the tile
-	static constexpr bool MULTI_RES = SIGMA >= NT;          // more residues than threads
+	static constexpr bool MULTI_RES = SIGMA >= NT;          // at least as many residues as threads
 	static constexpr int RPT = MULTI_RES ? SIGMA / NT : 1;  // residues per thread
 	static constexpr int NSEG = MULTI_RES ? 1 : NT / SIGMA; // walk segments per residue
 	static constexpr int NJ = NJ_TOTAL / NSEG;              // walk length per thread
 	static_assert(SIGMA >= 1, "pass exceeds level");
 	static_assert(NJ % BODY == 0 && NJ >= BODY, "segment must be whole bodies");
+	/* LDS offset of walk element u relative to the body's first element (which is
+	 * aligned to BODY*SIGMA, and 64 | BODY*SIGMA or BODY*SIGMA | 64) */
+	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> 6); }
 };
 
 /*
@@ -178,10 +187,13 @@ struct PassGeo {
  * v: in = stage-K0 inputs, out = stage-(K0+G-1) outputs (conventions above).
  * h[t][x], x in [0, 2d): the 2d inputs of stage t that precede this body
  * (d = stride of stage t in walk units = 2^(G-1-t)); updated on exit.
- * bias: 1 for the thread owning residue 0 (the "+1" of decode.c:561-564), else 0.
+ * bias_lo / bias_hi: the "+1" of decode.c:561-564 for the first / second half
+ * of the body (only the thread owning residue 0 of a stage-0 pass passes 1,
+ * and only for rows that exist: history before the stream start is all-zero).
  */
 template <int L, int K0, int G>
-__device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G][1 << G], uint32_t bias)
+__device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G][1 << G],
+					  uint32_t bias_lo, uint32_t bias_hi)
 {
 	constexpr int U = 1 << G, BODY = 2 * U;
 	constexpr bool EXACT32 = (L > 9);
@@ -211,8 +223,10 @@ __device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G
 				else
 					y = (z2 - z0) + (z1 << 1);
 			}
-			if (K0 + t == 0 && (u % ((U / 2) > 0 ? (U / 2) : 1)) == 0)
-				y += (kindN || !beta) ? bias : (0u - bias);
+			if (K0 + t == 0 && (u % ((U / 2) > 0 ? (U / 2) : 1)) == 0) {
+				const uint32_t b = (u < U) ? bias_lo : bias_hi;
+				y += (kindN || !beta) ? b : (0u - b);
+			}
 			v[u] = y;
 		}
 #pragma unroll
@@ -221,83 +235,142 @@ __device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G
 	}
 }
 
-template <int L, int K0, int G>
-__device__ __forceinline__ void fused_pass(uint32_t *tile, const int tid)
+template <int G>
+__device__ __forceinline__ void clear_hist(uint32_t (&h)[G][1 << G])
+{
+#pragma unroll
+	for (int t = 0; t < G; t++)
+#pragma unroll
+		for (int x = 0; x < (1 << G); x++)
+			h[t][x] = 0u;
+}
+
+/*
+ * First pass (stages 0..G-1): inputs come straight from HBM (staged int16
+ * indices, unpacked with the row's val), outputs go to the LDS tile.  A body is
+ * exactly two tile rows of one residue (2^G elements per row).
+ */
+template <int L, int G>
+__device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval, const int16_t *src,
+					   const int row_first, const int nrows, const int tid)
+{
+	using P = PassGeo<L, 0, G>;
+	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA, COLS = P::COLS;
+	constexpr int ROWS_PER_SEG = P::NJ / U;
+
+	auto load_rows = [&](uint32_t (&v)[BODY], int lr0, int i) {
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			const int lr = lr0 + half;
+			const int rho = row_first + lr;
+			const bool ok = (rho >= 0) && (rho < nrows);
+			const int32_t val = rowval[lr];
+			const int16_t *p = src + ((size_t)(ok ? rho : 0) << L) + i;
+#pragma unroll
+			for (int q = 0; q < U; q++) {
+				const int32_t x = ok ? (int32_t)p[q * SIGMA] : 0;
+				v[half * U + q] = (uint32_t)__mul24(x, val);
+			}
+		}
+	};
+	auto bias_of = [&](int lr, int i) -> uint32_t { return (i == 0 && row_first + lr >= 0) ? 1u : 0u; };
+
+#pragma unroll 1
+	for (int r = 0; r < P::RPT; r++) {
+		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
+		const int i = P::MULTI_RES ? tid + r * NT : tid % SIGMA;
+		uint32_t h[G][U];
+		clear_hist<G>(h);
+		const int lr_seg = seg * ROWS_PER_SEG;
+		if (P::NSEG > 1 && seg > 0) {
+			uint32_t w[BODY];
+			load_rows(w, lr_seg - 2, i);
+			pass_body<L, 0, G>(w, h, bias_of(lr_seg - 2, i), bias_of(lr_seg - 1, i));
+		}
+#pragma unroll 1
+		for (int it = 0; it < P::NJ / BODY; it++) {
+			const int lr0 = lr_seg + 2 * it;
+			uint32_t v[BODY];
+			load_rows(v, lr0, i);
+			pass_body<L, 0, G>(v, h, bias_of(lr0, i), bias_of(lr0 + 1, i));
+			uint32_t *o = tile + lds_at(lr0 * COLS + i);
+#pragma unroll
+			for (int u = 0; u < BODY; u++)
+				o[P::off(u)] = v[u];
+		}
+	}
+}
+
+/*
+ * Middle / last passes (stages K0..K0+G-1), in place on the LDS tile.
+ * LAST: the outputs are final values; they are converted to 16-bit samples,
+ * packed two per dword and parked at the start of the thread's own (already
+ * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
+ */
+template <int L, int K0, int G, bool LAST>
+__device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt)
 {
 	using P = PassGeo<L, K0, G>;
 	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA;
+	static_assert(!P::MULTI_RES, "only the first pass may own several residues");
+	static_assert(!LAST || SIGMA == 1, "last pass must end at stride 1");
 
-	if constexpr (P::MULTI_RES) {
-		__syncthreads();
-#pragma unroll 1
-		for (int r = 0; r < P::RPT; r++) {
-			const int i = tid + r * NT;
-			const uint32_t bias = (K0 == 0 && i == 0) ? 1u : 0u;
-			uint32_t h[G][U];
-#pragma unroll
-			for (int t = 0; t < G; t++)
-#pragma unroll
-				for (int x = 0; x < U; x++)
-					h[t][x] = 0u;
-			uint32_t *p = tile + i;
-#pragma unroll 1
-			for (int it = 0; it < P::NJ / BODY; it++, p += BODY * SIGMA) {
-				uint32_t v[BODY];
-#pragma unroll
-				for (int u = 0; u < BODY; u++)
-					v[u] = p[u * SIGMA];
-				pass_body<L, K0, G>(v, h, bias);
-#pragma unroll
-				for (int u = 0; u < BODY; u++)
-					p[u * SIGMA] = v[u];
-			}
-		}
-	} else {
-		const int seg = tid / SIGMA;
-		const int i = tid % SIGMA;
-		const uint32_t bias = (K0 == 0 && i == 0) ? 1u : 0u;
-		uint32_t *p = tile + (size_t)seg * P::NJ * SIGMA + i;
-		uint32_t h[G][U];
-#pragma unroll
-		for (int t = 0; t < G; t++)
-#pragma unroll
-			for (int x = 0; x < U; x++)
-				h[t][x] = 0u;
+	const int seg = tid / SIGMA;
+	const int i = tid % SIGMA;
+	const int m_seg = seg * P::NJ * SIGMA + i;              // first element of this thread's walk
+	uint32_t h[G][U];
+	clear_hist<G>(h);
 
-		/* warm-up: the BODY elements in front of this segment belong to the
-		 * previous segment's owner, who is about to overwrite them in place -
-		 * read them first, then everybody may start walking */
-		__syncthreads();
-		uint32_t w[BODY];
+	/* warm-up: the BODY elements in front of this segment belong to the previous
+	 * segment's owner, who is about to overwrite them in place - read them
+	 * first, then everybody may start walking */
+	__syncthreads();
+	uint32_t w[BODY];
+	{
+		const uint32_t *pw = tile + lds_at(seg ? m_seg - BODY * SIGMA : m_seg);
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
-			w[u] = seg ? p[(u - BODY) * SIGMA] : 0u;
-		__syncthreads();
-		pass_body<L, K0, G>(w, h, seg ? bias : 0u);
+			w[u] = seg ? pw[P::off(u)] : 0u;
+	}
+	__syncthreads();
+	pass_body<L, K0, G>(w, h, 0u, 0u);
 
 #pragma unroll 1
-		for (int it = 0; it < P::NJ / BODY; it++, p += BODY * SIGMA) {
-			uint32_t v[BODY];
+	for (int it = 0; it < P::NJ / BODY; it++) {
+		uint32_t *p = tile + lds_at(m_seg + it * BODY * SIGMA);
+		uint32_t v[BODY];
+#pragma unroll
+		for (int u = 0; u < BODY; u++)
+			v[u] = p[P::off(u)];
+		pass_body<L, K0, G>(v, h, 0u, 0u);
+		if constexpr (!LAST) {
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
-				v[u] = p[u * SIGMA];
-			pass_body<L, K0, G>(v, h, bias);
+				p[P::off(u)] = v[u];
+		} else {
+			uint32_t *o = tile + lds_at(m_seg) + it * (BODY / 2);
 #pragma unroll
-			for (int u = 0; u < BODY; u++)
-				p[u * SIGMA] = v[u];
+			for (int u = 0; u < BODY; u += 2)
+				o[u / 2] = pcm16((int32_t)v[u], L, fmt) | (pcm16((int32_t)v[u + 1], L, fmt) << 16);
 		}
 	}
 }
 
 /* stage grouping per level: G <= 3 keeps a body at 16 elements */
-template <int L> __device__ __forceinline__ void run_passes(uint32_t *tile, int tid);
-template <> __device__ __forceinline__ void run_passes<5>(uint32_t *t, int tid)  { fused_pass<5, 0, 3>(t, tid); fused_pass<5, 3, 2>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<6>(uint32_t *t, int tid)  { fused_pass<6, 0, 3>(t, tid); fused_pass<6, 3, 3>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<7>(uint32_t *t, int tid)  { fused_pass<7, 0, 3>(t, tid); fused_pass<7, 3, 2>(t, tid); fused_pass<7, 5, 2>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<8>(uint32_t *t, int tid)  { fused_pass<8, 0, 3>(t, tid); fused_pass<8, 3, 3>(t, tid); fused_pass<8, 6, 2>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<9>(uint32_t *t, int tid)  { fused_pass<9, 0, 3>(t, tid); fused_pass<9, 3, 3>(t, tid); fused_pass<9, 6, 3>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<10>(uint32_t *t, int tid) { fused_pass<10, 0, 3>(t, tid); fused_pass<10, 3, 3>(t, tid); fused_pass<10, 6, 2>(t, tid); fused_pass<10, 8, 2>(t, tid); }
-template <> __device__ __forceinline__ void run_passes<11>(uint32_t *t, int tid) { fused_pass<11, 0, 3>(t, tid); fused_pass<11, 3, 3>(t, tid); fused_pass<11, 6, 3>(t, tid); fused_pass<11, 9, 2>(t, tid); }
+template <int L> struct Plan;
+#define ACM_PLAN(LV, FIRST_G, ...) \
+	template <> struct Plan<LV> { \
+		static constexpr int G0 = FIRST_G; \
+		static __device__ __forceinline__ void rest(uint32_t *t, int tid, unsigned fmt) { __VA_ARGS__ } \
+	};
+ACM_PLAN(5, 3, lds_pass<5, 3, 2, true>(t, tid, fmt);)
+ACM_PLAN(6, 3, lds_pass<6, 3, 3, true>(t, tid, fmt);)
+ACM_PLAN(7, 3, lds_pass<7, 3, 2, false>(t, tid, fmt); lds_pass<7, 5, 2, true>(t, tid, fmt);)
+ACM_PLAN(8, 3, lds_pass<8, 3, 3, false>(t, tid, fmt); lds_pass<8, 6, 2, true>(t, tid, fmt);)
+ACM_PLAN(9, 3, lds_pass<9, 3, 3, false>(t, tid, fmt); lds_pass<9, 6, 3, true>(t, tid, fmt);)
+ACM_PLAN(10, 3, lds_pass<10, 3, 3, false>(t, tid, fmt); lds_pass<10, 6, 2, false>(t, tid, fmt); lds_pass<10, 8, 2, true>(t, tid, fmt);)
+ACM_PLAN(11, 3, lds_pass<11, 3, 3, false>(t, tid, fmt); lds_pass<11, 6, 3, false>(t, tid, fmt); lds_pass<11, 9, 2, true>(t, tid, fmt);)
+#undef ACM_PLAN
 
 template <int L>
 __global__ void __launch_bounds__(NT)
@@ -308,9 +381,10 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	constexpr int COLS = 1 << L;
 	constexpr int NELEM = (L >= 11) ? 32768 : 16384;
 	constexpr int TR = NELEM / COLS;                        // tile rows incl. 2 halo rows
+	constexpr int NJ_LAST = NELEM / NT;                     // samples per thread in the last pass
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;       // stage 0 wants odd tile rows negated
 
-	__shared__ __attribute__((aligned(16))) uint32_t tile[NELEM];
+	__shared__ uint32_t tile[NELEM + NELEM / 64];
 	__shared__ int32_t rowval[TR];
 
 	const int tid = threadIdx.x;
@@ -332,34 +406,12 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	}
 	__syncthreads();
 
-	/* load + unpack: 8 staged indices (16 B) per lane per step */
-	const int16_t *src = idx + s.idx_off;
-	for (int vec = tid; vec < NELEM / 8; vec += NT) {
-		const int ml = vec * 8;
-		const int lr = ml >> L;
-		const int col = ml & (COLS - 1);
-		const int rho = row_first + lr;
-		int4 raw = make_int4(0, 0, 0, 0);
-		if (rho >= 0 && rho < nrows)
-			raw = *reinterpret_cast<const int4 *>(src + ((size_t)rho << L) + col);
-		const int32_t val = rowval[lr];
-		uint4 lo, hi;
-		lo.x = (uint32_t)__mul24(lo16(raw.x), val);
-		lo.y = (uint32_t)__mul24(raw.x >> 16, val);
-		lo.z = (uint32_t)__mul24(lo16(raw.y), val);
-		lo.w = (uint32_t)__mul24(raw.y >> 16, val);
-		hi.x = (uint32_t)__mul24(lo16(raw.z), val);
-		hi.y = (uint32_t)__mul24(raw.z >> 16, val);
-		hi.z = (uint32_t)__mul24(lo16(raw.w), val);
-		hi.w = (uint32_t)__mul24(raw.w >> 16, val);
-		*reinterpret_cast<uint4 *>(&tile[ml]) = lo;
-		*reinterpret_cast<uint4 *>(&tile[ml + 4]) = hi;
-	}
-
-	run_passes<L>(tile, tid);
+	first_pass<L, Plan<L>::G0>(tile, rowval, idx + s.idx_off, row_first, nrows, tid);
+	Plan<L>::rest(tile, tid, fmt);
 	__syncthreads();
 
-	/* write-out of the payload rows (tile rows 2..TR-1), 8 samples (16 B) per lane per step */
+	/* write-out of the payload rows (tile rows 2..TR-1): 8 samples (16 B) per lane per step,
+	 * gathered from the per-thread parking areas of the last pass */
 	uint16_t *dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
 	for (int vec = tid; vec < (TR - 2) * COLS / 8; vec += NT) {
 		const int ml = 2 * COLS + vec * 8;
@@ -371,23 +423,19 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		const uint64_t g = ((uint64_t)(uint32_t)(rho - (int)s.row_begin) << L) + (uint32_t)col;
 		if (g >= s.n_emit)
 			break;
-		const uint4 a = *reinterpret_cast<const uint4 *>(&tile[ml]);
-		const uint4 b = *reinterpret_cast<const uint4 *>(&tile[ml + 4]);
-		uint32_t w[8];
-		w[0] = pcm16((int32_t)a.x, L, fmt); w[1] = pcm16((int32_t)a.y, L, fmt);
-		w[2] = pcm16((int32_t)a.z, L, fmt); w[3] = pcm16((int32_t)a.w, L, fmt);
-		w[4] = pcm16((int32_t)b.x, L, fmt); w[5] = pcm16((int32_t)b.y, L, fmt);
-		w[6] = pcm16((int32_t)b.z, L, fmt); w[7] = pcm16((int32_t)b.w, L, fmt);
+		const int owner = ml / NJ_LAST;
+		const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
+		uint4 o;
+		o.x = q[0];
+		o.y = q[1];
+		o.z = q[2];
+		o.w = q[3];
 		if (g + 8 <= s.n_emit) {
-			uint4 o;
-			o.x = w[0] | (w[1] << 16);
-			o.y = w[2] | (w[3] << 16);
-			o.z = w[4] | (w[5] << 16);
-			o.w = w[6] | (w[7] << 16);
 			*reinterpret_cast<uint4 *>(dst + g) = o;
 		} else {
+			const uint32_t w[4] = { o.x, o.y, o.z, o.w };
 			for (int e = 0; e < 8 && g + e < s.n_emit; e++)
-				dst[g + e] = (uint16_t)w[e];
+				dst[g + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
 		}
 	}
 }

@@ -1,0 +1,394 @@
+/*
+ * acmtool - command line front end of the MI355X-native ACM decoder.
+ *
+ * Command-line compatible with the reference tool (/root/reference/src/acmtool.c:
+ * option letters :416, messages, WAV layout :193-229, zero padding :293-310,
+ * header patcher :322-362) so that scripts written for it keep working; the
+ * decoding itself goes through libacm.h and therefore through the GPU.
+ *
+ * Extension (no reference counterpart): -B decodes all listed files as ONE
+ * batch on the GPU (acm_batch_decode) instead of one after the other.
+ */
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "acm_hip.h"
+#include "libacm.h"
+
+#define TOOL_BANNER "acmtool - libacm version " LIBACM_VERSION
+#define IO_CHUNK    (16 * 1024)
+
+struct settings {
+	int raw;            /* -r: no WAV header */
+	int force_chans;    /* -m / -s */
+	int no_output;      /* -n */
+	int quiet;          /* -q (also implied by -o -) */
+};
+
+static struct settings cfg;
+
+/* "<name>: Length: m:ss Chans:c(h) Freq:f A:level/rows kbps:k" (reference :51-53) */
+static void print_summary(const char *name, ACMStream *acm)
+{
+	const ACMInfo *inf = acm_info(acm);
+	unsigned secs = acm_time_total(acm) / 1000;
+	int kbps = (int)(acm_bitrate(acm) / 1000);
+
+	if (cfg.quiet)
+		return;
+	printf("%s: Length:%2d:%02d Chans:%d(%d) Freq:%d A:%d/%d kbps:%d\n",
+	       name, secs / 60, secs % 60, acm_channels(acm), acm->info.acm_channels,
+	       acm_rate(acm), inf->acm_level, inf->acm_rows, kbps);
+}
+
+/* ---- RIFF/WAVE header: 44 bytes, PCM, 16 bit ---- */
+static unsigned char *le16(unsigned char *p, unsigned v)
+{
+	p[0] = (unsigned char)(v & 0xFF);
+	p[1] = (unsigned char)((v >> 8) & 0xFF);
+	return p + 2;
+}
+
+static unsigned char *le32(unsigned char *p, unsigned v)
+{
+	return le16(le16(p, v & 0xFFFF), v >> 16);
+}
+
+static unsigned char *tag(unsigned char *p, const char *s)
+{
+	size_t n = strlen(s);
+	memcpy(p, s, n);
+	return p + n;
+}
+
+static int emit_wav_header(FILE *out, ACMStream *acm)
+{
+	unsigned char h[44], *p = h;
+	unsigned chans = acm_channels(acm);
+	unsigned rate = acm_rate(acm);
+	unsigned data = acm_pcm_total(acm) * ACM_WORD * chans;
+
+	p = tag(p, "RIFF");
+	p = le32(p, 4 + 8 + 16 + 8 + data);
+	p = tag(p, "WAVEfmt ");
+	p = le32(p, 16);
+	p = le16(p, 1);                          /* PCM */
+	p = le16(p, chans);
+	p = le32(p, rate);
+	p = le32(p, rate * chans * ACM_WORD);    /* bytes per second */
+	p = le16(p, ACM_WORD * 8 * chans / 8);   /* block align */
+	p = le16(p, ACM_WORD * 8);
+	p = tag(p, "data");
+	p = le32(p, data);
+	return fwrite(h, 1, sizeof(h), out) == sizeof(h) ? 0 : -1;
+}
+
+static char *swap_extension(const char *name, const char *ext)
+{
+	char *out = malloc(strlen(name) + strlen(ext) + 2);
+	char *dot;
+	strcpy(out, name);
+	dot = strrchr(out, '.');
+	if (dot)
+		*dot = 0;
+	strcat(out, ext);
+	return out;
+}
+
+/* pad with silence up to the length the header promised (reference :293-310) */
+static int pad_output(const char *name, FILE *out, char *buf, int done, int total)
+{
+	memset(buf, 0, IO_CHUNK);
+	if (done < total)
+		fprintf(stderr, "%s: adding filler_samples: %d\n", name, total - done);
+	while (done < total) {
+		int n = total - done < IO_CHUNK ? total - done : IO_CHUNK;
+		if (out && (int)fwrite(buf, 1, (size_t)n, out) != n)
+			break;
+		done += n;
+	}
+	return done;
+}
+
+static void decode_one(const char *src, const char *dst)
+{
+	ACMStream *acm;
+	FILE *out = NULL;
+	char *buf;
+	int done = 0, total, got;
+	int err = acm_open_file(&acm, src, cfg.force_chans);
+
+	if (err < 0) {
+		fprintf(stderr, "%s: %s\n", src, acm_strerror(err));
+		return;
+	}
+	if (!cfg.no_output) {
+		if (strcmp(dst, "-") == 0) {
+			out = stdout;
+			cfg.quiet = 1;
+		} else {
+			out = fopen(dst, "wb");
+		}
+		if (!out) {
+			perror(dst);
+			acm_close(acm);
+			return;
+		}
+	}
+	print_summary(src, acm);
+	if (out && !cfg.raw && emit_wav_header(out, acm) < 0) {
+		perror(dst);
+		fclose(out);
+		acm_close(acm);
+		return;
+	}
+
+	buf = malloc(IO_CHUNK);
+	total = (int)(acm_pcm_total(acm) * acm_channels(acm) * ACM_WORD);
+	while (done < total) {
+		got = acm_read_loop(acm, buf, IO_CHUNK / 2, 0, 2, 1);   /* 8 KiB requests, as the reference */
+		if (got == 0)
+			break;
+		if (got < 0) {
+			fprintf(stderr, "%s: %s\n", src, acm_strerror(got));
+			break;
+		}
+		if (out && (int)fwrite(buf, 1, (size_t)got, out) != got) {
+			fprintf(stderr, "%s: write error\n", dst);
+			break;
+		}
+		done += got;
+	}
+	pad_output(src, out, buf, done, total);
+
+	acm_close(acm);
+	if (out)
+		fclose(out);
+	free(buf);
+}
+
+/* -M / -S: rewrite the channel count in the 14-byte header (reference :322-362) */
+static void patch_channels(const char *name, int chans)
+{
+	static const unsigned char magic[4] = { 0x97, 0x28, 0x03, 0x01 };
+	unsigned char hdr[14];
+	int old;
+	FILE *f = fopen(name, "rb+");
+
+	if (!f) {
+		perror(name);
+		return;
+	}
+	if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr)) {
+		fprintf(stderr, "%s: cannot read header\n", name);
+		return;
+	}
+	if (memcmp(hdr, magic, sizeof(magic)) != 0) {
+		fprintf(stderr, "%s: not an ACM file\n", name);
+		return;
+	}
+	old = hdr[8] | (hdr[9] << 8);
+	if (old != 1 && old != 2) {
+		fprintf(stderr, "%s: suspicios number of channels: %d\n", name, old);
+		return;
+	}
+	if (fseek(f, 0, SEEK_SET)) {
+		perror(name);
+		return;
+	}
+	hdr[8] = (unsigned char)chans;
+	if (fwrite(hdr, 1, sizeof(hdr), f) != sizeof(hdr))
+		perror(name);
+	fclose(f);
+}
+
+static void info_one(const char *name)
+{
+	ACMStream *acm;
+	int err = acm_open_file(&acm, name, cfg.force_chans);
+	if (err < 0) {
+		printf("%s: %s\n", name, acm_strerror(err));    /* stdout, like the reference (:375) */
+		return;
+	}
+	print_summary(name, acm);
+	acm_close(acm);
+}
+
+/* -B: all files through one acm_batch_decode() */
+static int slurp(const char *name, unsigned char **data, size_t *len)
+{
+	FILE *f = fopen(name, "rb");
+	long n;
+	if (!f)
+		return -1;
+	fseek(f, 0, SEEK_END);
+	n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	*data = malloc(n > 0 ? (size_t)n : 1);
+	*len = n > 0 ? fread(*data, 1, (size_t)n, f) : 0;
+	fclose(f);
+	return 0;
+}
+
+static int decode_batch(int nfiles, char **names)
+{
+	acm_batch_item *items = calloc((size_t)nfiles, sizeof(*items));
+	acm_batch_opts opts;
+	acm_batch_timing tm;
+	acmhip_device *dev = NULL;
+	int i, rc;
+
+	memset(&opts, 0, sizeof(opts));
+	opts.force_chans = cfg.force_chans;
+	for (i = 0; i < nfiles; i++) {
+		unsigned char *data = NULL;
+		acm_stage_info si;
+		if (slurp(names[i], &data, &items[i].len) < 0) {
+			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(ACM_ERR_OPEN));
+			continue;
+		}
+		items[i].data = data;
+		if (acm_stage_probe(data, items[i].len, cfg.force_chans, &si) == ACM_OK) {
+			items[i].pcm_cap = si.total_values;
+			items[i].pcm = calloc(si.total_values, sizeof(int16_t));   /* zeros = the padding of :293-310 */
+		}
+	}
+	rc = acmhip_device_open(0, NULL, &dev);
+	if (rc == ACMHIP_OK)
+		rc = acm_batch_decode(dev, items, (size_t)nfiles, &opts, &tm);
+	if (rc != ACMHIP_OK) {
+		fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
+		return 1;
+	}
+	for (i = 0; i < nfiles; i++) {
+		acm_batch_item *it = &items[i];
+		char *dst;
+		FILE *out;
+		if (!it->data)
+			continue;
+		if (!it->pcm) {
+			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(it->status));
+			continue;
+		}
+		if (it->status < 0 && it->words == 0)
+			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(it->status));
+		if (!cfg.quiet)
+			printf("%s: Chans:%u Freq:%u A:%u/%u words:%llu/%u\n", names[i], it->channels, it->rate,
+			       it->level, it->rows, (unsigned long long)it->words, it->total_values);
+		if (cfg.no_output)
+			continue;
+		dst = swap_extension(names[i], ".raw");
+		out = fopen(dst, "wb");
+		if (!out) {
+			perror(dst);
+		} else {
+			unsigned whole = it->total_values - it->total_values % (it->channels ? it->channels : 1);
+			fwrite(it->pcm, 2, whole, out);
+			fclose(out);
+		}
+		free(dst);
+	}
+	if (!cfg.quiet)
+		printf("batch: %llu samples, parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
+		       (unsigned long long)tm.samples, tm.stage_s, tm.h2d_s, tm.kernel_s, tm.d2h_s, tm.total_s);
+	acmhip_device_close(dev);
+	return 0;
+}
+
+static void usage(int code)
+{
+	printf("%s\n", TOOL_BANNER);
+	printf("Play:   acmtool -p [-q][-m|-s] acmfile [acmfile ...]\n");
+	printf("Decode: acmtool -d [-q][-m|-s] [-r|-n] -o wavfile acmfile\n");
+	printf("        acmtool -d [-q][-m|-s] [-r|-n] acmfile [acmfile ...]\n");
+	printf("Other:  acmtool -i acmfile [acmfile ...]\n");
+	printf("        acmtool -M|-S acmfile [acmfile ...]\n");
+	printf("Commands:\n");
+	printf("  -p     play file(s)\n");
+	printf("  -d     decode audio into WAV files\n");
+	printf("  -i     show info about ACM files\n");
+	printf("  -M     modify ACM header to have 1 channel\n");
+	printf("  -S     modify ACM header to have 2 channels\n");
+	printf("Switches:\n");
+	printf("  -m     force mono\n");
+	printf("  -s     force stereo (default)\n");
+	printf("  -r     raw output - no wav header\n");
+	printf("  -q     be quiet\n");
+	printf("  -n     no output - for benchmarking\n");
+	printf("  -o FN  output to file, can be used if single source file\n");
+	exit(code);
+}
+
+int main(int argc, char *argv[])
+{
+	enum { CMD_NONE = 0, CMD_PLAY = 1, CMD_DECODE = 2, CMD_INFO = 4, CMD_CHANS = 8 };
+	int cmds = 0, ncmds = 0, set_chans = 0, batch = 0, c, i;
+	const char *outname = NULL;
+
+	while ((c = getopt(argc, argv, "pdiMSqhrmsnvo:B")) != -1) {
+		switch (c) {
+		case 'p': cmds |= CMD_PLAY; break;
+		case 'd': cmds |= CMD_DECODE; break;
+		case 'i': cmds |= CMD_INFO; break;
+		case 'M': cmds |= CMD_CHANS; set_chans = 1; break;
+		case 'S': cmds |= CMD_CHANS; set_chans = 2; break;
+		case 'q': cfg.quiet = 1; break;
+		case 'm': cfg.force_chans = 1; break;
+		case 's': cfg.force_chans = 2; break;
+		case 'r': cfg.raw = 1; break;
+		case 'n': cfg.no_output = 1; break;
+		case 'o': outname = optarg; break;
+		case 'B': batch = 1; break;
+		case 'h': usage(0); break;
+		case 'v':
+			printf("%s\n", TOOL_BANNER);
+			return 0;
+		default:
+			fprintf(stderr, "bad arg: -%c\n", c);
+			usage(1);
+		}
+	}
+	for (i = 1; i <= CMD_CHANS; i <<= 1)
+		ncmds += (cmds & i) != 0;
+	if (ncmds != 1) {
+		fprintf(stderr, "only one command at a time please\n");
+		usage(1);
+	}
+
+	if (cmds == CMD_PLAY) {
+		/* live playback needs libao, which this build never links (reference :479-482) */
+		fprintf(stderr, "For audio output, please compile with libao.\n");
+		return 1;
+	}
+	if (cmds == CMD_INFO) {
+		for (i = optind; i < argc; i++)
+			info_one(argv[i]);
+		return 0;
+	}
+	if (cmds == CMD_CHANS) {
+		for (i = optind; i < argc; i++)
+			patch_channels(argv[i], set_chans);
+		return 0;
+	}
+
+	/* decode */
+	if (optind == argc)
+		usage(1);
+	if (batch)
+		return decode_batch(argc - optind, argv + optind);
+	if (outname) {
+		if (optind + 1 != argc)
+			usage(1);
+		decode_one(argv[optind], outname);
+		return 0;
+	}
+	for (i = optind; i < argc; i++) {
+		char *dst = swap_extension(argv[i], cfg.raw ? ".raw" : ".wav");
+		decode_one(argv[i], dst);
+		free(dst);
+	}
+	return 0;
+}
