@@ -257,46 +257,55 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 	using P = PassGeo<L, 0, G>;
 	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA, COLS = P::COLS;
 	constexpr int ROWS_PER_SEG = P::NJ / U;
+	constexpr int NB = P::NJ / BODY;                        // bodies per walk
+	constexpr bool WARM = P::NSEG > 1;                      // segments > 0 re-run the two rows in front of them
 
-	auto load_rows = [&](uint32_t (&v)[BODY], int lr0, int i) {
-#pragma unroll
-		for (int half = 0; half < 2; half++) {
-			const int lr = lr0 + half;
-			const int rho = row_first + lr;
-			const bool ok = (rho >= 0) && (rho < nrows);
-			const int32_t val = rowval[lr];
-			const int16_t *p = src + ((size_t)(ok ? rho : 0) << L) + i;
-#pragma unroll
-			for (int q = 0; q < U; q++) {
-				const int32_t x = ok ? (int32_t)p[q * SIGMA] : 0;
-				v[half * U + q] = (uint32_t)__mul24(x, val);
-			}
-		}
-	};
-	auto bias_of = [&](int lr, int i) -> uint32_t { return (i == 0 && row_first + lr >= 0) ? 1u : 0u; };
+	/* rowval[lr + 2] = +-val of tile row lr, 0 for rows that do not exist (also lr = -2, -1):
+	 * a missing row is loaded from a clamped address and multiplied by 0, no predication */
+	const int last_row = nrows - 1;
 
 #pragma unroll 1
 	for (int r = 0; r < P::RPT; r++) {
 		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
 		const int i = P::MULTI_RES ? tid + r * NT : tid % SIGMA;
+		const int lr_seg = seg * ROWS_PER_SEG;
+		const int16_t *col = src + i;
+
+		/* every staged index of this walk, issued back to back (one HBM round trip) */
+		int32_t raw[(NB + (WARM ? 1 : 0)) * BODY];
+#pragma unroll
+		for (int b = (WARM ? -1 : 0); b < NB; b++) {
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				const int lr = lr_seg + 2 * b + half;
+				int rho = row_first + lr;
+				rho = rho < 0 ? 0 : (rho > last_row ? last_row : rho);
+				const int16_t *p = col + ((size_t)rho << L);
+#pragma unroll
+				for (int q = 0; q < U; q++)
+					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] = (int32_t)p[q * SIGMA];
+			}
+		}
+
 		uint32_t h[G][U];
 		clear_hist<G>(h);
-		const int lr_seg = seg * ROWS_PER_SEG;
-		if (P::NSEG > 1 && seg > 0) {
-			uint32_t w[BODY];
-			load_rows(w, lr_seg - 2, i);
-			pass_body<L, 0, G>(w, h, bias_of(lr_seg - 2, i), bias_of(lr_seg - 1, i));
-		}
-#pragma unroll 1
-		for (int it = 0; it < P::NJ / BODY; it++) {
-			const int lr0 = lr_seg + 2 * it;
+#pragma unroll
+		for (int b = (WARM ? -1 : 0); b < NB; b++) {
+			const int lr0 = lr_seg + 2 * b;
+			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
 			uint32_t v[BODY];
-			load_rows(v, lr0, i);
-			pass_body<L, 0, G>(v, h, bias_of(lr0, i), bias_of(lr0 + 1, i));
-			uint32_t *o = tile + lds_at(lr0 * COLS + i);
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
-				o[P::off(u)] = v[u];
+				v[u] = (uint32_t)__mul24(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1);
+			const uint32_t b0 = (i == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? 1u : 0u;
+			const uint32_t b1 = (i == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? 1u : 0u;
+			pass_body<L, 0, G>(v, h, b0, b1);
+			if (b >= 0) {
+				uint32_t *o = tile + lds_at(lr0 * COLS + i);
+#pragma unroll
+				for (int u = 0; u < BODY; u++)
+					o[P::off(u)] = v[u];
+			}
 		}
 	}
 }
@@ -335,7 +344,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	__syncthreads();
 	pass_body<L, K0, G>(w, h, 0u, 0u);
 
-#pragma unroll 1
+#pragma unroll
 	for (int it = 0; it < P::NJ / BODY; it++) {
 		uint32_t *p = tile + lds_at(m_seg + it * BODY * SIGMA);
 		uint32_t v[BODY];
@@ -373,7 +382,7 @@ ACM_PLAN(11, 3, lds_pass<11, 3, 3, false>(t, tid, fmt); lds_pass<11, 6, 3, false
 #undef ACM_PLAN
 
 template <int L>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 2)
 acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restrict__ tiles,
 	       const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
 	       int16_t *__restrict__ pcm, unsigned fmt)
@@ -385,7 +394,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;       // stage 0 wants odd tile rows negated
 
 	__shared__ uint32_t tile[NELEM + NELEM / 64];
-	__shared__ int32_t rowval[TR];
+	__shared__ int32_t rowval[TR + 2];                      // [lr + 2]; two leading zeros for the warm-up of segment 0
 
 	const int tid = threadIdx.x;
 	const AcmTile tl = tiles[blockIdx.x];
@@ -394,15 +403,15 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	const int nrows = (int)s.nrows;
 
 	/* per tile row: the block's val (decode.c:589), signed per the stage-0 convention */
-	for (int lr = tid; lr < TR; lr += NT) {
+	for (int lr = tid - 2; lr < TR; lr += NT) {
 		const int rho = row_first + lr;
 		int32_t v = 0;
-		if (rho >= 0 && rho < nrows) {
+		if (lr >= 0 && rho >= 0 && rho < nrows) {
 			v = (int32_t)hdr[s.hdr_off + (uint32_t)rho / s.rows].val;
 			if (NEG_ODD_ROWS && (lr & 1))
 				v = -v;
 		}
-		rowval[lr] = v;
+		rowval[lr + 2] = v;
 	}
 	__syncthreads();
 
