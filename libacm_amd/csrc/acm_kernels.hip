@@ -139,6 +139,14 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	}
 }
 
+/* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
+__device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
+{
+	uint32_t y;
+	asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(y) : "v"(z), "v"(t));
+	return y;
+}
+
 /*
  * Sign folding.  Odd positions of a stage need 2*z1 - (z2+z0); to keep every
  * element-stage at two VALU ops the stages alternate between two conventions:
@@ -162,6 +170,49 @@ struct StageKind {
  * all on the same banks without the pad, rotated by sigma banks each with it.
  */
 __device__ __forceinline__ int lds_at(int m) { return m + (m >> 6); }
+
+/*
+ * Write-out without per-sample shifts where possible.  For level <= 8 the whole
+ * cascade runs on values scaled by 2^(8-level) (the unpack multiplies by
+ * val << (8-level), the "+1" becomes 1 << (8-level); everything is linear mod
+ * 2^32 and only bits [level, level+16) of the result are used, which the
+ * scaling moves to bits [8, 24) - still inside the 25 bits v_mad_i32_i24 keeps
+ * exact).  The 16-bit sample is then bytes 1..2 of the value and two samples
+ * are packed, byte-swapped if asked, by ONE v_perm_b32; unsigned output is one
+ * xor per pair.  Levels 9..11 shift first.
+ */
+template <int L>
+struct OutScale {
+	static constexpr int SHIFT = (L <= 8) ? 8 - L : 0;
+};
+
+struct PcmFmt {
+	uint32_t sel;     /* v_perm_b32 selector */
+	uint32_t flip;    /* xor mask for unsigned output */
+};
+
+template <int L>
+__device__ __forceinline__ PcmFmt make_pcm_fmt(unsigned fmt)
+{
+	PcmFmt f;
+	const bool be = fmt & 1u, uns = fmt & 2u;
+	if (L <= 8)      /* sample = bytes 1,2 of each value: S1 = first value (bytes 0-3), S0 = second (bytes 4-7) */
+		f.sel = be ? 0x05060102u : 0x06050201u;
+	else             /* values already shifted down: sample = bytes 0,1 */
+		f.sel = be ? 0x04050001u : 0x05040100u;
+	f.flip = uns ? (be ? 0x00800080u : 0x80008000u) : 0u;
+	return f;
+}
+
+template <int L>
+__device__ __forceinline__ uint32_t pack_pcm(uint32_t a, uint32_t b, const PcmFmt &f)
+{
+	if (L > 8) {
+		a >>= L;
+		b >>= L;
+	}
+	return __builtin_amdgcn_perm(b, a, f.sel) ^ f.flip;
+}
 
 template <int L, int K0, int G>
 struct PassGeo {
@@ -213,19 +264,19 @@ __device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G
 			const uint32_t z2 = (u >= 2 * d) ? in[u - 2 * d] : h[t][u];
 			const int beta = (u >> pb) & 1;
 			uint32_t y;
+			/* the "+1" rides on the first op (an add3 at worst) */
+			const bool biased = (K0 + t == 0) && (u % ((U / 2) > 0 ? (U / 2) : 1)) == 0;
+			const uint32_t b = biased ? ((u < U) ? bias_lo : bias_hi) : 0u;
 			if (!kindN) {
-				const uint32_t s = z2 + z0;
-				y = beta ? sub_twice<EXACT32>(s, z1) : s + (z1 << 1);
+				/* even: y = (z2+z0+b) + 2*z1;  odd: -y = (z2+z0-b) - 2*z1 */
+				y = beta ? sub_twice<EXACT32>(biased ? z2 + z0 - b : z2 + z0, z1)
+					 : add_twice(biased ? z2 + z0 + b : z2 + z0, z1);
 			} else {
 				const int aneg = (u >> (pb + 1)) & 1;
 				if ((aneg ^ beta) == 0)
-					y = sub_twice<EXACT32>(z0 - z2, z1);
+					y = sub_twice<EXACT32>(biased ? z0 - z2 + b : z0 - z2, z1);
 				else
-					y = (z2 - z0) + (z1 << 1);
-			}
-			if (K0 + t == 0 && (u % ((U / 2) > 0 ? (U / 2) : 1)) == 0) {
-				const uint32_t b = (u < U) ? bias_lo : bias_hi;
-				y += (kindN || !beta) ? b : (0u - b);
+					y = add_twice(biased ? z2 - z0 + b : z2 - z0, z1);
 			}
 			v[u] = y;
 		}
@@ -263,13 +314,15 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 	/* rowval[lr + 2] = +-val of tile row lr, 0 for rows that do not exist (also lr = -2, -1):
 	 * a missing row is loaded from a clamped address and multiplied by 0, no predication */
 	const int last_row = nrows - 1;
+	/* lowest row any lane may touch: segment 0's (zero-weighted) warm-up sits two rows above the tile */
+	const int base_row = row_first - 2 < 0 ? 0 : (row_first - 2 > last_row ? last_row : row_first - 2);
+	const int16_t *tbase = src + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
 
 #pragma unroll 1
 	for (int r = 0; r < P::RPT; r++) {
 		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
 		const int i = P::MULTI_RES ? tid + r * NT : tid % SIGMA;
 		const int lr_seg = seg * ROWS_PER_SEG;
-		const int16_t *col = src + i;
 
 		/* every staged index of this walk, issued back to back (one HBM round trip) */
 		int32_t raw[(NB + (WARM ? 1 : 0)) * BODY];
@@ -280,10 +333,10 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 				const int lr = lr_seg + 2 * b + half;
 				int rho = row_first + lr;
 				rho = rho < 0 ? 0 : (rho > last_row ? last_row : rho);
-				const int16_t *p = col + ((size_t)rho << L);
+				const unsigned off = ((unsigned)(rho - base_row) << L) + (unsigned)i;
 #pragma unroll
 				for (int q = 0; q < U; q++)
-					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] = (int32_t)p[q * SIGMA];
+					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] = (int32_t)tbase[off + q * SIGMA];
 			}
 		}
 
@@ -297,8 +350,9 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
 				v[u] = (uint32_t)__mul24(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1);
-			const uint32_t b0 = (i == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? 1u : 0u;
-			const uint32_t b1 = (i == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? 1u : 0u;
+			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
+			const uint32_t b0 = (i == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? ONE : 0u;
+			const uint32_t b1 = (i == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? ONE : 0u;
 			pass_body<L, 0, G>(v, h, b0, b1);
 			if (b >= 0) {
 				uint32_t *o = tile + lds_at(lr0 * COLS + i);
@@ -327,6 +381,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	const int seg = tid / SIGMA;
 	const int i = tid % SIGMA;
 	const int m_seg = seg * P::NJ * SIGMA + i;              // first element of this thread's walk
+	const PcmFmt pf = make_pcm_fmt<L>(fmt);
 	uint32_t h[G][U];
 	clear_hist<G>(h);
 
@@ -360,7 +415,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			uint32_t *o = tile + lds_at(m_seg) + it * (BODY / 2);
 #pragma unroll
 			for (int u = 0; u < BODY; u += 2)
-				o[u / 2] = pcm16((int32_t)v[u], L, fmt) | (pcm16((int32_t)v[u + 1], L, fmt) << 16);
+				o[u / 2] = pack_pcm<L>(v[u], v[u + 1], pf);
 		}
 	}
 }
@@ -407,7 +462,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		const int rho = row_first + lr;
 		int32_t v = 0;
 		if (lr >= 0 && rho >= 0 && rho < nrows) {
-			v = (int32_t)hdr[s.hdr_off + (uint32_t)rho / s.rows].val;
+			v = (int32_t)(hdr[s.hdr_off + (uint32_t)rho / s.rows].val << OutScale<L>::SHIFT);
 			if (NEG_ODD_ROWS && (lr & 1))
 				v = -v;
 		}
