@@ -64,6 +64,8 @@ def build_hip(force=False):
             if force or _stale(o, [s] + _headers()):
                 cmd = [HIPCC, "-O3", "-g1", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
                        "--offload-arch=" + GFX, "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+                if os.environ.get("ACM_ABLATION"):      # timing-only kernel variants for profiling sessions
+                    cmd.insert(1, "-DACM_ABLATION=1")
                 if s.endswith(".cpp"):
                     cmd.insert(1, "-x")
                     cmd.insert(2, "hip")

@@ -37,18 +37,17 @@ struct AcmDevPatch {
 	uint32_t pad;
 };
 
-/* fused-kernel geometry (must match acm_kernels.hip) */
+/* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
 #define ACM_K1_MAX_LEVEL 11
-#define ACM_K1_THREADS   256
-static inline uint32_t acm_k1_tile_elems(uint32_t level) { return level >= 11 ? 32768u : 16384u; }
-static inline uint32_t acm_k1_tile_rows(uint32_t level) { return acm_k1_tile_elems(level) >> level; }   /* incl. 2 halo rows */
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
-int acmk_launch_fused(uint32_t level, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
+int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */
+int acmk_launch_fused(uint32_t level, int variant, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
 		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);

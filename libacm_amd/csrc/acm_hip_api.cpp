@@ -7,12 +7,15 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "acm_device.h"
 #include "acm_hip.h"
+
+#define ACM_K1_DEFAULT_VARIANT 0
 
 namespace {
 
@@ -65,6 +68,7 @@ struct acmhip_plan {
 	int32_t *d_plane[2] = { nullptr, nullptr };
 	uint64_t plane_elems = 0;
 	acmhip_plan_stats stats{};
+	int variant = 0;                        /* fused-kernel variant the tile tables were cut for */
 };
 
 extern "C" const char *acmhip_last_error(void)
@@ -214,6 +218,17 @@ bool fused_ok(const acmhip_stream_desc &s)
 	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL;
 }
 
+/* tuning knob: ACM_K1_VARIANT=n picks another built-in tile geometry (default: the measured-best one) */
+int pick_variant()
+{
+	int v = ACM_K1_DEFAULT_VARIANT;
+	if (const char *e = getenv("ACM_K1_VARIANT"))
+		v = atoi(e);
+	if (v < 0 || v >= acmk_fused_variants())
+		v = ACM_K1_DEFAULT_VARIANT;
+	return v;
+}
+
 } // namespace
 
 extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
@@ -260,6 +275,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	std::vector<uint32_t> sw_all;
 	uint64_t plane = 0, sw_max = 0;
 	acmhip_plan_stats st{};
+	const int variant = pick_variant();
 
 	for (size_t i = 0; i < n; i++) {
 		const acmhip_stream_desc &s = streams[i];
@@ -289,7 +305,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 
 		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s) && !has_patch[i];
 		if (fused) {
-			const uint32_t T = acm_k1_tile_rows(s.level) - 2;
+			const uint32_t T = (uint32_t)acmk_fused_tile_rows(s.level, variant) - 2;
 			const uint64_t cols = 1ull << s.level;
 			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
 			for (uint64_t r = 0; r < emit_rows; r += T)
@@ -323,6 +339,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	if (!pl)
 		return ACMHIP_ERR_NOMEM;
 	pl->dev = dev;
+	pl->variant = variant;
 	int rc = to_device(dev, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
 		if (!tiles[lv].empty()) {
@@ -391,7 +408,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	void *st = (void *)pl->dev->stream;
 
 	for (const LevelGroup &g : pl->fused)
-		LAUNCHTRY(acmk_launch_fused(g.level, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
 
 	if (pl->n_sw_all) {
 		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,

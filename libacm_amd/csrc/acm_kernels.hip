@@ -122,7 +122,17 @@ acm_sw_emit(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 // fused tile kernel
 // ---------------------------------------------------------------------------
-constexpr int NT = ACM_K1_THREADS;
+/* tile configuration: level, threads per workgroup, tile elements held in LDS */
+template <int L_, int NT_, int NELEM_>
+struct TileCfg {
+	static constexpr int L = L_;
+	static constexpr int NT = NT_;
+	static constexpr int NELEM = NELEM_;
+	static constexpr int COLS = 1 << L_;
+	static constexpr int TR = NELEM_ / COLS;          // tile rows incl. the 2 halo rows
+	static constexpr int NJ_LAST = NELEM_ / NT_;      // samples per thread in the last pass
+	static_assert(TR >= 4 && (TR % 2) == 0, "tile must hold the halo and at least two payload rows");
+};
 
 /* t - 2*z: one VALU op when 25 result bits suffice (level <= 9: the write-out
  * only looks at bits [level, level+16) and every op here is add/shift, so bit
@@ -214,10 +224,12 @@ __device__ __forceinline__ uint32_t pack_pcm(uint32_t a, uint32_t b, const PcmFm
 	return __builtin_amdgcn_perm(b, a, f.sel) ^ f.flip;
 }
 
-template <int L, int K0, int G>
+template <class C, int K0, int G>
 struct PassGeo {
-	static constexpr int COLS = 1 << L;
-	static constexpr int NELEM = (L >= 11) ? 32768 : 16384;
+	static constexpr int L = C::L;
+	static constexpr int NT = C::NT;
+	static constexpr int COLS = C::COLS;
+	static constexpr int NELEM = C::NELEM;
 	static constexpr int SIGMA = COLS >> (K0 + G);          // smallest stride of the pass
 	static constexpr int U = 1 << G;
 	static constexpr int BODY = 2 * U;                      // elements per unrolled body
@@ -296,50 +308,70 @@ __device__ __forceinline__ void clear_hist(uint32_t (&h)[G][1 << G])
 			h[t][x] = 0u;
 }
 
+/* what a workgroup needs to know about one tile (all wave-uniform) */
+struct TileCtx {
+	const int16_t *src;      /* staged row 0 of the stream */
+	const acmhip_blkhdr *hdr;
+	uint16_t *dst;           /* where sample (row_begin, 0) goes */
+	uint64_t n_emit;
+	int row_first;           /* stream row of tile row 0 (may be < 0) */
+	int nrows;
+	int row_begin;
+	uint32_t rows;           /* acm_rows */
+};
+
 /*
  * First pass (stages 0..G-1): inputs come straight from HBM (staged int16
  * indices, unpacked with the row's val), outputs go to the LDS tile.  A body is
- * exactly two tile rows of one residue (2^G elements per row).
+ * exactly two tile rows of one residue (2^G elements per row).  Split in two so
+ * that the loads of the NEXT tile can be in flight while this tile's LDS passes
+ * run: load() only issues global loads into `raw`, compute() consumes them.
  */
-template <int L, int G>
-__device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval, const int16_t *src,
-					   const int row_first, const int nrows, const int tid)
-{
-	using P = PassGeo<L, 0, G>;
-	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA, COLS = P::COLS;
-	constexpr int ROWS_PER_SEG = P::NJ / U;
-	constexpr int NB = P::NJ / BODY;                        // bodies per walk
-	constexpr bool WARM = P::NSEG > 1;                      // segments > 0 re-run the two rows in front of them
+template <class C, int G, int ABL = 0>
+struct FirstPass {
+	using P = PassGeo<C, 0, G>;
+	static constexpr int L = C::L;
+	static constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA, COLS = P::COLS;
+	static constexpr int ROWS_PER_SEG = P::NJ / U;
+	static constexpr int NB = P::NJ / BODY;                 // bodies per walk
+	static constexpr bool WARM = P::NSEG > 1;               // segments > 0 re-run the two rows in front of them
+	static constexpr int NRAW = (NB + (WARM ? 1 : 0)) * BODY;
+	static_assert(P::RPT == 1, "one residue per thread");
 
-	/* rowval[lr + 2] = +-val of tile row lr, 0 for rows that do not exist (also lr = -2, -1):
-	 * a missing row is loaded from a clamped address and multiplied by 0, no predication */
-	const int last_row = nrows - 1;
-	/* lowest row any lane may touch: segment 0's (zero-weighted) warm-up sits two rows above the tile */
-	const int base_row = row_first - 2 < 0 ? 0 : (row_first - 2 > last_row ? last_row : row_first - 2);
-	const int16_t *tbase = src + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
-
-#pragma unroll 1
-	for (int r = 0; r < P::RPT; r++) {
+	/* every staged index of this thread's walk, issued back to back (one HBM round trip).
+	 * Rows that do not exist are read from a clamped address; their rowval is 0. */
+	static __device__ __forceinline__ void load(int32_t (&raw)[NRAW], const TileCtx &t, const int tid)
+	{
 		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
-		const int i = P::MULTI_RES ? tid + r * NT : tid % SIGMA;
+		const int i = P::MULTI_RES ? tid : tid % SIGMA;
 		const int lr_seg = seg * ROWS_PER_SEG;
-
-		/* every staged index of this walk, issued back to back (one HBM round trip) */
-		int32_t raw[(NB + (WARM ? 1 : 0)) * BODY];
+		const int last_row = t.nrows - 1;
+		/* lowest row any lane may touch: segment 0's (zero-weighted) warm-up sits two rows above the tile */
+		const int base_row = t.row_first - 2 < 0 ? 0 : (t.row_first - 2 > last_row ? last_row : t.row_first - 2);
+		const int16_t *tbase = t.src + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
 #pragma unroll
 		for (int b = (WARM ? -1 : 0); b < NB; b++) {
 #pragma unroll
 			for (int half = 0; half < 2; half++) {
 				const int lr = lr_seg + 2 * b + half;
-				int rho = row_first + lr;
+				int rho = t.row_first + lr;
 				rho = rho < 0 ? 0 : (rho > last_row ? last_row : rho);
 				const unsigned off = ((unsigned)(rho - base_row) << L) + (unsigned)i;
 #pragma unroll
 				for (int q = 0; q < U; q++)
-					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] = (int32_t)tbase[off + q * SIGMA];
+					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] =
+						(ABL & 1) ? (int32_t)(off + q) : (int32_t)tbase[off + q * SIGMA];
 			}
 		}
+	}
 
+	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
+	static __device__ __forceinline__ void compute(const int32_t (&raw)[NRAW], uint32_t *tile, const int32_t *rowval,
+						       const int row_first, const int tid)
+	{
+		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
+		const int i = P::MULTI_RES ? tid : tid % SIGMA;
+		const int lr_seg = seg * ROWS_PER_SEG;
 		uint32_t h[G][U];
 		clear_hist<G>(h);
 #pragma unroll
@@ -353,7 +385,8 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
 			const uint32_t b0 = (i == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? ONE : 0u;
 			const uint32_t b1 = (i == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? ONE : 0u;
-			pass_body<L, 0, G>(v, h, b0, b1);
+			if (!(ABL & 4))
+				pass_body<L, 0, G>(v, h, b0, b1);
 			if (b >= 0) {
 				uint32_t *o = tile + lds_at(lr0 * COLS + i);
 #pragma unroll
@@ -362,7 +395,7 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
 			}
 		}
 	}
-}
+};
 
 /*
  * Middle / last passes (stages K0..K0+G-1), in place on the LDS tile.
@@ -370,10 +403,11 @@ __device__ __forceinline__ void first_pass(uint32_t *tile, const int32_t *rowval
  * packed two per dword and parked at the start of the thread's own (already
  * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
  */
-template <int L, int K0, int G, bool LAST>
+template <class C, int K0, int G, bool LAST, int ABL = 0>
 __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt)
 {
-	using P = PassGeo<L, K0, G>;
+	using P = PassGeo<C, K0, G>;
+	constexpr int L = C::L;
 	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA;
 	static_assert(!P::MULTI_RES, "only the first pass may own several residues");
 	static_assert(!LAST || SIGMA == 1, "last pass must end at stride 1");
@@ -397,7 +431,8 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			w[u] = seg ? pw[P::off(u)] : 0u;
 	}
 	__syncthreads();
-	pass_body<L, K0, G>(w, h, 0u, 0u);
+	if (!(ABL & 2))
+		pass_body<L, K0, G>(w, h, 0u, 0u);
 
 #pragma unroll
 	for (int it = 0; it < P::NJ / BODY; it++) {
@@ -406,7 +441,8 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
 			v[u] = p[P::off(u)];
-		pass_body<L, K0, G>(v, h, 0u, 0u);
+		if (!(ABL & 2))
+			pass_body<L, K0, G>(v, h, 0u, 0u);
 		if constexpr (!LAST) {
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
@@ -420,89 +456,281 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	}
 }
 
-/* stage grouping per level: G <= 3 keeps a body at 16 elements */
-template <int L> struct Plan;
-#define ACM_PLAN(LV, FIRST_G, ...) \
-	template <> struct Plan<LV> { \
-		static constexpr int G0 = FIRST_G; \
-		static __device__ __forceinline__ void rest(uint32_t *t, int tid, unsigned fmt) { __VA_ARGS__ } \
-	};
-ACM_PLAN(5, 3, lds_pass<5, 3, 2, true>(t, tid, fmt);)
-ACM_PLAN(6, 3, lds_pass<6, 3, 3, true>(t, tid, fmt);)
-ACM_PLAN(7, 3, lds_pass<7, 3, 2, false>(t, tid, fmt); lds_pass<7, 5, 2, true>(t, tid, fmt);)
-ACM_PLAN(8, 3, lds_pass<8, 3, 3, false>(t, tid, fmt); lds_pass<8, 6, 2, true>(t, tid, fmt);)
-ACM_PLAN(9, 3, lds_pass<9, 3, 3, false>(t, tid, fmt); lds_pass<9, 6, 3, true>(t, tid, fmt);)
-ACM_PLAN(10, 3, lds_pass<10, 3, 3, false>(t, tid, fmt); lds_pass<10, 6, 2, false>(t, tid, fmt); lds_pass<10, 8, 2, true>(t, tid, fmt);)
-ACM_PLAN(11, 3, lds_pass<11, 3, 3, false>(t, tid, fmt); lds_pass<11, 6, 3, false>(t, tid, fmt); lds_pass<11, 9, 2, true>(t, tid, fmt);)
-#undef ACM_PLAN
+/* the passes after the first: stage groups G, Rest... starting at stage K0; the last one emits PCM */
+template <class C, int ABL, int K0, int G, int... Rest>
+__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt)
+{
+	constexpr bool last = sizeof...(Rest) == 0;
+	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
+	lds_pass<C, K0, G, last, ABL>(tile, tid, fmt);
+	if constexpr (!last)
+		run_lds_passes<C, ABL, K0 + G, Rest...>(tile, tid, fmt);
+}
 
-template <int L>
-__global__ void __launch_bounds__(NT, 2)
-acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restrict__ tiles,
+/*
+ * Persistent workgroups: workgroup w handles tiles w, w + gridDim.x, ...  While the LDS passes of tile n
+ * run, the staged indices and block headers of tile n+1 are already on their way from HBM (registers), so
+ * the only exposed memory latency is the very first tile's.
+ * C: tile configuration; G0, Gs...: how the `level` stages are grouped into passes (first pass fed from
+ * HBM, the others in LDS).
+ */
+template <class C, int WAVES_PER_SIMD, int ABL, int G0, int... Gs>
+__global__ void __launch_bounds__(C::NT, WAVES_PER_SIMD)
+acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restrict__ tiles, const uint32_t ntiles,
 	       const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
 	       int16_t *__restrict__ pcm, unsigned fmt)
 {
-	constexpr int COLS = 1 << L;
-	constexpr int NELEM = (L >= 11) ? 32768 : 16384;
-	constexpr int TR = NELEM / COLS;                        // tile rows incl. 2 halo rows
-	constexpr int NJ_LAST = NELEM / NT;                     // samples per thread in the last pass
+	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;       // stage 0 wants odd tile rows negated
+	constexpr int NRV = (TR + 2 + NT - 1) / NT;             // rowval entries per thread
+	using FP = FirstPass<C, G0, ABL>;
 
 	__shared__ uint32_t tile[NELEM + NELEM / 64];
-	__shared__ int32_t rowval[TR + 2];                      // [lr + 2]; two leading zeros for the warm-up of segment 0
+	__shared__ int32_t rowval[2][TR + 2];                   // [buf][lr + 2]; two leading zeros for segment 0's warm-up
 
 	const int tid = threadIdx.x;
-	const AcmTile tl = tiles[blockIdx.x];
-	const AcmDevStream s = streams[tl.stream];
-	const int row_first = (int)tl.row0 - 2;                 // stream row of tile row 0 (may be < 0)
-	const int nrows = (int)s.nrows;
 
-	/* per tile row: the block's val (decode.c:589), signed per the stage-0 convention */
-	for (int lr = tid - 2; lr < TR; lr += NT) {
-		const int rho = row_first + lr;
-		int32_t v = 0;
-		if (lr >= 0 && rho >= 0 && rho < nrows) {
-			v = (int32_t)(hdr[s.hdr_off + (uint32_t)rho / s.rows].val << OutScale<L>::SHIFT);
-			if (NEG_ODD_ROWS && (lr & 1))
-				v = -v;
+	auto fetch_ctx = [&](uint32_t t) -> TileCtx {
+		const AcmTile tl = tiles[t];
+		const AcmDevStream s = streams[tl.stream];
+		TileCtx c;
+		c.src = idx + s.idx_off;
+		c.hdr = hdr + s.hdr_off;
+		c.dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
+		c.n_emit = s.n_emit;
+		c.row_first = (int)tl.row0 - 2;
+		c.nrows = (int)s.nrows;
+		c.row_begin = (int)s.row_begin;
+		c.rows = s.rows;
+		return c;
+	};
+	/* the block's val (decode.c:589) of every tile row, pre-scaled and signed per the stage-0 convention */
+	auto fetch_vals = [&](int32_t (&hv)[NRV], const TileCtx &c) {
+#pragma unroll
+		for (int k = 0; k < NRV; k++) {
+			const int lr = tid + k * NT - 2;
+			const int rho = c.row_first + lr;
+			hv[k] = 0;
+			if (lr >= 0 && lr < TR && rho >= 0 && rho < c.nrows)
+				hv[k] = (int32_t)c.hdr[(uint32_t)rho / c.rows].val;
 		}
-		rowval[lr + 2] = v;
-	}
-	__syncthreads();
-
-	first_pass<L, Plan<L>::G0>(tile, rowval, idx + s.idx_off, row_first, nrows, tid);
-	Plan<L>::rest(tile, tid, fmt);
-	__syncthreads();
-
-	/* write-out of the payload rows (tile rows 2..TR-1): 8 samples (16 B) per lane per step,
-	 * gathered from the per-thread parking areas of the last pass */
-	uint16_t *dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
-	for (int vec = tid; vec < (TR - 2) * COLS / 8; vec += NT) {
-		const int ml = 2 * COLS + vec * 8;
-		const int lr = ml >> L;
-		const int col = ml & (COLS - 1);
-		const int rho = row_first + lr;
-		if (rho >= nrows)
-			break;
-		const uint64_t g = ((uint64_t)(uint32_t)(rho - (int)s.row_begin) << L) + (uint32_t)col;
-		if (g >= s.n_emit)
-			break;
-		const int owner = ml / NJ_LAST;
-		const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
-		uint4 o;
-		o.x = q[0];
-		o.y = q[1];
-		o.z = q[2];
-		o.w = q[3];
-		if (g + 8 <= s.n_emit) {
-			*reinterpret_cast<uint4 *>(dst + g) = o;
-		} else {
-			const uint32_t w[4] = { o.x, o.y, o.z, o.w };
-			for (int e = 0; e < 8 && g + e < s.n_emit; e++)
-				dst[g + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+	};
+	auto store_vals = [&](const int32_t (&hv)[NRV], int32_t *rv) {
+#pragma unroll
+		for (int k = 0; k < NRV; k++) {
+			const int lr = tid + k * NT - 2;
+			if (lr < TR) {
+				int32_t v = (int32_t)((uint32_t)hv[k] << OutScale<L>::SHIFT);
+				if (NEG_ODD_ROWS && (lr & 1))
+					v = -v;
+				rv[lr + 2] = v;
+			}
 		}
+	};
+
+	uint32_t t = blockIdx.x;
+	if (t >= ntiles)
+		return;
+	TileCtx cur = fetch_ctx(t);
+	int32_t raw[FP::NRAW];
+	int32_t hv[NRV];
+	fetch_vals(hv, cur);
+	FP::load(raw, cur, tid);
+	store_vals(hv, rowval[0]);
+	int buf = 0;
+
+	for (;;) {
+		__syncthreads();                                /* rowval[buf] complete; previous write-out done with the tile */
+		FP::compute(raw, tile, rowval[buf], cur.row_first, tid);
+
+		/* prefetch the next tile: context (scalar), headers and staged indices (registers) */
+		const uint32_t tn = t + gridDim.x;
+		const bool more = tn < ntiles;
+		TileCtx nxt = cur;
+		if (more) {
+			nxt = fetch_ctx(tn);
+			fetch_vals(hv, nxt);
+			FP::load(raw, nxt, tid);
+		}
+
+		if (!(ABL & 8))
+			run_lds_passes<C, ABL, G0, Gs...>(tile, tid, fmt);
+		__syncthreads();
+
+		/* write-out of the payload rows (tile rows 2..TR-1): 8 samples (16 B) per lane per step,
+		 * gathered from the per-thread parking areas of the last pass */
+		for (int vec = tid; vec < (TR - 2) * COLS / 8; vec += NT) {
+			const int ml = 2 * COLS + vec * 8;
+			const int lr = ml >> L;
+			const int col = ml & (COLS - 1);
+			const int rho = cur.row_first + lr;
+			if (rho >= cur.nrows)
+				break;
+			const uint64_t g = ((uint64_t)(uint32_t)(rho - cur.row_begin) << L) + (uint32_t)col;
+			if (g >= cur.n_emit)
+				break;
+			const int owner = ml / NJ_LAST;
+			const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
+			uint4 o;
+			o.x = q[0];
+			o.y = q[1];
+			o.z = q[2];
+			o.w = q[3];
+			if ((ABL & 16) && o.x != 0x12345u)
+				continue;
+			if (g + 8 <= cur.n_emit) {
+				*reinterpret_cast<uint4 *>(cur.dst + g) = o;
+			} else {
+				const uint32_t w[4] = { o.x, o.y, o.z, o.w };
+				for (int e = 0; e < 8 && g + e < cur.n_emit; e++)
+					cur.dst[g + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+			}
+		}
+		if (!more)
+			break;
+		store_vals(hv, rowval[buf ^ 1]);
+		cur = nxt;
+		t = tn;
+		buf ^= 1;
 	}
 }
+
+/*
+ * Kernel variants.  variant 0: 256 threads, 64 samples per thread per pass (2 workgroups = 8 waves per CU);
+ * variant 1: 512 threads, 32 samples per thread per pass (16 waves per CU), more and shorter walks.
+ */
+struct FusedEntry {
+	void (*fn)(const AcmDevStream *, const AcmTile *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
+	int threads;
+	int tile_rows;
+	int wg_per_cu;       /* resident workgroups per CU (LDS-limited) */
+};
+
+template <class C, int W, int... Gs>
+constexpr FusedEntry entry() { return FusedEntry{ acm_fused_tile<C, W, 0, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+#ifdef ACM_ABLATION
+/* timing-only builds of the level-7 and level-9 kernels with parts removed (wrong output by design) */
+template <class C, int W, int ABL, int... Gs>
+constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+#endif
+
+#ifdef ACM_ABLATION
+constexpr int NVARIANTS = 12;
+#else
+constexpr int NVARIANTS = 3;
+#endif
+const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		entry<TileCfg<7, 256, 16384>, 2, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		entry<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 512, 16384>, 4, 2, 3>(),
+		entry<TileCfg<6, 512, 16384>, 4, 2, 2, 2>(),
+		entry<TileCfg<7, 512, 16384>, 4, 2, 2, 3>(),
+		entry<TileCfg<8, 512, 16384>, 4, 2, 3, 3>(),
+		entry<TileCfg<9, 512, 16384>, 4, 3, 3, 3>(),
+		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
+		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
+	},
+	{	/* variant 2: 256 threads on half-size tiles, 4 workgroups per CU */
+		entry<TileCfg<5, 256, 8192>, 4, 2, 3>(),
+		entry<TileCfg<6, 256, 8192>, 4, 2, 2, 2>(),
+		entry<TileCfg<7, 256, 8192>, 4, 2, 2, 3>(),
+		entry<TileCfg<8, 256, 8192>, 4, 2, 3, 3>(),
+		entry<TileCfg<9, 256, 8192>, 4, 3, 3, 3>(),
+		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
+		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
+	},
+#ifdef ACM_ABLATION
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 1, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 1, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 2, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 2, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 4, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 4, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 6, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 6, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 8, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 8, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 16, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 16, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 17, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 17, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 23, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 23, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		abl<TileCfg<7, 256, 16384>, 2, 19, 3, 2, 2>(),
+		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl<TileCfg<9, 256, 16384>, 2, 19, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+#endif
+};
 
 inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 {
@@ -518,20 +746,42 @@ inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 
 #define ACMK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-extern "C" int acmk_launch_fused(uint32_t level, const AcmDevStream *d_streams, const AcmTile *d_tiles,
+extern "C" int acmk_fused_variants(void)
+{
+	return NVARIANTS;
+}
+
+extern "C" int acmk_fused_tile_rows(uint32_t level, int variant)
+{
+	if (level < ACM_K1_MIN_LEVEL || level > ACM_K1_MAX_LEVEL || variant < 0 || variant >= NVARIANTS)
+		return 0;
+	return g_fused[variant][level - ACM_K1_MIN_LEVEL].tile_rows;
+}
+
+extern "C" int acmk_launch_fused(uint32_t level, int variant, const AcmDevStream *d_streams, const AcmTile *d_tiles,
 				 uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
 				 int16_t *d_pcm, unsigned fmt, void *stream)
 {
-	hipStream_t st = (hipStream_t)stream;
 	if (ntiles == 0)
 		return 0;
-	switch (level) {
-#define ACMK_CASE(LV) case LV: hipLaunchKernelGGL(acm_fused_tile<LV>, dim3(ntiles), dim3(NT), 0, st, d_streams, d_tiles, d_idx, d_hdr, d_pcm, fmt); break;
-	ACMK_CASE(5) ACMK_CASE(6) ACMK_CASE(7) ACMK_CASE(8) ACMK_CASE(9) ACMK_CASE(10) ACMK_CASE(11)
-#undef ACMK_CASE
-	default:
+	if (level < ACM_K1_MIN_LEVEL || level > ACM_K1_MAX_LEVEL || variant < 0 || variant >= NVARIANTS)
 		return -1;
+	const FusedEntry &e = g_fused[variant][level - ACM_K1_MIN_LEVEL];
+	/* persistent grid: as many workgroups as the chip holds at once (256 CUs), never more than tiles */
+	static int cus = 0;
+	if (!cus) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+			cus = prop.multiProcessorCount;
+		if (cus <= 0)
+			cus = 256;
 	}
+	uint32_t grid = (uint32_t)(cus * e.wg_per_cu);
+	if (grid > ntiles)
+		grid = ntiles;
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream,
+			   d_streams, d_tiles, ntiles, d_idx, d_hdr, d_pcm, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

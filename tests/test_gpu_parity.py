@@ -29,8 +29,8 @@ def check_streams(dev, files, flags=capi.PLAN_AUTO, fmt=capi.FMT_S16LE, force_ch
 @pytest.mark.parametrize("rows", [1, 3, 16, 17, 64])
 def test_fused_matrix(dev, level, rows):
     """fused tile kernel, every supported level x awkward row counts, several blocks (cross-block history)"""
-    nblocks = max(3, (3 * (capi_tile_rows(level) - 2)) // rows + 2)     # span >= 3 tiles
-    nblocks = min(nblocks, 600)
+    nblocks = max(3, (3 * (capi_tile_rows(level) - 2)) // rows + 2)     # span >= 3 tiles of the largest geometry
+    nblocks = min(nblocks, 1600)
     f = make_stream(level * 100 + rows, level, rows, nblocks, cut=5)
     st = check_streams(dev, [f])
     assert st.fused_streams == 1 and st.stagewise_streams == 0
