@@ -42,6 +42,9 @@ typedef struct acmsynth_params {
 	uint32_t single_code;    /* for MIX_SINGLE */
 	uint32_t wavc;           /* 1 = prepend the 28-byte WAVC header */
 	uint32_t allow_out_of_range; /* 1 = let linear widths exceed pwr+1 (H1) */
+	uint32_t prime_table;    /* 1 = block 0 gets pwr 15, so every amplitude-table entry has been written
+	                            before any later block can read a stale one (keeps H1 cases deterministic
+	                            in the reference, whose table starts as uninitialised heap) */
 } acmsynth_params;
 
 /* fill *p with the BASELINE.md section 5 defaults (pwr U[4,12], val U[1,255], speech mix, mono 22050) */

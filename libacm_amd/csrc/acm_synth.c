@@ -263,6 +263,8 @@ size_t acmsynth_generate(const acmsynth_params *p, uint8_t *out, size_t cap)
 
 	for (b = 0; b < p->nblocks; b++) {
 		unsigned pwr = rng_range(&r, p->pwr_min, p->pwr_max);
+		if (b == 0 && p->prime_table)
+			pwr = 15;
 		unsigned val = rng_range(&r, p->val_min, p->val_max);
 		bw_put(&w, pwr, 4);
 		bw_put(&w, val, 16);

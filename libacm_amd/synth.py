@@ -15,7 +15,8 @@ class Params(C.Structure):
                 ("nblocks", C.c_uint32), ("channels", C.c_uint32), ("rate", C.c_uint32),
                 ("total_values", C.c_uint32), ("pwr_min", C.c_uint32), ("pwr_max", C.c_uint32),
                 ("val_min", C.c_uint32), ("val_max", C.c_uint32), ("mix", C.c_uint32),
-                ("single_code", C.c_uint32), ("wavc", C.c_uint32), ("allow_out_of_range", C.c_uint32)]
+                ("single_code", C.c_uint32), ("wavc", C.c_uint32), ("allow_out_of_range", C.c_uint32),
+                ("prime_table", C.c_uint32)]
 
 
 _lib = None

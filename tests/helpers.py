@@ -21,3 +21,56 @@ def oracle_pcm(data, force_chans=0, be=0, sgned=1):
 def fmt_args(fmt):
     """ACMHIP_FMT_* -> (bigendianp, sgned)"""
     return (fmt & 1), (0 if fmt & 2 else 1)
+
+
+def juggle_inputs(level, rows, nblocks=4):
+    """Deterministic raw int32 block matrices for the juggle_block vectors (golden family F9):
+    full-range values, except block 1 which has realistic magnitudes."""
+    rng = np.random.default_rng([0xAC3D, level, rows])
+    cols = 1 << level
+    out = []
+    for b in range(nblocks):
+        blk = rng.integers(-2 ** 31, 2 ** 31 - 1, size=rows * cols, dtype=np.int64).astype(np.int32)
+        if b == 1:
+            blk = (blk >> 14).astype(np.int32)
+        out.append(blk)
+    return out
+
+
+import hashlib
+import json
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_golden = None
+
+
+def golden():
+    global _golden
+    if _golden is None:
+        with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+            _golden = json.load(f)["cases"]
+    return _golden
+
+
+def golden_file(name):
+    with open(os.path.join(GOLDEN_DIR, "acm", name + ".acm"), "rb") as f:
+        return f.read()
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def decode_record(stream_cls_factory, data, force_chans=0, be=0, sgned=1, step=8192, **io_kw):
+    """Decode through any libacm.h-shaped stream wrapper and summarise like make_golden.ref_decode()."""
+    s = stream_cls_factory(data, force_chans, **io_kw)
+    if s.err < 0:
+        return {"open": s.err}
+    pcm, rc = s.decode_all(step, be, sgned)
+    rec = {"open": 0, "status": rc, "words": len(pcm) // 2, "sha256": sha(pcm),
+           "head": [int(x) for x in np.frombuffer(pcm[:128], dtype="<u2")],
+           "tail": [int(x) for x in np.frombuffer(pcm[-128:], dtype="<u2")] if len(pcm) >= 128 else [],
+           "info": s.info(), "raw_tell_end": s.getter("raw_tell")}
+    s.close()
+    return rec

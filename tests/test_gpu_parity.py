@@ -80,7 +80,7 @@ def test_mixed_batch(dev):
 def test_h1_stale_table_patches(dev):
     """indices outside the current table range read the previous blocks' table (hazard H1)"""
     for lv, rows in ((5, 7), (7, 16), (3, 4)):
-        f = make_stream(900 + lv, lv, rows, 8, mix=1, allow_out_of_range=1, pwr_min=0, pwr_max=6)
+        f = make_stream(900 + lv, lv, rows, 8, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
         s = capi.stage_file(f)
         assert s.info.npatches > 0
         check_streams(dev, [f])

@@ -1,0 +1,206 @@
+"""The drop-in libacm.h API of libacm_hip.so against the golden traces of the reference.
+
+CPU part: everything that only needs the host parser (open/close ownership, header errors, getters,
+seeking with decode-and-discard, truncation bookkeeping).  GPU part (-m gpu): the PCM itself."""
+import pytest
+
+import oracle_api as O
+from helpers import decode_record, golden, golden_file, sha
+from libacm_amd import capi
+
+
+def ours(data, force_chans=0, **io_kw):
+    return O.LibacmStream(O.bind_libacm(capi.lib()), data, force_chans, **io_kw)
+
+
+# ------------------------------------------------------------------ CPU
+def test_open_errors_and_ownership():
+    for case in golden()["F6_headers"] + golden()["F5_wavc"]["bad"]:
+        s = ours(golden_file(case["file"]))
+        assert s.err == (case["open"] if case["open"] < 0 else 0), case["file"]
+        if s.err < 0:
+            assert s.io.closed == 0         # on failure the caller keeps its handle (decode.c:817-823)
+        else:
+            s.close()
+            assert s.io.closed == 1         # on success acm_close runs close_func once (decode.c:882-883)
+    capi.lib().acm_close(None)              # acm_close(NULL) is a no-op
+
+
+def test_read_func_contract():
+    s = ours(golden_file("f7_src"))
+    assert s.io.read_calls and all(c == (1, 65536) for c in s.io.read_calls)   # decode.c:51
+    s.close()
+
+
+def test_getters_after_open():
+    g = golden()["F7_api"]["getters"]
+    src = golden_file("f7_src")
+    for label, fc, kw in (("plain", 0, {}), ("force1", 1, {}), ("force2", 2, {}), ("nolen", 0, {"with_length": False})):
+        s = ours(src, fc, **kw)
+        for k, v in g[label].items():
+            got = s.info() if k == "info" else s.getter(k)
+            assert got == v, (label, k, got, v)
+        s.close()
+
+
+def test_seek_and_discard_bookkeeping():
+    """acm_seek_pcm / acm_seek_time / acm_read(NULL) positions, incl. acm_raw_tell (util.c:192-253)"""
+    g = golden()["F7_api"]
+    s = ours(golden_file("f7_src"))
+    for step in g["seeks"]:
+        if step["op"] == "read":
+            rc, _ = s.read(step["arg"], discard=True)
+            assert (rc, s.getter("pcm_tell")) == (step["rc"], step["pcm_tell"]), step
+        else:
+            rc = s.seek_pcm(step["arg"]) if step["op"] == "pcm" else s.seek_time(step["arg"])
+            assert (rc, s.getter("pcm_tell"), s.getter("raw_tell")) == (step["rc"], step["pcm_tell"], step["raw_tell"]), step
+    s.close()
+    s = ours(golden_file("f7_src"), seekable=False)
+    s.read(256, discard=True)
+    assert s.seek_pcm(0) == g["noseek_back"] == -8
+    assert s.seek_pcm(300) == g["noseek_fwd"]
+    s.close()
+    s = ours(golden_file("f7_src"))
+    assert [s.read(64, wordlen=1, discard=True)[0], s.read(64, wordlen=4, discard=True)[0]] == g["bad_wordlen"]
+    s.close()
+
+
+def discard_all(s):
+    words = 0
+    while True:
+        rc, _ = s.read(8192, discard=True, loop=True)
+        if rc <= 0:
+            return words, rc
+        words += rc // 2
+
+
+def test_truncation_every_byte_discard():
+    g = golden()["F4_truncation"]
+    base = golden_file(g["file"])
+    for cut in g["cuts"]:
+        s = ours(base[:cut["len"]])
+        assert s.err == (cut["open"] if cut["open"] < 0 else 0)
+        if s.err == 0:
+            words, rc = discard_all(s)
+            assert (words, rc, s.getter("raw_tell")) == (cut["words"], cut["status"], cut["raw_tell_end"]), cut
+            s.close()
+
+
+def test_short_reads_and_read_errors_discard():
+    g = golden()["F7_api"]
+    src = golden_file("f7_src")
+    for sr in g["short_reads"]:
+        s = ours(src, max_read=sr["max_read"])
+        assert s.err == (sr["open"] if sr["open"] < 0 else 0), sr
+        if s.err == 0:
+            words, rc = discard_all(s)
+            assert (words, rc) == (sr["words"], sr["status"]), sr
+            s.close()
+    for re_ in g["read_errors"]:
+        s = ours(src, fail_read_at=re_["fail_at"])
+        assert s.err == (re_["open"] if re_["open"] < 0 else 0), re_
+        if s.err == 0:
+            words, rc = discard_all(s)
+            assert (words, rc) == (re_["words"], re_["status"]), re_
+            s.close()
+
+
+def test_corrupt_streams_discard():
+    for case in golden()["F3_corrupt"]:
+        s = ours(golden_file(case["file"]))
+        assert s.err == 0
+        words, rc = discard_all(s)
+        assert (words, rc) == (case["words"], case["status"]), case["file"]
+        s.close()
+    gl = golden()["F7_api"]["loop_swallow"]
+    s = ours(golden_file(gl["file"]))
+    assert [s.read(4096, discard=True, loop=True)[0] for _ in range(3)] == gl["rc"]
+    s.close()
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["F1_matrix", "F2_codes", "F3_corrupt", "F6_headers"])
+def test_pcm_families(dev, family):
+    for case in golden()[family]:
+        rec = decode_record(ours, golden_file(case["file"]))
+        for k in ("open", "status", "words", "sha256", "info", "raw_tell_end"):
+            if k in case:
+                assert rec.get(k) == case[k], (case["file"], k)
+
+
+@pytest.mark.gpu
+def test_pcm_truncation_every_byte(dev):
+    g = golden()["F4_truncation"]
+    base = golden_file(g["file"])
+    for cut in g["cuts"]:
+        rec = decode_record(ours, base[:cut["len"]])
+        for k in ("open", "status", "words", "sha256", "raw_tell_end"):
+            assert rec.get(k) == cut[k], (cut["len"], k)
+
+
+@pytest.mark.gpu
+def test_pcm_wavc_and_quirk(dev):
+    g = golden()["F5_wavc"]
+    for k, fc in (("plain", 0), ("wavc", 0), ("wavc_quirk", -1), ("plain_quirk", -1)):
+        rec = decode_record(ours, golden_file(g[k]["file"]), fc)
+        assert (rec["sha256"], rec["words"], rec["info"]) == (g[k]["sha256"], g[k]["words"], g[k]["info"])
+
+
+@pytest.mark.gpu
+def test_pcm_api_traces(dev):
+    g = golden()["F7_api"]
+    src = golden_file("f7_src")
+    s = ours(src)
+    for step in g["reads"]:
+        rc, b = s.read(step["ask"])
+        assert (rc, sha(b), s.getter("pcm_tell"), s.getter("raw_tell"), s.getter("time_tell")) == \
+               (step["rc"], step["sha"], step["pcm_tell"], step["raw_tell"], step["time_tell"]), step
+    s.close()
+    for f in g["formats"]:
+        rec = decode_record(ours, src, be=f["be"], sgned=f["sgned"])
+        assert (rec["sha256"], rec["words"]) == (f["sha256"], f["words"])
+    s = ours(src)
+    for step in g["seeks"]:
+        if step["op"] == "read":
+            rc, b = s.read(step["arg"])
+            assert (rc, sha(b), s.getter("pcm_tell")) == (step["rc"], step["sha"], step["pcm_tell"]), step
+        else:
+            rc = s.seek_pcm(step["arg"]) if step["op"] == "pcm" else s.seek_time(step["arg"])
+            assert (rc, s.getter("pcm_tell"), s.getter("raw_tell")) == (step["rc"], step["pcm_tell"], step["raw_tell"]), step
+    s.close()
+    gl = g["loop_swallow"]
+    s = ours(golden_file(gl["file"]))
+    rc1, b1 = s.read(4096, loop=True)
+    assert [rc1, s.read(4096, loop=True)[0], s.read(4096, loop=True)[0]] == gl["rc"] and sha(b1) == gl["sha"]
+    s.close()
+
+
+@pytest.mark.gpu
+def test_format_switch_mid_stream(dev):
+    """the window is re-synthesised when a caller changes the sample layout between reads"""
+    src = golden_file("f7_src")
+    want = {}
+    for be in (0, 1):
+        for sg in (0, 1):
+            o = O.Oracle(src)
+            want[(be, sg)] = o.read(1 << 20, be=be, sgned=sg, loop=True)[1]
+            o.close()
+    s = ours(src)
+    pos = 0
+    for k, (be, sg) in enumerate([(0, 1), (1, 1), (0, 0), (1, 0), (0, 1), (1, 0)] * 4):
+        rc, b = s.read(40 + 2 * k, be=be, sgned=sg)
+        assert rc > 0 and b == want[(be, sg)][pos:pos + rc]
+        pos += rc
+    s.close()
+
+
+@pytest.mark.gpu
+def test_long_stream_many_windows(dev):
+    """windows grow 64K -> 4M samples; the carry (2 staged rows) must make window seams invisible"""
+    from helpers import make_stream, oracle_pcm
+    for lv, rows, nb in ((7, 16, 4000), (9, 16, 700), (3, 1, 30000), (11, 5, 60), (0, 1, 5000)):
+        f = make_stream(2000 + lv, lv, rows, nb, cut=11)
+        rec = decode_record(ours, f)
+        want, st = oracle_pcm(f)
+        assert rec["words"] == want.size and rec["sha256"] == sha(want.tobytes()) and rec["status"] == st
