@@ -85,6 +85,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7; if the system copy
+    # gets loaded first (through libacm_hip.so's DT_NEEDED) and torch later brings its own, the second one
+    # finds no GPUs.  Importing torch first makes the loader resolve our DT_NEEDED to the copy already mapped.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = _build.build_hip()
     L = C.CDLL(path)
     vp, sz = C.c_void_p, C.c_size_t
