@@ -183,6 +183,17 @@ def main():
     launch_ms = ev_ms / args.steps                         # average duration of one launch (rank 0's own events)
     achieved = batch.samples * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
 
+    # HBM traffic per launch from the committed PMC run of this same command (profiles/run_profile.sh):
+    # bench.py cannot collect counters on itself, so this is the profile's number, not a live one
+    traffic = None
+    try:
+        key = {(7, 16, 1000, 1024): "level7_1024x1000blocks_rows16", (9, 16, 250, 1024): "level9_1024x250blocks_rows16"}.get(
+            (args.level, args.rows, args.blocks, args.streams))
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            traffic = json.load(f)[key]["hbm_bytes_per_launch"] if key else None
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "decoded PCM Msamples/sec over a batch of ACM streams (hot path on HBM-resident staged input)",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -196,8 +207,10 @@ def main():
                    "kernel": "stagewise" if args.stagewise else "fused_tile", "tiles": int(stats.tiles),
                    "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "acm_fused_tile<%d>" % args.level, "launch_ms": round(launch_ms, 4),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+                     "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
+                     "kernel": "acm_fused_tile<TileCfg<%d,...>>" % args.level, "launch_ms": round(launch_ms, 4),
                      "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
 
