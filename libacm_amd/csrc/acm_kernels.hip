@@ -149,6 +149,23 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	}
 }
 
+/* idx * val with both operands inside 24 bits: one full-rate multiply (the compiler otherwise falls back to
+ * the quarter-rate v_mul_lo_u32 when it cannot prove the operand ranges across the prefetch loop) */
+template <bool PAIR>
+__device__ __forceinline__ uint32_t mul_idx_val(uint32_t loaded, int32_t val, int word)
+{
+	/* SDWA: operand 0 = one sign-extended 16-bit word of the loaded register (low word, or either word of a
+	 * 4-byte load holding two adjacent columns), so no extraction / extension op is needed */
+	uint32_t y;
+	if (PAIR && word == 1)
+		asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+		    : "=v"(y) : "v"(loaded), "v"(val));
+	else
+		asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+		    : "=v"(y) : "v"(loaded), "v"(val));
+	return y;
+}
+
 /* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
 __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
@@ -327,71 +344,104 @@ struct TileCtx {
  * that the loads of the NEXT tile can be in flight while this tile's LDS passes
  * run: load() only issues global loads into `raw`, compute() consumes them.
  */
-template <class C, int G, int ABL = 0>
+template <class C, int G, int W, int ABL = 0>
 struct FirstPass {
-	using P = PassGeo<C, 0, G>;
-	static constexpr int L = C::L;
-	static constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA, COLS = P::COLS;
-	static constexpr int ROWS_PER_SEG = P::NJ / U;
-	static constexpr int NB = P::NJ / BODY;                 // bodies per walk
-	static constexpr bool WARM = P::NSEG > 1;               // segments > 0 re-run the two rows in front of them
-	static constexpr int NRAW = (NB + (WARM ? 1 : 0)) * BODY;
-	static_assert(P::RPT == 1, "one residue per thread");
+	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS;
+	static constexpr int U = 1 << G, BODY = 2 * U;
+	static constexpr int SIGMA = COLS >> G;                 // stride between a residue's consecutive columns
+	static constexpr int TPS = SIGMA / W;                   // threads per segment, each owning W adjacent residues
+	static constexpr int NSEG = NT / TPS;                   // row segments per tile
+	static constexpr int RPS = C::TR / NSEG;                // rows per segment
+	static constexpr int NB = RPS / 2;                      // bodies (row pairs) per segment
+	static constexpr bool WARM = NSEG > 1;                  // segments > 0 re-run the two rows in front of them
+	static constexpr int NRAW = (NB + (WARM ? 1 : 0)) * BODY;   // loaded registers: one per (row, q), W samples each
+	static_assert(W == 1 || W == 2, "1 or 2 adjacent columns per lane");
+	static_assert(SIGMA % W == 0 && TPS <= NT && NT % TPS == 0, "segment geometry");
+	static_assert(RPS >= 2 && RPS % 2 == 0 && NSEG * RPS == C::TR, "segments are whole row pairs");
+	/* LDS offset of the residue's q-th column / second row relative to (first row, first column) of the body */
+	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> 6); }
 
-	/* every staged index of this thread's walk, issued back to back (one HBM round trip).
-	 * Rows that do not exist are read from a clamped address; their rowval is 0. */
-	static __device__ __forceinline__ void load(int32_t (&raw)[NRAW], const TileCtx &t, const int tid)
+	/* every staged index of this thread's walk, issued back to back (one HBM round trip): 2-byte loads for
+	 * W = 1, 4-byte loads (two adjacent columns) for W = 2.  Rows that do not exist are read from a clamped
+	 * address; their rowval is 0. */
+	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const TileCtx &t, const int tid)
 	{
-		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
-		const int i = P::MULTI_RES ? tid : tid % SIGMA;
-		const int lr_seg = seg * ROWS_PER_SEG;
+		const int seg = tid / TPS;
+		const int i0 = (tid % TPS) * W;
+		const int lr_seg = seg * RPS;
 		const int last_row = t.nrows - 1;
 		/* lowest row any lane may touch: segment 0's (zero-weighted) warm-up sits two rows above the tile */
 		const int base_row = t.row_first - 2 < 0 ? 0 : (t.row_first - 2 > last_row ? last_row : t.row_first - 2);
-		const int16_t *tbase = t.src + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
+		const uint16_t *tbase = reinterpret_cast<const uint16_t *>(t.src) + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
+		/* interior tile (the common case): every row from row_first-2 to row_first+TR-1 exists, so the
+		 * offsets are lane-constant + compile-time constants; otherwise clamp each row into the stream */
+		const bool interior = (t.row_first >= 2) && (t.row_first + C::TR <= t.nrows);
+		const unsigned lane_off = ((unsigned)(lr_seg + 2) << L) + (unsigned)i0;
 #pragma unroll
 		for (int b = (WARM ? -1 : 0); b < NB; b++) {
 #pragma unroll
 			for (int half = 0; half < 2; half++) {
 				const int lr = lr_seg + 2 * b + half;
-				int rho = t.row_first + lr;
-				rho = rho < 0 ? 0 : (rho > last_row ? last_row : rho);
-				const unsigned off = ((unsigned)(rho - base_row) << L) + (unsigned)i;
+				unsigned off0;
+				if (interior) {
+					off0 = lane_off + (unsigned)((2 * b + half) << L);
+				} else {
+					int rho = t.row_first + lr;
+					rho = rho < 0 ? 0 : (rho > last_row ? last_row : rho);
+					off0 = ((unsigned)(rho - base_row) << L) + (unsigned)i0;
+				}
 #pragma unroll
-				for (int q = 0; q < U; q++)
-					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] =
-						(ABL & 1) ? (int32_t)(off + q) : (int32_t)tbase[off + q * SIGMA];
+				for (int q = 0; q < U; q++) {
+					uint32_t x;
+					if (ABL & 1)
+						x = off0 + q;
+					else if (W == 1)
+						x = tbase[off0 + q * SIGMA];
+					else
+						x = *reinterpret_cast<const uint32_t *>(tbase + off0 + q * SIGMA);
+					raw[(b + (WARM ? 1 : 0)) * BODY + half * U + q] = x;
+				}
 			}
 		}
 	}
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
-	static __device__ __forceinline__ void compute(const int32_t (&raw)[NRAW], uint32_t *tile, const int32_t *rowval,
+	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NRAW], uint32_t *tile, const int32_t *rowval,
 						       const int row_first, const int tid)
 	{
-		const int seg = P::MULTI_RES ? 0 : tid / SIGMA;
-		const int i = P::MULTI_RES ? tid : tid % SIGMA;
-		const int lr_seg = seg * ROWS_PER_SEG;
-		uint32_t h[G][U];
-		clear_hist<G>(h);
+		const int seg = tid / TPS;
+		const int i0 = (tid % TPS) * W;
+		const int lr_seg = seg * RPS;
+		uint32_t h[W][G][U];
+#pragma unroll
+		for (int w = 0; w < W; w++)
+			clear_hist<G>(h[w]);
+		/* the loads were issued a whole tile ago: touching the YOUNGEST one first makes the compiler emit a
+		 * single s_waitcnt vmcnt for all of them instead of one per consumer */
+		asm volatile("" :: "v"(raw[NRAW - 1]));
 #pragma unroll
 		for (int b = (WARM ? -1 : 0); b < NB; b++) {
 			const int lr0 = lr_seg + 2 * b;
 			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
-			uint32_t v[BODY];
-#pragma unroll
-			for (int u = 0; u < BODY; u++)
-				v[u] = (uint32_t)__mul24(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1);
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
-			const uint32_t b0 = (i == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? ONE : 0u;
-			const uint32_t b1 = (i == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? ONE : 0u;
-			if (!(ABL & 4))
-				pass_body<L, 0, G>(v, h, b0, b1);
-			if (b >= 0) {
-				uint32_t *o = tile + lds_at(lr0 * COLS + i);
+			const uint32_t b0 = (i0 == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? ONE : 0u;
+			const uint32_t b1 = (i0 == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? ONE : 0u;
+			uint32_t v[W][BODY];
+#pragma unroll
+			for (int w = 0; w < W; w++) {
 #pragma unroll
 				for (int u = 0; u < BODY; u++)
-					o[P::off(u)] = v[u];
+					v[w][u] = mul_idx_val<W == 2>(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1, w);
+				if (!(ABL & 4))
+					pass_body<L, 0, G>(v[w], h[w], w == 0 ? b0 : 0u, w == 0 ? b1 : 0u);
+			}
+			if (b >= 0) {
+				uint32_t *o = tile + lds_at(lr0 * COLS + i0);
+#pragma unroll
+				for (int u = 0; u < BODY; u++)
+#pragma unroll
+					for (int w = 0; w < W; w++)
+						o[off(u) + w] = v[w][u];
 			}
 		}
 	}
@@ -421,26 +471,43 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 
 	/* warm-up: the BODY elements in front of this segment belong to the previous
 	 * segment's owner, who is about to overwrite them in place - read them
-	 * first, then everybody may start walking */
+	 * first, then everybody may start walking.  Segment 0 reads the zeroed guard
+	 * zone in front of the tile (history before the tile = zeros). */
 	__syncthreads();
 	uint32_t w[BODY];
 	{
-		const uint32_t *pw = tile + lds_at(seg ? m_seg - BODY * SIGMA : m_seg);
+		const uint32_t *pw = tile + lds_at(m_seg - BODY * SIGMA);
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
-			w[u] = seg ? pw[P::off(u)] : 0u;
+			w[u] = pw[P::off(u)];
 	}
 	__syncthreads();
+
+	/* software pipeline: the reads of body k+1 are in flight while body k is computed */
+	constexpr int NBODY = P::NJ / BODY;
+	uint32_t nxt[BODY];
+	{
+		const uint32_t *p0 = tile + lds_at(m_seg);
+#pragma unroll
+		for (int u = 0; u < BODY; u++)
+			nxt[u] = p0[P::off(u)];
+	}
 	if (!(ABL & 2))
 		pass_body<L, K0, G>(w, h, 0u, 0u);
 
 #pragma unroll
-	for (int it = 0; it < P::NJ / BODY; it++) {
+	for (int it = 0; it < NBODY; it++) {
 		uint32_t *p = tile + lds_at(m_seg + it * BODY * SIGMA);
 		uint32_t v[BODY];
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
-			v[u] = p[P::off(u)];
+			v[u] = nxt[u];
+		if (it + 1 < NBODY) {
+			const uint32_t *pn = tile + lds_at(m_seg + (it + 1) * BODY * SIGMA);
+#pragma unroll
+			for (int u = 0; u < BODY; u++)
+				nxt[u] = pn[P::off(u)];
+		}
 		if (!(ABL & 2))
 			pass_body<L, K0, G>(v, h, 0u, 0u);
 		if constexpr (!LAST) {
@@ -455,6 +522,22 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 		}
 	}
 }
+
+#ifdef ACM_STAMPS
+/* diagnostic build only (profiles/ubench/phases.hip): per-workgroup cycle sums of the tile loop's phases */
+__device__ unsigned long long g_acm_stamps[2048][8];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+	unsigned long long t;
+	__builtin_amdgcn_sched_barrier(0);
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	return t;
+}
+#define ACM_STAMP(k) do { const unsigned long long n_ = stamp_now(); acc_[k] += n_ - last_; last_ = n_; } while (0)
+#else
+#define ACM_STAMP(k) do { } while (0)
+#endif
 
 /* the passes after the first: stage groups G, Rest... starting at stage K0; the last one emits PCM */
 template <class C, int ABL, int K0, int G, int... Rest>
@@ -474,7 +557,7 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
  * C: tile configuration; G0, Gs...: how the `level` stages are grouped into passes (first pass fed from
  * HBM, the others in LDS).
  */
-template <class C, int WAVES_PER_SIMD, int ABL, int G0, int... Gs>
+template <class C, int WAVES_PER_SIMD, int ABL, int W0, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WAVES_PER_SIMD)
 acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restrict__ tiles, const uint32_t ntiles,
 	       const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
@@ -483,10 +566,12 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;       // stage 0 wants odd tile rows negated
 	constexpr int NRV = (TR + 2 + NT - 1) / NT;             // rowval entries per thread
-	using FP = FirstPass<C, G0, ABL>;
+	using FP = FirstPass<C, G0, W0, ABL>;
 
-	__shared__ uint32_t tile[NELEM + NELEM / 64];
+	constexpr int GUARD = NELEM / 32 + 64;                  // zeros in front of the tile: segment 0's warm-up reads land here
+	__shared__ uint32_t tile_mem[GUARD + NELEM + NELEM / 64];
 	__shared__ int32_t rowval[2][TR + 2];                   // [buf][lr + 2]; two leading zeros for segment 0's warm-up
+	uint32_t *const tile = tile_mem + GUARD;
 
 	const int tid = threadIdx.x;
 
@@ -531,17 +616,25 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	uint32_t t = blockIdx.x;
 	if (t >= ntiles)
 		return;
+	for (int k = tid; k < GUARD; k += NT)
+		tile_mem[k] = 0u;                               /* never written again */
 	TileCtx cur = fetch_ctx(t);
-	int32_t raw[FP::NRAW];
+	uint32_t raw[FP::NRAW];
 	int32_t hv[NRV];
 	fetch_vals(hv, cur);
 	FP::load(raw, cur, tid);
 	store_vals(hv, rowval[0]);
 	int buf = 0;
+#ifdef ACM_STAMPS
+	unsigned long long acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long last_ = stamp_now();
+#endif
 
 	for (;;) {
 		__syncthreads();                                /* rowval[buf] complete; previous write-out done with the tile */
+		ACM_STAMP(0);
 		FP::compute(raw, tile, rowval[buf], cur.row_first, tid);
+		ACM_STAMP(1);
 
 		/* prefetch the next tile: context (scalar), headers and staged indices (registers) */
 		const uint32_t tn = t + gridDim.x;
@@ -553,39 +646,63 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 			FP::load(raw, nxt, tid);
 		}
 
+		ACM_STAMP(2);
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, G0, Gs...>(tile, tid, fmt);
+		ACM_STAMP(3);
 		__syncthreads();
+		ACM_STAMP(4);
 
 		/* write-out of the payload rows (tile rows 2..TR-1): 8 samples (16 B) per lane per step,
 		 * gathered from the per-thread parking areas of the last pass */
-		for (int vec = tid; vec < (TR - 2) * COLS / 8; vec += NT) {
-			const int ml = 2 * COLS + vec * 8;
-			const int lr = ml >> L;
-			const int col = ml & (COLS - 1);
-			const int rho = cur.row_first + lr;
-			if (rho >= cur.nrows)
-				break;
-			const uint64_t g = ((uint64_t)(uint32_t)(rho - cur.row_begin) << L) + (uint32_t)col;
-			if (g >= cur.n_emit)
-				break;
-			const int owner = ml / NJ_LAST;
-			const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
-			uint4 o;
-			o.x = q[0];
-			o.y = q[1];
-			o.z = q[2];
-			o.w = q[3];
-			if ((ABL & 16) && o.x != 0x12345u)
-				continue;
-			if (g + 8 <= cur.n_emit) {
-				*reinterpret_cast<uint4 *>(cur.dst + g) = o;
+		{
+			constexpr int NVEC = (TR - 2) * COLS / 8;       /* 16-byte pieces of the payload */
+			constexpr int PER_OWNER = NJ_LAST / 8;          /* pieces per parking area */
+			const uint64_t g0 = (uint64_t)(uint32_t)(cur.row_first + 2 - cur.row_begin) << L;   /* first payload sample */
+			const bool whole = (cur.row_first + TR <= cur.nrows) && (g0 + (uint64_t)(TR - 2) * COLS <= cur.n_emit);
+			if (whole) {
+				/* interior tile (the common case): no per-piece checks, 32-bit offsets from a uniform base */
+				uint4 *out = reinterpret_cast<uint4 *>(cur.dst + g0);
+#pragma unroll
+				for (int k = 0; k < (NVEC + NT - 1) / NT; k++) {
+					const int vec = tid + k * NT;
+					if (NVEC % NT == 0 || vec < NVEC) {
+						const int owner = (2 * COLS / 8 + vec) / PER_OWNER;
+						const int piece = (2 * COLS / 8 + vec) % PER_OWNER;
+						const uint32_t *q = tile + lds_at(owner * NJ_LAST) + piece * 4;
+						uint4 o;
+						o.x = q[0];
+						o.y = q[1];
+						o.z = q[2];
+						o.w = q[3];
+						if (!(ABL & 16) || o.x == 0x12345u)
+							out[vec] = o;
+					}
+				}
 			} else {
-				const uint32_t w[4] = { o.x, o.y, o.z, o.w };
-				for (int e = 0; e < 8 && g + e < cur.n_emit; e++)
-					cur.dst[g + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+				for (int vec = tid; vec < NVEC; vec += NT) {
+					const int ml = 2 * COLS + vec * 8;
+					const int lr = ml >> L;
+					const int col = ml & (COLS - 1);
+					const int rho = cur.row_first + lr;
+					if (rho >= cur.nrows)
+						break;
+					const uint64_t g = ((uint64_t)(uint32_t)(rho - cur.row_begin) << L) + (uint32_t)col;
+					if (g >= cur.n_emit)
+						break;
+					const int owner = ml / NJ_LAST;
+					const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
+					const uint32_t w[4] = { q[0], q[1], q[2], q[3] };
+					if (g + 8 <= cur.n_emit) {
+						*reinterpret_cast<uint4 *>(cur.dst + g) = make_uint4(w[0], w[1], w[2], w[3]);
+					} else {
+						for (int e = 0; e < 8 && g + e < cur.n_emit; e++)
+							cur.dst[g + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+					}
+				}
 			}
 		}
+		ACM_STAMP(5);
 		if (!more)
 			break;
 		store_vals(hv, rowval[buf ^ 1]);
@@ -593,6 +710,12 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		t = tn;
 		buf ^= 1;
 	}
+#ifdef ACM_STAMPS
+	if ((tid & 63) == 0 && blockIdx.x < 2048 / 4) {
+		for (int k = 0; k < 8; k++)
+			g_acm_stamps[blockIdx.x * 4 + (tid >> 6) % 4][k] = acc_[k];
+	}
+#endif
 }
 
 /*
@@ -607,17 +730,20 @@ struct FusedEntry {
 };
 
 template <class C, int W, int... Gs>
-constexpr FusedEntry entry() { return FusedEntry{ acm_fused_tile<C, W, 0, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry entry() { return FusedEntry{ acm_fused_tile<C, W, 0, 1, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+/* same with two adjacent columns per lane in the first pass (4-byte HBM loads) */
+template <class C, int W, int... Gs>
+constexpr FusedEntry entry2() { return FusedEntry{ acm_fused_tile<C, W, 0, 2, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-7 and level-9 kernels with parts removed (wrong output by design) */
 template <class C, int W, int ABL, int... Gs>
-constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 12;
+constexpr int NVARIANTS = 14;
 #else
-constexpr int NVARIANTS = 3;
+constexpr int NVARIANTS = 5;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{
@@ -646,6 +772,24 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<9, 256, 8192>, 4, 3, 3, 3>(),
 		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
 		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
+	},
+	{	/* variant 3: variant 0's tiles, first pass with 4-byte HBM loads (two adjacent columns per lane) */
+		entry2<TileCfg<5, 256, 16384>, 2, 1, 2, 2>(),
+		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
+		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
+		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		entry2<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry2<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	},
+	{	/* variant 4: fewer, deeper LDS passes */
+		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
+		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		entry<TileCfg<7, 256, 16384>, 2, 3, 4>(),
+		entry<TileCfg<8, 256, 16384>, 2, 4, 4>(),
+		entry<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
+		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
+		entry<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
 	},
 #ifdef ACM_ABLATION
 	{
