@@ -231,14 +231,15 @@ __device__ __forceinline__ PcmFmt make_pcm_fmt(unsigned fmt)
 	return f;
 }
 
-template <int L>
+template <int L, bool FLIP>
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t a, uint32_t b, const PcmFmt &f)
 {
 	if (L > 8) {
 		a >>= L;
 		b >>= L;
 	}
-	return __builtin_amdgcn_perm(b, a, f.sel) ^ f.flip;
+	const uint32_t p = __builtin_amdgcn_perm(b, a, f.sel);
+	return FLIP ? (p ^ f.flip) : p;                 /* signed output (the common case) skips the xor */
 }
 
 template <class C, int K0, int G>
@@ -453,7 +454,7 @@ struct FirstPass {
  * packed two per dword and parked at the start of the thread's own (already
  * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
  */
-template <class C, int K0, int G, bool LAST, int ABL = 0>
+template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true>
 __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt)
 {
 	using P = PassGeo<C, K0, G>;
@@ -518,7 +519,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			uint32_t *o = tile + lds_at(m_seg) + it * (BODY / 2);
 #pragma unroll
 			for (int u = 0; u < BODY; u += 2)
-				o[u / 2] = pack_pcm<L>(v[u], v[u + 1], pf);
+				o[u / 2] = pack_pcm<L, FLIP>(v[u], v[u + 1], pf);
 		}
 	}
 }
@@ -545,9 +546,14 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
 {
 	constexpr bool last = sizeof...(Rest) == 0;
 	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
-	lds_pass<C, K0, G, last, ABL>(tile, tid, fmt);
-	if constexpr (!last)
+	if constexpr (!last) {
+		lds_pass<C, K0, G, false, ABL>(tile, tid, fmt);
 		run_lds_passes<C, ABL, K0 + G, Rest...>(tile, tid, fmt);
+	} else if (fmt & 2u) {
+		lds_pass<C, K0, G, true, ABL, true>(tile, tid, fmt);    /* unsigned samples */
+	} else {
+		lds_pass<C, K0, G, true, ABL, false>(tile, tid, fmt);
+	}
 }
 
 /*
@@ -719,8 +725,13 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 }
 
 /*
- * Kernel variants.  variant 0: 256 threads, 64 samples per thread per pass (2 workgroups = 8 waves per CU);
- * variant 1: 512 threads, 32 samples per thread per pass (16 waves per CU), more and shorter walks.
+ * Kernel variants (ACM_K1_VARIANT=n picks one; tuning aid, see profiles/sweep_variants.py):
+ *   0  default: per level the fastest measured geometry
+ *   1  256 threads, 16K-element tiles, 2-byte first-pass loads (64 samples per thread per pass)
+ *   2  512 threads (32 samples per thread per pass, 16 waves per CU)
+ *   3  256 threads on half-size tiles (4 workgroups per CU)
+ *   4  as 1 with 4-byte first-pass loads (two adjacent columns per lane)
+ *   5  as 1 with fewer, deeper LDS passes
  */
 struct FusedEntry {
 	void (*fn)(const AcmDevStream *, const AcmTile *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
@@ -741,12 +752,21 @@ constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs.
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 14;
+constexpr int NVARIANTS = 15;
 #else
-constexpr int NVARIANTS = 5;
+constexpr int NVARIANTS = 6;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
-	{
+	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
+		entry2<TileCfg<5, 256, 8192>, 4, 2, 3>(),
+		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
+		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
+		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		entry2<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
+	},
+	{	/* variant 1 */
 		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
 		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
 		entry<TileCfg<7, 256, 16384>, 2, 3, 2, 2>(),
@@ -755,7 +775,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
 		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
 	},
-	{
+	{	/* variant 2 */
 		entry<TileCfg<5, 512, 16384>, 4, 2, 3>(),
 		entry<TileCfg<6, 512, 16384>, 4, 2, 2, 2>(),
 		entry<TileCfg<7, 512, 16384>, 4, 2, 2, 3>(),
@@ -764,7 +784,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
 		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
 	},
-	{	/* variant 2: 256 threads on half-size tiles, 4 workgroups per CU */
+	{	/* variant 3 */
 		entry<TileCfg<5, 256, 8192>, 4, 2, 3>(),
 		entry<TileCfg<6, 256, 8192>, 4, 2, 2, 2>(),
 		entry<TileCfg<7, 256, 8192>, 4, 2, 2, 3>(),
@@ -773,7 +793,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
 		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
 	},
-	{	/* variant 3: variant 0's tiles, first pass with 4-byte HBM loads (two adjacent columns per lane) */
+	{	/* variant 4 */
 		entry2<TileCfg<5, 256, 16384>, 2, 1, 2, 2>(),
 		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
 		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
@@ -782,7 +802,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
 		entry2<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
 	},
-	{	/* variant 4: fewer, deeper LDS passes */
+	{	/* variant 5 */
 		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
 		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
 		entry<TileCfg<7, 256, 16384>, 2, 3, 4>(),
