@@ -437,7 +437,9 @@ struct FirstPass {
 					pass_body<L, 0, G>(v[w], h[w], w == 0 ? b0 : 0u, w == 0 ? b1 : 0u);
 			}
 			if (b >= 0) {
-				uint32_t *o = tile + lds_at(lr0 * COLS + i0);
+				/* rows of a segment start on a multiple of 64 elements: body b sits at a constant offset */
+				static_assert((2 * COLS) % 64 == 0 && (RPS * COLS) % 64 == 0, "row pairs are whole 64-element groups");
+				uint32_t *o = tile + lds_at(lr_seg * COLS + i0) + b * (2 * COLS + 2 * COLS / 64);
 #pragma unroll
 				for (int u = 0; u < BODY; u++)
 #pragma unroll
@@ -467,6 +469,17 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	const int i = tid % SIGMA;
 	const int m_seg = seg * P::NJ * SIGMA + i;              // first element of this thread's walk
 	const PcmFmt pf = make_pcm_fmt<L>(fmt);
+	/* one runtime address per thread; every body of the walk (and the warm-up body in front of it) sits at a
+	 * compile-time offset from it: NJ*SIGMA is a multiple of 64 and bodies never straddle a pad dword */
+	uint32_t *const base = tile + lds_at(m_seg);
+	constexpr int BS = BODY * SIGMA;
+	constexpr bool ALIGNED = (P::NJ * SIGMA) % 64 == 0;     // segments start on a 64-element group (not so for 32-sample walks at stride 1)
+	auto body_ptr = [&](int it) -> uint32_t * {
+		if constexpr (ALIGNED)
+			return base + (it * BS + ((it * BS) >> 6));
+		else
+			return tile + lds_at(m_seg + it * BS);
+	};
 	uint32_t h[G][U];
 	clear_hist<G>(h);
 
@@ -477,7 +490,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	__syncthreads();
 	uint32_t w[BODY];
 	{
-		const uint32_t *pw = tile + lds_at(m_seg - BODY * SIGMA);
+		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= 64 ? BS / 64 : 1)) : tile + lds_at(m_seg - BS);
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
 			w[u] = pw[P::off(u)];
@@ -488,23 +501,22 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	constexpr int NBODY = P::NJ / BODY;
 	uint32_t nxt[BODY];
 	{
-		const uint32_t *p0 = tile + lds_at(m_seg);
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
-			nxt[u] = p0[P::off(u)];
+			nxt[u] = base[P::off(u)];
 	}
 	if (!(ABL & 2))
 		pass_body<L, K0, G>(w, h, 0u, 0u);
 
 #pragma unroll
 	for (int it = 0; it < NBODY; it++) {
-		uint32_t *p = tile + lds_at(m_seg + it * BODY * SIGMA);
+		uint32_t *p = body_ptr(it);
 		uint32_t v[BODY];
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
 			v[u] = nxt[u];
 		if (it + 1 < NBODY) {
-			const uint32_t *pn = tile + lds_at(m_seg + (it + 1) * BODY * SIGMA);
+			const uint32_t *pn = body_ptr(it + 1);
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
 				nxt[u] = pn[P::off(u)];
@@ -516,7 +528,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			for (int u = 0; u < BODY; u++)
 				p[P::off(u)] = v[u];
 		} else {
-			uint32_t *o = tile + lds_at(m_seg) + it * (BODY / 2);
+			uint32_t *o = base + it * (BODY / 2);
 #pragma unroll
 			for (int u = 0; u < BODY; u += 2)
 				o[u / 2] = pack_pcm<L, FLIP>(v[u], v[u + 1], pf);
@@ -672,7 +684,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 #pragma unroll
 				for (int k = 0; k < (NVEC + NT - 1) / NT; k++) {
 					const int vec = tid + k * NT;
-					if (NVEC % NT == 0 || vec < NVEC) {
+					if (k < NVEC / NT || vec < NVEC) {      /* only the last round can be partial */
 						const int owner = (2 * COLS / 8 + vec) / PER_OWNER;
 						const int piece = (2 * COLS / 8 + vec) % PER_OWNER;
 						const uint32_t *q = tile + lds_at(owner * NJ_LAST) + piece * 4;
