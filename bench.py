@@ -199,8 +199,10 @@ def main():
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: %d synthetic mono streams per GPU, acm_level %d, acm_rows %d, "
-                               "%d blocks each" % (args.streams, args.level, args.rows, args.blocks),
+        "config": {"workload": "%s%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each" % (
+                       "BASELINE.json configs[1]: " if (args.streams, args.level, args.rows, args.blocks, args.channels)
+                       == (1024, 7, 16, 1000, 1) else "", args.streams, "mono" if args.channels == 1 else "stereo",
+                       args.level, args.rows, args.blocks),
                    "streams_per_gpu": args.streams, "acm_level": args.level, "acm_rows": args.rows,
                    "blocks_per_stream": args.blocks, "channels": args.channels,
                    "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
