@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-9/level-11 side measurements")
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
+    ap.add_argument("--workload", choices=["uniform", "corpus"], default="uniform",
+                    help="uniform = BASELINE configs[1]-style batch (default); corpus = configs[2]: --files mixed "
+                         "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
+    ap.add_argument("--files", type=int, default=4000)
     return ap.parse_args()
 
 
@@ -158,8 +162,15 @@ def main():
     # ---- stage the workload (untimed): synth -> host bit parsing -> HBM ----
     keep = 0 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 512)
     t0 = time.perf_counter()
-    batch = workload.build_uniform(args.streams, args.level, args.rows, args.blocks, channels=args.channels,
-                                   seed0=rank * args.streams, keep_files=keep)
+    if args.workload == "corpus":
+        # configs[2]/[3]: the SAME corpus whatever N; rank r decodes its longest-first shard of the file list
+        from libacm_amd import batch as fe
+        shapes = workload.corpus_shapes(args.files)
+        mine = fe.shard_longest_first([s["total_values"] for s in shapes], world)[rank]
+        batch = workload.build_corpus(len(mine), shapes=[shapes[i] for i in mine], seed0=0, keep_files=keep)
+    else:
+        batch = workload.build_uniform(args.streams, args.level, args.rows, args.blocks, channels=args.channels,
+                                       seed0=rank * args.streams, keep_files=keep)
     t_stage = time.perf_counter() - t0
     bufs = batch.upload(dev)
     plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
@@ -188,7 +199,7 @@ def main():
     traffic = None
     try:
         key = {(7, 16, 1000, 1024): "level7_1024x1000blocks_rows16", (9, 16, 250, 1024): "level9_1024x250blocks_rows16"}.get(
-            (args.level, args.rows, args.blocks, args.streams))
+            (args.level, args.rows, args.blocks, args.streams)) if args.workload == "uniform" else None
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
             traffic = json.load(f)[key]["hbm_bytes_per_launch"] if key else None
     except Exception:
@@ -198,13 +209,16 @@ def main():
         "metric": "decoded PCM Msamples/sec over a batch of ACM streams (hot path on HBM-resident staged input)",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%s%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each" % (
+        "scaling": "strong" if args.workload == "corpus" else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": ("BASELINE.json configs[2]: %d-file corpus, mixed mono/stereo, acm_level 7-9, 1-60 s at 22050 Hz, "
+                                "sharded by file" % args.files) if args.workload == "corpus" else
+                               "%s%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each" % (
                        "BASELINE.json configs[1]: " if (args.streams, args.level, args.rows, args.blocks, args.channels)
                        == (1024, 7, 16, 1000, 1) else "", args.streams, "mono" if args.channels == 1 else "stereo",
                        args.level, args.rows, args.blocks),
-                   "streams_per_gpu": args.streams, "acm_level": args.level, "acm_rows": args.rows,
-                   "blocks_per_stream": args.blocks, "channels": args.channels,
+                   "streams_per_gpu": len(batch.descs), "acm_level": "7-9" if args.workload == "corpus" else args.level,
+                   "acm_rows": args.rows, "blocks_per_stream": "ragged" if args.workload == "corpus" else args.blocks,
+                   "channels": "1|2" if args.workload == "corpus" else args.channels,
                    "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
                    "kernel": "stagewise" if args.stagewise else "fused_tile", "tiles": int(stats.tiles),
                    "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2)},
@@ -212,7 +226,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": "acm_fused_tile<TileCfg<%d,...>>" % args.level, "launch_ms": round(launch_ms, 4),
+                     "kernel": "acm_fused_tile<TileCfg<%s,...>>" % ("7|8|9" if args.workload == "corpus" else args.level), "launch_ms": round(launch_ms, 4),
                      "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
 

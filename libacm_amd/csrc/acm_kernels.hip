@@ -199,18 +199,20 @@ struct StageKind {
 __device__ __forceinline__ int lds_at(int m) { return m + (m >> 6); }
 
 /*
- * Write-out without per-sample shifts where possible.  For level <= 8 the whole
- * cascade runs on values scaled by 2^(8-level) (the unpack multiplies by
- * val << (8-level), the "+1" becomes 1 << (8-level); everything is linear mod
- * 2^32 and only bits [level, level+16) of the result are used, which the
- * scaling moves to bits [8, 24) - still inside the 25 bits v_mad_i32_i24 keeps
- * exact).  The 16-bit sample is then bytes 1..2 of the value and two samples
- * are packed, byte-swapped if asked, by ONE v_perm_b32; unsigned output is one
- * xor per pair.  Levels 9..11 shift first.
+ * Write-out without per-sample shifts where possible.  The whole cascade is linear mod 2^32 and only bits
+ * [level, level+16) of the result are used, so it may run on values scaled by a power of two (the unpack
+ * multiplies by val << SHIFT, the "+1" becomes 1 << SHIFT) that moves the sample onto a byte boundary:
+ *   level <= 8 : SHIFT = 8 - level, sample = bytes 1..2 - bits [0,24) still inside the 25 bits that the
+ *                one-op v_mad_i32_i24 butterfly keeps exact;
+ *   level == 9 : no scaling (bits 9..24 are needed and 25 is all mad24 gives): two shifts per pair instead;
+ *   level >= 10: these levels use exact 32-bit butterflies anyway, SHIFT = 16 - level, sample = bytes 2..3.
+ * Two samples are then packed, byte-swapped if asked, by ONE v_perm_b32; unsigned output is one xor per pair.
  */
 template <int L>
 struct OutScale {
-	static constexpr int SHIFT = (L <= 8) ? 8 - L : 0;
+	static constexpr int SHIFT = (L <= 8) ? 8 - L : (L >= 10 ? 16 - L : 0);
+	static constexpr int BYTE = (L <= 8) ? 1 : (L >= 10 ? 2 : 0);     /* first byte of the sample inside the value */
+	static constexpr bool PRESHIFT = (L == 9);
 };
 
 struct PcmFmt {
@@ -223,10 +225,10 @@ __device__ __forceinline__ PcmFmt make_pcm_fmt(unsigned fmt)
 {
 	PcmFmt f;
 	const bool be = fmt & 1u, uns = fmt & 2u;
-	if (L <= 8)      /* sample = bytes 1,2 of each value: S1 = first value (bytes 0-3), S0 = second (bytes 4-7) */
-		f.sel = be ? 0x05060102u : 0x06050201u;
-	else             /* values already shifted down: sample = bytes 0,1 */
-		f.sel = be ? 0x04050001u : 0x05040100u;
+	/* v_perm_b32(S0 = second value, S1 = first value): byte k of S1 is index k, of S0 index 4+k */
+	constexpr uint32_t lo = OutScale<L>::BYTE, hi = OutScale<L>::BYTE + 1;
+	f.sel = be ? ((4 + lo) << 24 | (4 + hi) << 16 | lo << 8 | hi)
+		   : ((4 + hi) << 24 | (4 + lo) << 16 | hi << 8 | lo);
 	f.flip = uns ? (be ? 0x00800080u : 0x80008000u) : 0u;
 	return f;
 }
@@ -234,7 +236,7 @@ __device__ __forceinline__ PcmFmt make_pcm_fmt(unsigned fmt)
 template <int L, bool FLIP>
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t a, uint32_t b, const PcmFmt &f)
 {
-	if (L > 8) {
+	if (OutScale<L>::PRESHIFT) {
 		a >>= L;
 		b >>= L;
 	}

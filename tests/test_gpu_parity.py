@@ -111,3 +111,57 @@ def test_truncated_and_corrupt_streams(dev):
     bad = synth.generate(seed=5, level=5, rows=4, nblocks=3, mix=synth.MIX_SINGLE, single_code=25)
     staged = capi.stage_file(bad)
     assert staged.info.blocks == 0 and staged.info.end_status == -6
+
+
+def test_corpus_shaped_batch(dev):
+    """BASELINE configs[2] in miniature: mixed levels 7-9, mono/stereo, ragged lengths, one plan (3 launches)"""
+    from libacm_amd import workload
+    shapes = workload.corpus_shapes(24, dur_min=0.05, dur_max=1.5)
+    b = workload.build_corpus(len(shapes), shapes=shapes, keep_files=len(shapes))
+    bufs = b.upload(dev)
+    plan = capi.Plan(dev, b.descs)
+    assert plan.stats().launches == 3 and plan.stats().fused_streams == len(shapes)
+    plan.launch(*bufs)
+    out = np.zeros(b.pcm_words, dtype=np.uint16)
+    dev.download(out, bufs[2])
+    for d, f in zip(b.descs, b.files):
+        want, st = oracle_pcm(f.tobytes())
+        assert st == 0 and d.n_emit == want.size
+        assert np.array_equal(out[d.pcm_off:d.pcm_off + d.n_emit], want)
+    plan.destroy()
+    for p in bufs:
+        dev.free(p)
+
+
+def test_many_short_streams_stress_shape(dev):
+    """BASELINE configs[4] in miniature: thousands of 2-block stereo streams at level 11, rows 64 (every tile
+    touches a stream start); a replicated stream must decode identically wherever it sits in the batch"""
+    from libacm_amd import workload
+    b = workload.build_uniform(96, 11, 64, 2, channels=2, keep_files=4, seed0=77)
+    reps = 8
+    descs = []
+    per = b.descs[0].n_emit
+    pad = (per + 63) // 64 * 64
+    for r in range(reps):
+        for d in b.descs:
+            descs.append(capi.StreamDesc(idx_off=d.idx_off, hdr_off=d.hdr_off, pcm_off=(len(descs)) * pad, n_emit=d.n_emit,
+                                         level=d.level, rows=d.rows, nrows=d.nrows, row_begin=0))
+    d_idx, d_hdr, d_pcm0 = b.upload(dev)
+    dev.free(d_pcm0)
+    d_pcm = dev.malloc(len(descs) * pad * 2)
+    plan = capi.Plan(dev, descs)
+    plan.launch(d_idx, d_hdr, d_pcm)
+    out = np.zeros(len(descs) * pad, dtype=np.uint16)
+    dev.download(out, d_pcm)
+    n = len(b.descs)
+    for k in range(4):
+        want, _ = oracle_pcm(b.files[k].tobytes())
+        for r in range(reps):
+            got = out[(r * n + k) * pad:(r * n + k) * pad + per]
+            assert np.array_equal(got, want), (k, r)
+    first = out[:n * pad]
+    for r in range(1, reps):
+        assert np.array_equal(out[r * n * pad:(r + 1) * n * pad], first)
+    plan.destroy()
+    for p in (d_idx, d_hdr, d_pcm):
+        dev.free(p)
