@@ -280,12 +280,32 @@ static int decode_batch(int nfiles, char **names)
 			       it->level, it->rows, (unsigned long long)it->words, it->total_values);
 		if (cfg.no_output)
 			continue;
-		dst = swap_extension(names[i], ".raw");
+		/* same files a one-by-one run would leave behind: WAV unless -r, silence-padded to the header's length */
+		dst = swap_extension(names[i], cfg.raw ? ".raw" : ".wav");
 		out = fopen(dst, "wb");
 		if (!out) {
 			perror(dst);
 		} else {
-			unsigned whole = it->total_values - it->total_values % (it->channels ? it->channels : 1);
+			unsigned chans = it->channels ? it->channels : 1;
+			unsigned whole = it->total_values / chans * chans;      /* acm_pcm_total * channels */
+			if (!cfg.raw) {
+				unsigned char h[44], *p = h;
+				p = tag(p, "RIFF");
+				p = le32(p, 4 + 8 + 16 + 8 + whole * ACM_WORD);
+				p = tag(p, "WAVEfmt ");
+				p = le32(p, 16);
+				p = le16(p, 1);
+				p = le16(p, chans);
+				p = le32(p, it->rate);
+				p = le32(p, it->rate * chans * ACM_WORD);
+				p = le16(p, ACM_WORD * 8 * chans / 8);
+				p = le16(p, ACM_WORD * 8);
+				p = tag(p, "data");
+				p = le32(p, whole * ACM_WORD);
+				fwrite(h, 1, sizeof(h), out);
+			}
+			if (it->words < whole)
+				fprintf(stderr, "%s: adding filler_samples: %d\n", names[i], (int)((whole - it->words) * ACM_WORD));
 			fwrite(it->pcm, 2, whole, out);
 			fclose(out);
 		}

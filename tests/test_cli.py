@@ -79,11 +79,17 @@ def test_cli_batch_mode(dev):
             p = os.path.join(td, "b%d.acm" % k)
             open(p, "wb").write(golden_file(src))
             names.append(p)
-        r = subprocess.run([tool(), "-d", "-B", "-q"] + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert r.returncode == 0, r.stderr
-        batch = [open(p[:-4] + ".raw", "rb").read() for p in names]
-        for p in names:
-            os.remove(p[:-4] + ".raw")
-        r = subprocess.run([tool(), "-d", "-r", "-q"] + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        single = [open(p[:-4] + ".raw", "rb").read() for p in names]
-        assert batch == single
+        trunc = os.path.join(td, "b_trunc.acm")
+        open(trunc, "wb").write(golden_file("f7_src")[:400])
+        names.append(trunc)
+        for flags, ext in ((["-r"], ".raw"), ([], ".wav")):
+            r = subprocess.run([tool(), "-d", "-B", "-q"] + flags + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+            batch = [open(p[:-4] + ext, "rb").read() for p in names]
+            berr = r.stderr
+            for p in names:
+                os.remove(p[:-4] + ext)
+            r = subprocess.run([tool(), "-d", "-q"] + flags + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            single = [open(p[:-4] + ext, "rb").read() for p in names]
+            assert batch == single
+            assert b"adding filler_samples" in berr and berr == r.stderr
