@@ -55,6 +55,11 @@ def parse_args():
     return ap.parse_args()
 
 
+def workload_cpus():
+    from libacm_amd import workload
+    return workload.usable_cpus()
+
+
 def cpu_baseline(batch, budget_s):
     """Decode file images of the workload on the host, one thread, until the budget is used."""
     import oracle_api as O
@@ -101,7 +106,7 @@ def cpu_baseline(batch, budget_s):
         "sample": "%d of the workload's streams (%.1f Msamples), whole decode path incl. bit parsing, 1 thread, %.1f s"
                   % (n, words / 1e6, dt),
         "fill_only_msamples_s": round(fw / dt_fill / 1e6, 2) if dt_fill > 0 else None,
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "usable_cpus": workload_cpus(),
     }
 
 
@@ -239,6 +244,17 @@ def main():
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
+        if not args.no_cpu and batch.files:
+            # informational: file bytes -> PCM in host memory through acm_batch_decode (host parsing on all
+            # cores + PCIe both ways); by contract this is NOT `value`
+            try:
+                res, tm = capi.batch_decode(dev, [f.tobytes() for f in batch.files], threads=0)
+                out["end_to_end"] = {"streams": len(batch.files), "msamples_s": round(tm.samples / tm.total_s / 1e6, 1),
+                                     "parse_s": round(tm.stage_s, 3), "h2d_s": round(tm.h2d_s, 3),
+                                     "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
+                                     "total_s": round(tm.total_s, 3), "host_threads": workload_cpus()}
+            except Exception as e:
+                out["end_to_end"] = {"error": str(e)[:200]}
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)

@@ -7,6 +7,8 @@
  * one pinned staging arena, shipped to HBM in one copy, synthesised by one
  * acmhip_plan_launch, and the PCM comes back in one copy.
  */
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -41,11 +43,29 @@ uint64_t deliverable_words(uint64_t total_values, uint64_t block_len, unsigned c
 	return pos;
 }
 
+/* CPUs this process may actually use: the hardware count, capped by a cgroup-v2 CPU quota if there is one
+ * (a 256-thread box with a 16-CPU quota parses slower with 256 threads than with 16) */
+int usable_cpus()
+{
+	int n = (int)std::max(1u, std::thread::hardware_concurrency());
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		long long quota = 0, period = 0;
+		char q[32] = "";
+		if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+			quota = atoll(q);
+			if (quota > 0)
+				n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+		}
+		fclose(f);
+	}
+	return n;
+}
+
 template <typename F>
 void parallel_for(size_t n, int threads, F fn)
 {
 	if (threads <= 0)
-		threads = (int)std::max(1u, std::thread::hardware_concurrency());
+		threads = usable_cpus();
 	threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n));
 	std::atomic<size_t> next{ 0 };
 	auto work = [&]() {
