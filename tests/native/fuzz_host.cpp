@@ -1,0 +1,104 @@
+// Sanitizer harness for the HOST half of the product (bit reader, filler parsers, stream control): built with
+// g++ -fsanitize=address,undefined (GPU sanitizers are not available on the pool; this is the CPU build).
+// Feeds mutated / truncated ACM images through acm_stage_file and through the libacm.h API in
+// decode-and-discard mode (acm_read(NULL) never needs the device).  The device entry points are stubbed: a
+// call into any of them would mean the host path tried to synthesise, which this harness treats as a failure.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "acm_hip.h"
+#include "libacm.h"
+
+static int device_calls = 0;
+extern "C" {
+const char *acmhip_last_error(void) { return "stub"; }
+int acmhip_device_open(int, void *, acmhip_device **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+int acmhip_device_sync(acmhip_device *) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+int acmhip_malloc(acmhip_device *, size_t, void **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+int acmhip_free(acmhip_device *, void *) { return 0; }
+int acmhip_upload(acmhip_device *, void *, const void *, size_t) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+int acmhip_download(acmhip_device *, void *, const void *, size_t) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+int acmhip_plan_create(acmhip_device *, const acmhip_stream_desc *, size_t, const acmhip_patch *, size_t, unsigned, acmhip_plan **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+void acmhip_plan_destroy(acmhip_plan *) {}
+int acmhip_plan_launch(acmhip_plan *, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+}
+
+struct Mem { const uint8_t *p; size_t len, pos; unsigned max_read; };
+static int rd(void *ptr, int size, int n, void *arg)
+{
+	Mem *m = (Mem *)arg;
+	size_t want = (size_t)size * n;
+	if (m->max_read && want > m->max_read) want = m->max_read;
+	if (want > m->len - m->pos) want = m->len - m->pos;
+	memcpy(ptr, m->p + m->pos, want);
+	m->pos += want;
+	return (int)(want / size);
+}
+static int sk(void *arg, int off, int) { Mem *m = (Mem *)arg; m->pos = (size_t)off > m->len ? m->len : (size_t)off; return 0; }
+static int ln(void *arg) { return (int)((Mem *)arg)->len; }
+
+static uint64_t rng = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 11); }
+
+static void exercise(const std::vector<uint8_t> &img)
+{
+	acm_stage_info si;
+	if (acm_stage_probe(img.data(), img.size(), 0, &si) == ACM_OK) {
+		const uint64_t bl = (uint64_t)si.rows * si.cols;
+		uint64_t need = (si.total_values + bl - 1) / bl;
+		if (need * bl < (1u << 22)) {                 /* keep allocations sane for mutated headers */
+			std::vector<int16_t> idx(need * bl);
+			std::vector<acmhip_blkhdr> hdr(need);
+			std::vector<acmhip_patch> pt(4096);
+			acm_stage_file(img.data(), img.size(), (int)(rnd() % 4) - 1, idx.data(), hdr.data(), need, pt.data(), pt.size(), &si);
+		}
+	}
+	Mem m{ img.data(), img.size(), 0, (rnd() & 3) ? 0u : 1u + rnd() % 9 };
+	acm_io_callbacks io{ rd, sk, nullptr, ln };
+	ACMStream *s = nullptr;
+	if (acm_open_decoder(&s, &m, io, (int)(rnd() % 4) - 1) != ACM_OK)
+		return;
+	if ((uint64_t)s->block_len * 2 > (1u << 24)) {        /* window buffers scale with block_len: skip absurd headers */
+		acm_close(s);
+		return;
+	}
+	for (int k = 0; k < 40; k++) {
+		switch (rnd() % 5) {
+		case 0: acm_seek_pcm(s, rnd() % (acm_pcm_total(s) + 5)); break;
+		case 1: acm_seek_time(s, rnd() % (acm_time_total(s) + 5)); break;
+		default: acm_read_loop(s, NULL, 2 + rnd() % 20000, 0, 2, 1); break;
+		}
+		(void)acm_raw_tell(s); (void)acm_pcm_tell(s); (void)acm_time_tell(s); (void)acm_bitrate(s);
+	}
+	acm_close(s);
+}
+
+int main(int argc, char **argv)
+{
+	int iters = argc > 2 ? atoi(argv[2]) : 300, files = 0;
+	for (int a = 1; a < argc; a++) {
+		if (a == 2) continue;
+		FILE *f = fopen(argv[a], "rb");
+		if (!f) continue;
+		std::vector<uint8_t> base;
+		uint8_t tmp[4096]; size_t n;
+		while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) base.insert(base.end(), tmp, tmp + n);
+		fclose(f);
+		files++;
+		exercise(base);
+		for (int i = 0; i < iters && !base.empty(); i++) {
+			std::vector<uint8_t> img = base;
+			int flips = 1 + rnd() % 4;
+			for (int k = 0; k < flips; k++) img[rnd() % img.size()] ^= (uint8_t)(1u << (rnd() & 7));
+			if (rnd() % 3 == 0) img.resize(rnd() % (img.size() + 1));
+			exercise(img);
+		}
+	}
+	if (device_calls) { fprintf(stderr, "host path called into the device %d times\n", device_calls); return 2; }
+	printf("fuzz ok: %d files x %d mutations\n", files, iters);
+	return 0;
+}

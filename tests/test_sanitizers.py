@@ -1,0 +1,28 @@
+"""ASan + UBSan over the host half of the product (GPU sanitizers are unavailable on the pool: CPU build only).
+tests/native/fuzz_host.cpp links acm_fill.cpp + acm_stream.cpp against stubbed device entry points and drives
+mutated/truncated golden files through staging, seeks and decode-and-discard reads."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_parser_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "fuzz_host")
+    src = [os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"),
+           os.path.join(ROOT, "libacm_amd", "csrc", "acm_fill.cpp"),
+           os.path.join(ROOT, "libacm_amd", "csrc", "acm_stream.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "libacm_amd", "csrc"), "-o", exe] + src + ["-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 and "sanitize" in r.stdout and "cannot find" in r.stdout:
+        pytest.skip("sanitizer runtimes not installed")
+    assert r.returncode == 0, r.stdout
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "acm", "f[1257]_*.acm")))[:40]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, files[0], "60"] + files[1:], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
