@@ -250,7 +250,7 @@ def main():
             try:
                 res, tm = capi.batch_decode(dev, [f.tobytes() for f in batch.files], threads=0)
                 out["end_to_end"] = {"streams": len(batch.files), "msamples_s": round(tm.samples / tm.total_s / 1e6, 1),
-                                     "parse_s": round(tm.stage_s, 3), "h2d_s": round(tm.h2d_s, 3),
+                                     "parse_s": round(tm.stage_s, 3), "alloc_s": round(tm.alloc_s, 3), "h2d_s": round(tm.h2d_s, 3),
                                      "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
                                      "total_s": round(tm.total_s, 3), "host_threads": workload_cpus()}
             except Exception as e:

@@ -204,8 +204,10 @@ typedef struct acm_batch_opts {
 } acm_batch_opts;
 
 typedef struct acm_batch_timing {
-	double stage_s, h2d_s, kernel_s, d2h_s, total_s;
+	double stage_s;          /* host bit parsing (all threads), headers included */
+	double h2d_s, kernel_s, d2h_s, total_s;
 	uint64_t samples;
+	double alloc_s;          /* pinned + device arena allocation */
 } acm_batch_timing;
 
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,

@@ -55,7 +55,7 @@ class BatchOpts(C.Structure):
 
 class BatchTiming(C.Structure):
     _fields_ = [("stage_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double),
-                ("d2h_s", C.c_double), ("total_s", C.c_double), ("samples", C.c_uint64)]
+                ("d2h_s", C.c_double), ("total_s", C.c_double), ("samples", C.c_uint64), ("alloc_s", C.c_double)]
 
 
 # every symbol include/acm_hip.h declares (checked by tests/test_abi.py)

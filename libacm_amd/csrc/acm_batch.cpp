@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#include "acm_device.h"
 #include "acm_hip.h"
 #include "libacm.h"
 
@@ -43,29 +44,20 @@ uint64_t deliverable_words(uint64_t total_values, uint64_t block_len, unsigned c
 	return pos;
 }
 
-/* CPUs this process may actually use: the hardware count, capped by a cgroup-v2 CPU quota if there is one
- * (a 256-thread box with a 16-CPU quota parses slower with 256 threads than with 16) */
-int usable_cpus()
+/* Default size of the parser pool.  Streams are independent and the parser is compute bound, so more threads
+ * help up to the core count; past ~64 the returns vanish (and boxes with a cgroup CPU quota time-slice the
+ * surplus), measured with profiles/e2e_probe.py. */
+int default_threads()
 {
-	int n = (int)std::max(1u, std::thread::hardware_concurrency());
-	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-		long long quota = 0, period = 0;
-		char q[32] = "";
-		if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-			quota = atoll(q);
-			if (quota > 0)
-				n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
-		}
-		fclose(f);
-	}
-	return n;
+	const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+	return std::min(hw, 64);
 }
 
 template <typename F>
 void parallel_for(size_t n, int threads, F fn)
 {
 	if (threads <= 0)
-		threads = usable_cpus();
+		threads = default_threads();
 	threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n));
 	std::atomic<size_t> next{ 0 };
 	auto work = [&]() {
@@ -136,26 +128,26 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		pcm_total += round_up(s.need_blocks * bl, 64);
 	}
 
+	const auto t_hdr = clk::now();
 	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr;
 	acmhip_blkhdr *h_hdr = nullptr, *d_hdr = nullptr;
 	acmhip_plan *plan = nullptr;
 	int rc = ACMHIP_OK;
 	auto cleanup = [&]() {
 		acmhip_plan_destroy(plan);
-		acmhip_free(dev, d_idx);
-		acmhip_free(dev, d_hdr);
-		acmhip_free(dev, d_pcm);
-		acmhip_host_free(h_idx);
-		acmhip_host_free(h_hdr);
-		acmhip_host_free(h_pcm);
+		acmhip_arena_unlock(dev);
 	};
 #define BTRY(call) do { rc = (call); if (rc != ACMHIP_OK) { cleanup(); return rc; } } while (0)
-	BTRY(acmhip_host_alloc(idx_total * sizeof(int16_t), (void **)&h_idx));
-	BTRY(acmhip_host_alloc(hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
-	BTRY(acmhip_host_alloc(pcm_total * sizeof(int16_t), (void **)&h_pcm));
-	BTRY(acmhip_malloc(dev, idx_total * sizeof(int16_t), (void **)&d_idx));
-	BTRY(acmhip_malloc(dev, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
-	BTRY(acmhip_malloc(dev, pcm_total * sizeof(int16_t), (void **)&d_pcm));
+	/* arenas live in the device handle and are reused by the next batch */
+	acmhip_arena_lock(dev);
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
+	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
+	const auto t_alloc = clk::now();
+	tm.alloc_s = secs(t_hdr, t_alloc);
 
 	/* 2. bit parsing, one stream per task */
 	parallel_for(n, opts.threads, [&](size_t i) {
@@ -182,7 +174,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		it.words = deliverable_words(info.total_values, (uint64_t)info.rows * info.cols, info.channels, info.blocks);
 	});
 	const auto t1 = clk::now();
-	tm.stage_s = secs(t0, t1);
+	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t1);
 
 	/* 3. descriptors */
 	std::vector<acmhip_stream_desc> descs;

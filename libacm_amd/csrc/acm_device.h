@@ -44,6 +44,14 @@ struct AcmDevPatch {
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* grow-only staging arenas owned by a device handle (acm_hip_api.cpp): pinned host slots 0-2, device slots 3-5.
+ * hipHostMalloc of gigabytes costs ~0.1 s; the batch front end reuses them across calls.  A device handle
+ * serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
+enum { ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_SLOTS };
+int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
+void acmhip_arena_lock(acmhip_device *dev);
+void acmhip_arena_unlock(acmhip_device *dev);
+
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
 int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */

@@ -108,6 +108,67 @@ struct BitCursor {
 	}
 };
 
+/*
+ * Fast cursor: plain bit offset into the current refill buffer, fields fetched with one unaligned 8-byte
+ * load.  Only used while the column being parsed lies well inside the buffer, where the reference reader's
+ * state is a pure function of the bit offset (it tops up exactly 32 bits whenever a field does not fit, so
+ * buf_pos stays congruent to its phase mod 4 and bit_avail = 8*buf_pos - offset in [0, 31]); enter()/leave()
+ * convert between the two views.  Near the end of the buffer, across refills, at EOF and after short reads
+ * the exact BitCursor above takes over.
+ */
+struct FastCursor {
+	const unsigned char *buf;
+	uint64_t bit;           /* offset of the next unread bit in buf */
+	uint64_t win;           /* the next `have` bits, LSB first */
+	unsigned have;
+
+	inline void refill()
+	{
+		memcpy(&win, buf + (bit >> 3), sizeof(win));
+		win >>= (bit & 7);
+		have = 64 - (unsigned)(bit & 7);        /* >= 57 */
+	}
+	inline int get(unsigned n)                      /* n <= 31 */
+	{
+		if (have < n)
+			refill();
+		const int v = (int)((uint32_t)win & ((1u << n) - 1));
+		win >>= n;
+		have -= n;
+		bit += n;
+		return v;
+	}
+};
+
+/* bits a column can take at most, code included: linear code 16 */
+inline uint64_t worst_column_bits(unsigned rows) { return 5 + (uint64_t)rows * 16; }
+
+inline bool fast_enter(const BitCursor &bc, FastCursor &fc, uint64_t need_bits)
+{
+	const ACMStream *s = bc.s;
+	const int64_t at = (int64_t)8 * s->buf_pos - (int64_t)bc.avail;     /* next unread bit, relative to the buffer */
+	if (at < 0 || s->buf_pos < 4 || (uint64_t)at + need_bits + 64 > (uint64_t)8 * s->buf_size)
+		return false;
+	fc.buf = s->buf;
+	fc.bit = (uint64_t)at;
+	fc.refill();
+	return true;
+}
+
+inline void fast_leave(BitCursor &bc, const FastCursor &fc, unsigned phase)
+{
+	ACMStream *s = bc.s;
+	/* the reference sits on the first 4-byte boundary (of its phase) at or behind the cursor */
+	unsigned pos = (unsigned)((fc.bit + 7) >> 3);
+	pos += (phase - pos) & 3u;
+	const unsigned avail = 8 * pos - (unsigned)fc.bit;
+	uint64_t w;
+	memcpy(&w, s->buf + (fc.bit >> 3), sizeof(w));
+	s->buf_pos = pos;
+	bc.avail = avail;
+	bc.acc = avail ? (uint32_t)(w >> (fc.bit & 7)) & (0xFFFFFFFFu >> (32 - avail)) : 0u;
+}
+
 /* largest |index| a filler code can produce; 0xFFFF marks the invalid codes (:480-489) */
 inline unsigned code_reach(unsigned code)
 {
@@ -130,7 +191,8 @@ const int8_t kWide3[8] = { -4, -3, -2, -1, 1, 2, 3, 4 };
  * One column.  `col` points at idx[0*cols + c]; consecutive rows are `pitch`
  * apart.  Mirrors the per-filler bit grammar of :181-476; returns 1 or <0.
  */
-int parse_column(BitCursor &bc, unsigned code, unsigned rows, int16_t *col, size_t pitch)
+template <class Cursor>
+__attribute__((always_inline)) inline int parse_column(Cursor &bc, unsigned code, unsigned rows, int16_t *col, size_t pitch)
 {
 	unsigned r = 0, b;
 
@@ -347,15 +409,41 @@ int parse_block(ACMStream *s, TableHistory *tab, int16_t *idx, acmhip_blkhdr *hd
 	hdr->pwr = (uint32_t)pwr;
 	const int lim = 1 << pwr;                               /* valid indices: [-lim, lim) */
 
+	const uint64_t col_bits = worst_column_bits(rows);
+	/* whole rest of the block inside the buffer (the normal case: a block is a few KB, the buffer 64 KB):
+	 * stay on the fast cursor for all columns and convert back once */
+	FastCursor blk;
+	const bool block_fast = fast_enter(bc, blk, (uint64_t)cols * col_bits);
+	const unsigned block_phase = s->buf_pos & 3u;
 	for (unsigned c = 0; c < cols; c++) {
-		const int code = bc.get_or_end(5);              /* :496 */
-		if (code < 0) {
-			rc = code;
-			goto fail;
+		int code;
+		FastCursor fc;
+		if (block_fast) {
+			FastCursor cur = blk;                   /* a local copy keeps the cursor in registers */
+			code = cur.get(5);
+			rc = parse_column(cur, (unsigned)code, rows, idx + c, cols);
+			blk = cur;
+			if (rc < 0) {
+				fast_leave(bc, blk, block_phase);
+				goto fail;
+			}
+		} else if (fast_enter(bc, fc, col_bits)) {
+			const unsigned phase = s->buf_pos & 3u;
+			code = fc.get(5);
+			rc = parse_column(fc, (unsigned)code, rows, idx + c, cols);
+			fast_leave(bc, fc, phase);
+			if (rc < 0)
+				goto fail;
+		} else {
+			code = bc.get_or_end(5);                /* :496 */
+			if (code < 0) {
+				rc = code;
+				goto fail;
+			}
+			rc = parse_column(bc, (unsigned)code, rows, idx + c, cols);
+			if (rc < 0)
+				goto fail;
 		}
-		rc = parse_column(bc, (unsigned)code, rows, idx + c, cols);
-		if (rc < 0)
-			goto fail;
 		/* can this code produce an index outside [-lim, lim)?  linear codes span
 		 * [-reach, reach-1], the others are symmetric +-reach */
 		const int reach = (int)code_reach((unsigned)code);
@@ -376,6 +464,8 @@ int parse_block(ACMStream *s, TableHistory *tab, int16_t *idx, acmhip_blkhdr *hd
 			}
 		}
 	}
+	if (block_fast)
+		fast_leave(bc, blk, block_phase);
 	bc.commit();
 	return 1;
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -43,6 +44,9 @@ struct acmhip_device {
 	int ordinal;
 	hipStream_t stream;
 	bool own_stream;
+	void *arena[ACM_ARENA_SLOTS] = {};
+	size_t arena_cap[ACM_ARENA_SLOTS] = {};
+	std::mutex arena_mutex;
 };
 
 /* per level: the fused-kernel tile table, or the stage-wise stream list */
@@ -123,9 +127,57 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 		return;
 	(void)hipSetDevice(dev->ordinal);
 	(void)hipStreamSynchronize(dev->stream);
+	for (int k = 0; k < ACM_ARENA_SLOTS; k++) {
+		if (!dev->arena[k])
+			continue;
+		if (k < ACM_ARENA_D_IDX)
+			(void)hipHostFree(dev->arena[k]);
+		else
+			(void)hipFree(dev->arena[k]);
+	}
 	if (dev->own_stream)
 		(void)hipStreamDestroy(dev->stream);
 	delete dev;
+}
+
+extern "C" int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out)
+{
+	if (!dev || slot < 0 || slot >= ACM_ARENA_SLOTS || !out)
+		return ACMHIP_ERR_ARG;
+	if (bytes < 16)
+		bytes = 16;
+	if (dev->arena_cap[slot] < bytes) {
+		HIPTRY(hipSetDevice(dev->ordinal));
+		if (dev->arena[slot]) {
+			HIPTRY(hipStreamSynchronize(dev->stream));
+			if (slot < ACM_ARENA_D_IDX)
+				(void)hipHostFree(dev->arena[slot]);
+			else
+				(void)hipFree(dev->arena[slot]);
+			dev->arena[slot] = nullptr;
+			dev->arena_cap[slot] = 0;
+		}
+		const size_t want = bytes + bytes / 8;          /* a little headroom against creeping batches */
+		if (slot < ACM_ARENA_D_IDX)
+			HIPTRY(hipHostMalloc(&dev->arena[slot], want, hipHostMallocDefault));
+		else
+			HIPTRY(hipMalloc(&dev->arena[slot], want));
+		dev->arena_cap[slot] = want;
+	}
+	*out = dev->arena[slot];
+	return ACMHIP_OK;
+}
+
+extern "C" void acmhip_arena_lock(acmhip_device *dev)
+{
+	if (dev)
+		dev->arena_mutex.lock();
+}
+
+extern "C" void acmhip_arena_unlock(acmhip_device *dev)
+{
+	if (dev)
+		dev->arena_mutex.unlock();
 }
 
 extern "C" int acmhip_device_sync(acmhip_device *dev)

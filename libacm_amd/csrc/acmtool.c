@@ -312,8 +312,8 @@ static int decode_batch(int nfiles, char **names)
 		free(dst);
 	}
 	if (!cfg.quiet)
-		printf("batch: %llu samples, parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
-		       (unsigned long long)tm.samples, tm.stage_s, tm.h2d_s, tm.kernel_s, tm.d2h_s, tm.total_s);
+		printf("batch: %llu samples, alloc %.3fs parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
+		       (unsigned long long)tm.samples, tm.alloc_s, tm.stage_s, tm.h2d_s, tm.kernel_s, tm.d2h_s, tm.total_s);
 	acmhip_device_close(dev);
 	return 0;
 }

@@ -97,3 +97,34 @@ def test_synth_is_deterministic_and_valid():
     assert a == b and a != c
     pcm, st = O.Oracle.decode_all(a)
     assert st == 0 and pcm.size == 5 * 16 * 128
+
+
+def test_differential_fuzz_against_oracle():
+    """mutated and truncated streams: the product's parser and the oracle must agree on how many blocks
+    decode, how the stream ends, and on every unpacked value (table primed so that H1 stays deterministic)"""
+    rng = np.random.default_rng(99)
+    bases = [bytearray(make_stream(5000 + k, lv, rows, 6, mix=k % 2, prime_table=1, channels=1 + k % 2))
+             for k, (lv, rows) in enumerate([(3, 5), (5, 16), (7, 3), (2, 1), (6, 17)])]
+    for it in range(400):
+        g = bytearray(bases[it % len(bases)])
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(len(g) // 3, len(g)))
+            g[pos] ^= 1 << int(rng.integers(0, 8))
+        if it % 3 == 0:
+            g = g[:int(rng.integers(len(g) // 3, len(g) + 1))]
+        data = bytes(g)
+        st = capi.stage_file(data)
+        o = O.Oracle(data)
+        b = 0
+        while True:
+            if b * st.block_len >= st.info.total_values:
+                break
+            rc, raw, pwr, val = o.fill_next_block()
+            if rc != 1:
+                assert b == st.info.blocks, (it, b, st.info.blocks, rc)
+                assert st.info.end_status == (0 if rc == O.CLEAN_EOF else rc), (it, rc, st.info.end_status)
+                break
+            assert b < st.info.blocks, (it, b)
+            assert np.array_equal(unpacked(st, b), raw.view(np.uint32)), (it, b)
+            b += 1
+        assert b == st.info.blocks
