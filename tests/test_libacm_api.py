@@ -204,3 +204,54 @@ def test_long_stream_many_windows(dev):
         rec = decode_record(ours, f)
         want, st = oracle_pcm(f)
         assert rec["words"] == want.size and rec["sha256"] == sha(want.tobytes()) and rec["status"] == st
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_share_the_device(dev):
+    """several threads, each decoding its own stream through acm_read on the shared default device
+    (reference contract: one ACMStream = one thread at a time, distinct streams independent)"""
+    import threading
+    from helpers import make_stream, oracle_pcm
+    files = [make_stream(2600 + k, [7, 9, 5, 11][k % 4], [16, 16, 3, 4][k % 4], [300, 60, 900, 12][k % 4], channels=1 + k % 2)
+             for k in range(8)]
+    want = [oracle_pcm(f)[0].tobytes() for f in files]
+    got = [None] * len(files)
+
+    def work(k):
+        s = ours(files[k])
+        out = []
+        ask = [8192, 4000, 123456, 4][k % 4]      # (a 2-byte request on a stereo stream yields 0, as in the reference)
+        while True:
+            rc, b = s.read(ask, loop=True)
+            if rc <= 0:
+                break
+            out.append(b)
+        s.close()
+        got[k] = b"".join(out)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(files))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_interleaved_reads_on_two_streams(dev):
+    """alternate small reads on two open streams: windows, carries and plans must not leak between them"""
+    from helpers import make_stream, oracle_pcm
+    fa, fb = make_stream(2700, 7, 16, 200), make_stream(2701, 9, 3, 150, channels=2)
+    wa, wb = oracle_pcm(fa)[0].tobytes(), oracle_pcm(fb)[0].tobytes()
+    a, b = ours(fa), ours(fb)
+    ga, gb = [], []
+    for k in range(100000):
+        ra, xa = a.read(3000 + (k % 7) * 2)
+        rb, xb = b.read(5000 - (k % 5) * 4)
+        ga.append(xa)
+        gb.append(xb)
+        if ra <= 0 and rb <= 0:
+            break
+    a.close()
+    b.close()
+    assert b"".join(ga) == wa and b"".join(gb) == wb

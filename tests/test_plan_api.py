@@ -1,0 +1,75 @@
+"""Argument validation and degenerate cases of the hot-path C ABI (include/acm_hip.h)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_stream, oracle_pcm
+from libacm_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def desc(**kw):
+    d = dict(idx_off=0, hdr_off=0, pcm_off=0, n_emit=128, level=7, rows=1, nrows=1, row_begin=0)
+    d.update(kw)
+    return capi.StreamDesc(**d)
+
+
+def test_rejects_bad_descriptors(dev):
+    for bad in (dict(level=16), dict(rows=0), dict(rows=4096), dict(idx_off=4), dict(pcm_off=2),
+                dict(row_begin=2), dict(n_emit=129), dict(nrows=2, row_begin=1, n_emit=129)):
+        with pytest.raises(capi.AcmHipError):
+            capi.Plan(dev, [desc(**bad)])
+    p = capi.Patch(0, 1, 5)
+    with pytest.raises(capi.AcmHipError):
+        capi.Plan(dev, [desc()], (capi.Patch * 1)(p))
+    assert capi.lib().acmhip_plan_create(None, None, 0, None, 0, 0, None) == -103
+    h = C.c_void_p()
+    assert capi.lib().acmhip_device_open(99, None, C.byref(h)) == -103
+
+
+def test_empty_and_zero_emit_plans(dev):
+    plan = capi.Plan(dev, [])
+    plan.launch(None, None, None)
+    st = plan.stats()
+    assert (st.samples, st.launches) == (0, 0)
+    plan.destroy()
+    plan = capi.Plan(dev, [desc(n_emit=0), desc(n_emit=0, level=3)])
+    plan.launch(None, None, None)
+    assert plan.stats().launches == 0
+    with pytest.raises(capi.AcmHipError):
+        plan.launch(None, None, None, fmt=4)
+    plan.destroy()
+
+
+def test_plan_is_reusable_and_format_is_per_launch(dev):
+    f = make_stream(4400, 8, 16, 30, cut=4)
+    s = capi.stage_file(f)
+    ar = capi.Arena([s])
+    d_idx, d_hdr, d_pcm = dev.malloc(ar.idx.nbytes), dev.malloc(ar.hdr.nbytes), dev.malloc(ar.pcm_words * 2)
+    dev.upload(d_idx, ar.idx)
+    dev.upload(d_hdr, ar.hdr)
+    plan = capi.Plan(dev, ar.descs)
+    out = np.zeros(ar.pcm_words, dtype=np.uint16)
+    for fmt in (0, 1, 2, 3, 0):
+        plan.launch(d_idx, d_hdr, d_pcm, fmt)
+        dev.download(out, d_pcm)
+        want, _ = oracle_pcm(f, 0, fmt & 1, 0 if fmt & 2 else 1)
+        assert np.array_equal(out[:want.size], want)
+    ms = plan.time(d_idx, d_hdr, d_pcm, reps=3)
+    assert ms > 0
+    plan.destroy()
+    for p in (d_idx, d_hdr, d_pcm):
+        dev.free(p)
+
+
+def test_external_stream_handle(dev):
+    """a caller-owned hipStream_t (here torch's) can carry the launches"""
+    import torch
+    st = torch.cuda.Stream()
+    with capi.Device(0, st.cuda_stream) as d2:
+        assert capi.lib().acmhip_device_stream(d2.h) == st.cuda_stream
+        f = make_stream(4401, 7, 16, 25)
+        got = capi.synth(d2, [capi.stage_file(f)])[0]
+        assert np.array_equal(got, oracle_pcm(f)[0])
