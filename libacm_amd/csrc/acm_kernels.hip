@@ -924,6 +924,9 @@ inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 
 #define ACMK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+/* gridDim.y carries the stream index and is limited to 65535: walk long lists in slices */
+constexpr uint32_t SW_MAX_Y = 65535;
+
 extern "C" int acmk_fused_variants(void)
 {
 	return NVARIANTS;
@@ -968,11 +971,12 @@ extern "C" int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t 
 				  uint64_t max_elems, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
 				  int32_t *d_x, void *stream)
 {
-	if (nlist == 0)
-		return 0;
-	hipLaunchKernelGGL(acm_sw_unpack, sw_grid(max_elems, nlist), dim3(SW_THREADS), 0, (hipStream_t)stream,
-			   d_streams, d_list, d_idx, d_hdr, d_x);
-	ACMK_CHECK_LAUNCH();
+	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
+		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
+		hipLaunchKernelGGL(acm_sw_unpack, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
+				   d_streams, d_list + at, d_idx, d_hdr, d_x);
+		ACMK_CHECK_LAUNCH();
+	}
 	return 0;
 }
 
@@ -990,21 +994,23 @@ extern "C" int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *
 				 uint64_t max_elems, uint32_t level, uint32_t k, const int32_t *d_in,
 				 int32_t *d_out, void *stream)
 {
-	if (nlist == 0)
-		return 0;
-	hipLaunchKernelGGL(acm_sw_stage, sw_grid(max_elems, nlist), dim3(SW_THREADS), 0, (hipStream_t)stream,
-			   d_streams, d_list, level, k, d_in, d_out);
-	ACMK_CHECK_LAUNCH();
+	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
+		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
+		hipLaunchKernelGGL(acm_sw_stage, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
+				   d_streams, d_list + at, level, k, d_in, d_out);
+		ACMK_CHECK_LAUNCH();
+	}
 	return 0;
 }
 
 extern "C" int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
 				uint64_t max_emit, const int32_t *d_x, int16_t *d_pcm, unsigned fmt, void *stream)
 {
-	if (nlist == 0)
-		return 0;
-	hipLaunchKernelGGL(acm_sw_emit, sw_grid(max_emit, nlist), dim3(SW_THREADS), 0, (hipStream_t)stream,
-			   d_streams, d_list, d_x, d_pcm, fmt);
-	ACMK_CHECK_LAUNCH();
+	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
+		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
+		hipLaunchKernelGGL(acm_sw_emit, sw_grid(max_emit, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
+				   d_streams, d_list + at, d_x, d_pcm, fmt);
+		ACMK_CHECK_LAUNCH();
+	}
 	return 0;
 }

@@ -73,3 +73,28 @@ def test_external_stream_handle(dev):
         f = make_stream(4401, 7, 16, 25)
         got = capi.synth(d2, [capi.stage_file(f)])[0]
         assert np.array_equal(got, oracle_pcm(f)[0])
+
+
+def test_more_streams_than_grid_y(dev):
+    """stage-wise launches slice stream lists longer than gridDim.y (65535)"""
+    f = make_stream(4402, 2, 3, 2)
+    s = capi.stage_file(f)
+    want, _ = oracle_pcm(f)
+    n = 70000
+    per = 64
+    descs = [capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=k * per, n_emit=s.words, level=s.info.level,
+                             rows=s.info.rows, nrows=s.info.blocks * s.info.rows, row_begin=0) for k in range(n)]
+    idx = np.zeros(64, np.int16)
+    idx[:s.idx.size] = s.idx
+    d_idx, d_hdr, d_pcm = dev.malloc(idx.nbytes), dev.malloc(s.hdr.nbytes), dev.malloc(n * per * 2)
+    dev.upload(d_idx, idx)
+    dev.upload(d_hdr, s.hdr)
+    plan = capi.Plan(dev, descs)
+    plan.launch(d_idx, d_hdr, d_pcm)
+    out = np.zeros(n * per, dtype=np.uint16)
+    dev.download(out, d_pcm)
+    out = out.reshape(n, per)[:, :want.size]
+    assert np.array_equal(out, np.broadcast_to(want, out.shape))
+    plan.destroy()
+    for p in (d_idx, d_hdr, d_pcm):
+        dev.free(p)
