@@ -766,9 +766,9 @@ constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs.
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 15;
+constexpr int NVARIANTS = 17;
 #else
-constexpr int NVARIANTS = 6;
+constexpr int NVARIANTS = 8;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
@@ -777,8 +777,8 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
 		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
 		entry2<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
-		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
 	{	/* variant 1 */
 		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
@@ -824,6 +824,24 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
 		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
 		entry<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
+	},
+	{	/* variant 6: alternative stage groupings (tuning) */
+		entry2<TileCfg<5, 256, 8192>, 4, 1, 2, 2>(),
+		entry2<TileCfg<6, 256, 16384>, 2, 1, 2, 3>(),
+		entry2<TileCfg<7, 256, 16384>, 2, 1, 3, 3>(),
+		entry2<TileCfg<8, 256, 16384>, 2, 2, 3, 3>(),
+		entry2<TileCfg<9, 256, 16384>, 2, 2, 2, 2, 3>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 2, 2, 3>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 2, 3, 3>(),
+	},
+	{	/* variant 7: alternative stage groupings (tuning) */
+		entry2<TileCfg<5, 256, 16384>, 2, 2, 3>(),
+		entry2<TileCfg<6, 256, 16384>, 2, 3, 3>(),
+		entry2<TileCfg<7, 256, 16384>, 2, 3, 2, 2>(),
+		entry2<TileCfg<8, 256, 16384>, 2, 3, 2, 3>(),
+		entry2<TileCfg<9, 256, 16384>, 2, 3, 2, 2, 2>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
 #ifdef ACM_ABLATION
 	{
