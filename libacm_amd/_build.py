@@ -66,6 +66,8 @@ def build_hip(force=False):
                        "--offload-arch=" + GFX, "-I", INC, "-I", CSRC, "-c", s, "-o", o]
                 if os.environ.get("ACM_ABLATION"):      # timing-only kernel variants for profiling sessions
                     cmd.insert(1, "-DACM_ABLATION=1")
+                extra = os.environ.get("ACM_HIPCC_EXTRA", "").split()           # compiler-flag experiments
+                cmd[1:1] = extra
                 if s.endswith(".cpp"):
                     cmd.insert(1, "-x")
                     cmd.insert(2, "hip")
