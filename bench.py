@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=16)
     ap.add_argument("--blocks", type=int, default=1000)
     ap.add_argument("--channels", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-9/level-11 side measurements")
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
@@ -165,7 +165,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---- stage the workload (untimed): synth -> host bit parsing -> HBM ----
-    keep = 0 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 512)
+    keep = 0 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 1024)
     t0 = time.perf_counter()
     if args.workload == "corpus":
         # configs[2]/[3]: the SAME corpus whatever N; rank r decodes its longest-first shard of the file list
