@@ -18,12 +18,14 @@
  * before it ("halo").  No state is carried between launches.
  *
  * Two kernel families:
- *   fused tile kernel (levels 5..11, no H1 patches): one workgroup = one tile of
- *     TR rows (2 halo + T payload) held in LDS as int32; load+unpack, then the
- *     stages in groups of G=2..3 per LDS round trip ("passes": each thread owns
- *     one residue class of the pass's smallest stride and walks it with the
- *     inputs of the G stages in registers), then convert+store.  HBM traffic:
- *     2 B read (+2/T halo) + 2 B written per sample.
+ *   fused tile kernel (levels 5..11, no H1 patches): persistent workgroups, one tile at a time.  A tile is
+ *     TR rows (2 halo + T payload) of one stream held in LDS as int32.  The stages are grouped into passes of
+ *     G = 2..4: each thread owns one residue class of the pass's smallest stride and walks it with the inputs
+ *     of the G stages in registers (one LDS read + one write per element per PASS, not per stage).  The
+ *     first pass is fed straight from HBM (4-byte loads issued one tile ahead, unpacked by an SDWA multiply),
+ *     the last one emits packed 16-bit samples that leave as 16 B/lane stores.  HBM traffic: 2 B read
+ *     (+2/T halo, mostly L2 hits) + 2 B written per sample.  Two VALU ops per butterfly (sign folding +
+ *     v_mad_i32_i24); measured limit is instruction issue, not HBM.
  *   stage-wise kernels (any level 0..15, H1 patches): unpack to an int32 plane,
  *     one elementwise launch per stage (ping-pong planes), emit.  8*level B of
  *     HBM traffic per sample; generic fallback and cross-check.
@@ -254,9 +256,8 @@ struct PassGeo {
 	static constexpr int U = 1 << G;
 	static constexpr int BODY = 2 * U;                      // elements per unrolled body
 	static constexpr int NJ_TOTAL = NELEM / SIGMA;          // walk length of one residue over the tile
-	static constexpr bool MULTI_RES = SIGMA >= NT;          // at least as many residues as threads
-	static constexpr int RPT = MULTI_RES ? SIGMA / NT : 1;  // residues per thread
-	static constexpr int NSEG = MULTI_RES ? 1 : NT / SIGMA; // walk segments per residue
+	static_assert(SIGMA < NT, "LDS passes need more threads than residues (the first pass takes the wide strides)");
+	static constexpr int NSEG = NT / SIGMA;                 // walk segments per residue
 	static constexpr int NJ = NJ_TOTAL / NSEG;              // walk length per thread
 	static_assert(SIGMA >= 1, "pass exceeds level");
 	static_assert(NJ % BODY == 0 && NJ >= BODY, "segment must be whole bodies");
@@ -464,7 +465,6 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	using P = PassGeo<C, K0, G>;
 	constexpr int L = C::L;
 	constexpr int U = P::U, BODY = P::BODY, SIGMA = P::SIGMA;
-	static_assert(!P::MULTI_RES, "only the first pass may own several residues");
 	static_assert(!LAST || SIGMA == 1, "last pass must end at stride 1");
 
 	const int seg = tid / SIGMA;
