@@ -746,6 +746,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
  *   3  256 threads on half-size tiles (4 workgroups per CU)
  *   4  as 1 with 4-byte first-pass loads (two adjacent columns per lane)
  *   5  as 1 with fewer, deeper LDS passes
+ *   6, 7  alternative stage groupings;  8  128-thread workgroups (128 samples per thread per pass)
  */
 struct FusedEntry {
 	void (*fn)(const AcmDevStream *, const AcmTile *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
@@ -766,13 +767,13 @@ constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs.
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 17;
+constexpr int NVARIANTS = 18;
 #else
-constexpr int NVARIANTS = 8;
+constexpr int NVARIANTS = 9;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
-		entry2<TileCfg<5, 256, 8192>, 4, 2, 3>(),
+		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
 		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
 		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
 		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
@@ -842,6 +843,15 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<9, 256, 16384>, 2, 3, 2, 2, 2>(),
 		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
 		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
+	},
+	{	/* variant 8: 128-thread workgroups, 128 samples per thread per pass (half the warm-up share) */
+		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
+		entry2<TileCfg<6, 128, 16384>, 1, 2, 2, 2>(),
+		entry2<TileCfg<7, 128, 16384>, 1, 2, 2, 3>(),
+		entry2<TileCfg<8, 128, 16384>, 1, 3, 3, 2>(),
+		entry2<TileCfg<9, 128, 16384>, 1, 3, 3, 3>(),
+		entry2<TileCfg<10, 128, 16384>, 1, 3, 3, 4>(),
+		entry2<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
 	},
 #ifdef ACM_ABLATION
 	{

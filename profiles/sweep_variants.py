@@ -29,8 +29,9 @@ print(json.dumps(out))
 
 streams = sys.argv[1] if len(sys.argv) > 1 else "512"
 nvar = int(os.environ.get("NVAR", "5"))
+variants = [int(x) for x in os.environ["VARIANTS"].split(",")] if os.environ.get("VARIANTS") else list(range(nvar))
 rows = {}
-for v in range(nvar):
+for v in variants:
     env = dict(os.environ, ACM_K1_VARIANT=str(v))
     r = subprocess.run([sys.executable, "-c", CODE, streams], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
