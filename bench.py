@@ -52,6 +52,8 @@ def parse_args():
                     help="uniform = BASELINE configs[1]-style batch (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
     ap.add_argument("--files", type=int, default=4000)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank - exercises the N>1 code path on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -147,7 +149,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -157,7 +159,7 @@ def main():
         raise SystemExit("bench.py: no HIP device - the hot path has no CPU fallback")
     dev = capi.Device(local)
 
-    sync_t = torch.zeros(1, device="cuda:%d" % local) if world > 1 else None
+    sync_t = torch.zeros(1, device="cuda:%d" % local) if dist is not None else None
 
     def barrier():
         if dist is not None:
@@ -165,7 +167,8 @@ def main():
             torch.cuda.synchronize()
 
     # ---- stage the workload (untimed): synth -> host bit parsing -> HBM ----
-    keep = 0 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 1024)
+    # every rank keeps a few file images for the setup-time self check; rank 0 at N=1 keeps the CPU baseline's sample
+    keep = 4 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 1024)
     t0 = time.perf_counter()
     if args.workload == "corpus":
         # configs[2]/[3]: the SAME corpus whatever N; rank r decodes its longest-first shard of the file list
@@ -180,6 +183,29 @@ def main():
     bufs = batch.upload(dev)
     plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
     stats = plan.stats()
+
+    # setup-time self check (untimed, before the warm-up): the first streams must match the oracle bit for bit,
+    # and repeated launches over the same resident input must keep producing exactly that (idempotence: the hot
+    # path carries no state between launches; also catches races)
+    verified = None
+    if batch.files:
+        try:
+            import oracle_api as O
+            nchk = min(4, len(batch.files))
+            want = [O.Oracle.decode_all(batch.files[k].tobytes())[0].view(np.uint16) for k in range(nchk)]
+            verified = True
+            for rep in range(8):
+                plan.launch(*bufs)
+                dev.sync()
+                for k in range(nchk):
+                    d = batch.descs[k]
+                    got = np.zeros(d.n_emit, dtype=np.uint16)
+                    dev.download(got, bufs[2] + 2 * d.pcm_off)
+                    verified = verified and bool(np.array_equal(got, want[k][:d.n_emit]))
+        except Exception as e:
+            verified = "error: %s" % str(e)[:120]
+        if verified is False:
+            raise SystemExit("bench.py: HIP output differs from the oracle - refusing to report a number")
 
     wall, ev_ms = time_plan(dev, plan, bufs, args.steps, args.warmup, barrier)
 
@@ -214,7 +240,7 @@ def main():
         "metric": "decoded PCM Msamples/sec over a batch of ACM streams (hot path on HBM-resident staged input)",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if args.workload == "corpus" else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "scaling": "strong" if args.workload == "corpus" else "weak", "vs_baseline": None, "verified_vs_oracle": verified, "dtype": "int32", "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[2]: %d-file corpus, mixed mono/stereo, acm_level 7-9, 1-60 s at 22050 Hz, "
                                 "sharded by file" % args.files) if args.workload == "corpus" else
                                "%s%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each" % (
@@ -244,7 +270,7 @@ def main():
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
-        if not args.no_cpu and batch.files:
+        if not args.no_cpu and len(batch.files) > 4:
             # informational: file bytes -> PCM in host memory through acm_batch_decode (host parsing on all
             # cores + PCIe both ways); by contract this is NOT `value`
             try:
