@@ -489,7 +489,8 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	 * segment's owner, who is about to overwrite them in place - read them
 	 * first, then everybody may start walking.  Segment 0 reads the zeroed guard
 	 * zone in front of the tile (history before the tile = zeros). */
-	__syncthreads();
+	if (!(ABL & 32))
+		__syncthreads();
 	uint32_t w[BODY];
 	{
 		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= 64 ? BS / 64 : 1)) : tile + lds_at(m_seg - BS);
@@ -497,7 +498,8 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 		for (int u = 0; u < BODY; u++)
 			w[u] = pw[P::off(u)];
 	}
-	__syncthreads();
+	if (!(ABL & 32))
+		__syncthreads();
 
 	/* software pipeline: the reads of body k+1 are in flight while body k is computed */
 	constexpr int NBODY = P::NJ / BODY;
@@ -763,11 +765,13 @@ constexpr FusedEntry entry2() { return FusedEntry{ acm_fused_tile<C, W, 0, 2, Gs
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-7 and level-9 kernels with parts removed (wrong output by design) */
 template <class C, int W, int ABL, int... Gs>
+constexpr FusedEntry abl2() { return FusedEntry{ acm_fused_tile<C, W, ABL, 2, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+template <class C, int W, int ABL, int... Gs>
 constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 18;
+constexpr int NVARIANTS = 19;
 #else
 constexpr int NVARIANTS = 9;
 #endif
@@ -854,6 +858,15 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
 	},
 #ifdef ACM_ABLATION
+	{	/* timing only: default geometry without the barriers inside the LDS passes */
+		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
+		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
+		abl2<TileCfg<7, 256, 16384>, 2, 32, 2, 2, 3>(),
+		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		abl2<TileCfg<9, 256, 16384>, 2, 32, 3, 3, 3>(),
+		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
+	},
 	{
 		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
 		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
