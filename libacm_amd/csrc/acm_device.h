@@ -55,7 +55,7 @@ void acmhip_arena_unlock(acmhip_device *dev);
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
 int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */
-int acmk_launch_fused(uint32_t level, int variant, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+int acmk_launch_fused(uint32_t level, int variant, int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
 		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);

@@ -44,6 +44,7 @@ struct acmhip_device {
 	int ordinal;
 	hipStream_t stream;
 	bool own_stream;
+	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
 	std::mutex arena_mutex;
@@ -108,6 +109,11 @@ extern "C" int acmhip_device_open(int ordinal, void *hip_stream, acmhip_device *
 	if (!d)
 		return ACMHIP_ERR_NOMEM;
 	d->ordinal = ordinal;
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess)
+			d->cus = prop.multiProcessorCount;
+	}
 	d->own_stream = (hip_stream == nullptr);
 	d->stream = (hipStream_t)hip_stream;
 	if (d->own_stream) {
@@ -460,7 +466,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	void *st = (void *)pl->dev->stream;
 
 	for (const LevelGroup &g : pl->fused)
-		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
 
 	if (pl->n_sw_all) {
 		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,

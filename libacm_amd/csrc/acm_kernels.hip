@@ -980,7 +980,7 @@ extern "C" int acmk_fused_tile_rows(uint32_t level, int variant)
 	return g_fused[variant][level - ACM_K1_MIN_LEVEL].tile_rows;
 }
 
-extern "C" int acmk_launch_fused(uint32_t level, int variant, const AcmDevStream *d_streams, const AcmTile *d_tiles,
+extern "C" int acmk_launch_fused(uint32_t level, int variant, int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles,
 				 uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
 				 int16_t *d_pcm, unsigned fmt, void *stream)
 {
@@ -989,17 +989,9 @@ extern "C" int acmk_launch_fused(uint32_t level, int variant, const AcmDevStream
 	if (level < ACM_K1_MIN_LEVEL || level > ACM_K1_MAX_LEVEL || variant < 0 || variant >= NVARIANTS)
 		return -1;
 	const FusedEntry &e = g_fused[variant][level - ACM_K1_MIN_LEVEL];
-	/* persistent grid: as many workgroups as the chip holds at once (256 CUs), never more than tiles */
-	static int cus = 0;
-	if (!cus) {
-		int dev = 0;
-		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-			cus = prop.multiProcessorCount;
-		if (cus <= 0)
-			cus = 256;
-	}
-	uint32_t grid = (uint32_t)(cus * e.wg_per_cu);
+	/* persistent grid: as many workgroups as the chip holds at once, never more than tiles.  `cus` comes from
+	 * the device handle: nothing here queries or synchronises, so the launch can be captured into a hipGraph */
+	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
 	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream,

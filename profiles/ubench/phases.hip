@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 3; rep++) {
     (void)hipEventRecord(e0);
-    acmk_launch_fused(level, variant, d_s, d_t, (uint32_t)tiles.size(), d_idx, d_hdr, d_pcm, 0, nullptr);
+    acmk_launch_fused(level, variant, 256, d_s, d_t, (uint32_t)tiles.size(), d_idx, d_hdr, d_pcm, 0, nullptr);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   }
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -98,3 +98,31 @@ def test_more_streams_than_grid_y(dev):
     plan.destroy()
     for p in (d_idx, d_hdr, d_pcm):
         dev.free(p)
+
+
+def test_launch_is_graph_capturable(dev):
+    """acmhip_plan_launch neither allocates nor synchronises: a caller can capture it into a hipGraph
+    (here through torch's CUDAGraph on torch's own stream) and replay it"""
+    import torch
+    f = make_stream(4403, 7, 16, 40)
+    s = capi.stage_file(f)
+    ar = capi.Arena([s])
+    t_idx = torch.from_numpy(ar.idx).cuda()
+    t_hdr = torch.from_numpy(ar.hdr.view(np.int32)).cuda()
+    t_pcm = torch.zeros(ar.pcm_words, dtype=torch.int16, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        d2 = capi.Device(0, side.cuda_stream)
+        plan = capi.Plan(d2, ar.descs)
+        plan.launch(t_idx.data_ptr(), t_hdr.data_ptr(), t_pcm.data_ptr())      # warm (module load) outside capture
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.launch(t_idx.data_ptr(), t_hdr.data_ptr(), t_pcm.data_ptr())
+        t_pcm.zero_()
+        g.replay()
+        side.synchronize()
+    want, _ = oracle_pcm(f)
+    assert np.array_equal(t_pcm.cpu().numpy().view(np.uint16)[:want.size], want)
+    plan.destroy()
+    d2.close()
