@@ -235,10 +235,17 @@ __device__ __forceinline__ PcmFmt make_pcm_fmt(unsigned fmt)
 	return f;
 }
 
-template <int L, bool FLIP>
+template <int L, bool FLIP, bool BIGEND = true>
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t a, uint32_t b, const PcmFmt &f)
 {
 	if (OutScale<L>::PRESHIFT) {
+		if (!BIGEND) {
+			/* two ops per pair: a >> L, then SDWA drops the low half of b >> L into the upper word */
+			uint32_t p = a >> L;
+			asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+			    : "+v"(p) : "v"((uint32_t)L), "v"(b));
+			return FLIP ? (p ^ f.flip) : p;
+		}
 		a >>= L;
 		b >>= L;
 	}
@@ -459,7 +466,7 @@ struct FirstPass {
  * packed two per dword and parked at the start of the thread's own (already
  * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
  */
-template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true>
+template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true, bool BIGEND = true>
 __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt)
 {
 	using P = PassGeo<C, K0, G>;
@@ -535,7 +542,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			uint32_t *o = base + it * (BODY / 2);
 #pragma unroll
 			for (int u = 0; u < BODY; u += 2)
-				o[u / 2] = pack_pcm<L, FLIP>(v[u], v[u + 1], pf);
+				o[u / 2] = pack_pcm<L, FLIP, BIGEND>(v[u], v[u + 1], pf);
 		}
 	}
 }
@@ -565,10 +572,10 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
 	if constexpr (!last) {
 		lds_pass<C, K0, G, false, ABL>(tile, tid, fmt);
 		run_lds_passes<C, ABL, K0 + G, Rest...>(tile, tid, fmt);
-	} else if (fmt & 2u) {
-		lds_pass<C, K0, G, true, ABL, true>(tile, tid, fmt);    /* unsigned samples */
+	} else if (fmt == ACMHIP_FMT_S16LE) {
+		lds_pass<C, K0, G, true, ABL, false, false>(tile, tid, fmt);   /* the common layout: no xor, no byte swap */
 	} else {
-		lds_pass<C, K0, G, true, ABL, false>(tile, tid, fmt);
+		lds_pass<C, K0, G, true, ABL, true, true>(tile, tid, fmt);     /* any other layout through the general path */
 	}
 }
 
