@@ -201,13 +201,22 @@ typedef struct acm_batch_opts {
 	unsigned fmt;            /* ACMHIP_FMT_* */
 	int      threads;        /* host staging threads, 0 = hardware concurrency */
 	unsigned plan_flags;     /* ACMHIP_PLAN_* */
+	unsigned parse;          /* ACM_BATCH_PARSE_* */
 } acm_batch_opts;
+
+/* where the bit parsing of a batch runs */
+#define ACM_BATCH_PARSE_HOST   0u   /* host thread pool (default; the exact reader, any stream) */
+#define ACM_BATCH_PARSE_DEVICE 1u   /* one GPU lane per stream for clean streams; streams the device parser is not
+                                       sure about (data running out, corrupt symbols, hazard H1, rows > 512) are
+                                       re-parsed by the host reader.  Pays off for thousands of streams per batch. */
 
 typedef struct acm_batch_timing {
 	double stage_s;          /* host bit parsing (all threads), headers included */
 	double h2d_s, kernel_s, d2h_s, total_s;
 	uint64_t samples;
 	double alloc_s;          /* pinned + device arena allocation */
+	uint64_t device_parsed;  /* ACM_BATCH_PARSE_DEVICE: streams staged by the device parser ... */
+	uint64_t host_parsed;    /* ... and streams (re)parsed by the host reader */
 } acm_batch_timing;
 
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,

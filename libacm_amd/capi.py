@@ -50,12 +50,14 @@ class BatchItem(C.Structure):
 
 
 class BatchOpts(C.Structure):
-    _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint)]
+    _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint),
+                ("parse", C.c_uint)]
 
 
 class BatchTiming(C.Structure):
     _fields_ = [("stage_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double),
-                ("d2h_s", C.c_double), ("total_s", C.c_double), ("samples", C.c_uint64), ("alloc_s", C.c_double)]
+                ("d2h_s", C.c_double), ("total_s", C.c_double), ("samples", C.c_uint64), ("alloc_s", C.c_double),
+                ("device_parsed", C.c_uint64), ("host_parsed", C.c_uint64)]
 
 
 # every symbol include/acm_hip.h declares (checked by tests/test_abi.py)
@@ -336,7 +338,10 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
     return (res, st) if return_stats else res
 
 
-def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO):
+PARSE_HOST, PARSE_DEVICE = 0, 1
+
+
+def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST):
     """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming)."""
     n = len(files)
     bufs = [_as_u8(f) for f in files]
@@ -348,7 +353,7 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
         items[k].len = bufs[k].size
         items[k].pcm = outs[k].ctypes.data if outs[k].size else None
         items[k].pcm_cap = outs[k].size
-    opts = BatchOpts(force_chans, fmt, threads, flags)
+    opts = BatchOpts(force_chans, fmt, threads, flags, parse)
     tm = BatchTiming()
     _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
     return [(items[k].status, outs[k][:items[k].words]) for k in range(n)], tm

@@ -92,7 +92,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	acm_batch_opts opts{};
 	if (opts_in)
 		opts = *opts_in;
-	if (opts.fmt > 3)
+	if (opts.fmt > 3 || opts.parse > ACM_BATCH_PARSE_DEVICE)
 		return ACMHIP_ERR_ARG;
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
@@ -128,9 +128,26 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		pcm_total += round_up(s.need_blocks * bl, 64);
 	}
 
+	const bool dev_parse = (opts.parse == ACM_BATCH_PARSE_DEVICE);
+	uint64_t files_total = 0;
+	std::vector<uint64_t> file_off;
+	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
+	if (dev_parse) {
+		file_off.resize(n);
+		for (size_t i = 0; i < n; i++) {
+			const Slot &s = slots[i];
+			if (!s.ok || s.need_blocks == 0 || items[i].len >= 0xFFFFFFF0u || !acmk_parse_supported(s.info.level, s.info.rows))
+				continue;
+			file_off[i] = files_total;
+			files_total += round_up(items[i].len, 8) + 16;  /* zero tail: the device reader loads whole dwords */
+			dev_ids.push_back(i);
+		}
+	}
+
 	const auto t_hdr = clk::now();
-	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr;
+	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr, *d_idx_cm = nullptr;
 	acmhip_blkhdr *h_hdr = nullptr, *d_hdr = nullptr;
+	uint8_t *h_files = nullptr, *d_files = nullptr, *h_jobs = nullptr, *d_jobs = nullptr;
 	acmhip_plan *plan = nullptr;
 	int rc = ACMHIP_OK;
 	auto cleanup = [&]() {
@@ -146,14 +163,21 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
+	const size_t jobs_bytes = round_up(dev_ids.size() * sizeof(AcmParseJob), 64);
+	const size_t res_bytes = dev_ids.size() * sizeof(AcmParseResult);
+	if (!dev_ids.empty()) {
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_FILES, files_total, (void **)&h_files));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_FILES, files_total, (void **)&d_files));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX_CM, idx_total * sizeof(int16_t), (void **)&d_idx_cm));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, jobs_bytes + res_bytes, (void **)&h_jobs));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, jobs_bytes + res_bytes, (void **)&d_jobs));
+	}
 	const auto t_alloc = clk::now();
 	tm.alloc_s = secs(t_hdr, t_alloc);
 
-	/* 2. bit parsing, one stream per task */
-	parallel_for(n, opts.threads, [&](size_t i) {
+	/* 2. bit parsing, one stream per task: the exact host reader ... */
+	auto host_stage = [&](size_t i) {
 		Slot &s = slots[i];
-		if (!s.ok)
-			return;
 		acm_batch_item &it = items[i];
 		acm_stage_info info{};
 		/* first pass counts patches (normally zero), second only if there are any */
@@ -172,9 +196,79 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		s.info = info;
 		it.status = info.end_status;
 		it.words = deliverable_words(info.total_values, (uint64_t)info.rows * info.cols, info.channels, info.blocks);
-	});
+	};
+	std::vector<size_t> host_ids;                   /* streams the host reader stages */
+	double h2d_files_s = 0;
+	if (!dev_parse) {
+		for (size_t i = 0; i < n; i++)
+			if (slots[i].ok)
+				host_ids.push_back(i);
+	} else {
+		/* ... or one device lane per stream, with the host reader behind it for everything unusual */
+		std::vector<char> on_dev(n, 0);
+		AcmParseJob *jobs = reinterpret_cast<AcmParseJob *>(h_jobs);
+		AcmParseResult *results = reinterpret_cast<AcmParseResult *>(h_jobs + jobs_bytes);
+		uint32_t max_blocks = 0, max_cols = 0;
+		for (size_t k = 0; k < dev_ids.size(); k++) {
+			const Slot &s = slots[dev_ids[k]];
+			on_dev[dev_ids[k]] = 1;
+			AcmParseJob &j = jobs[k];
+			j.file_off = file_off[dev_ids[k]];
+			j.idx_off = s.idx_off;
+			j.hdr_off = s.hdr_off;
+			j.file_len = (uint32_t)items[dev_ids[k]].len;
+			j.data_start = (uint32_t)s.info.header_bytes;
+			j.level = s.info.level;
+			j.rows = s.info.rows;
+			j.blocks = (uint32_t)s.need_blocks;
+			j.pad = 0;
+			max_blocks = std::max(max_blocks, j.blocks);
+			max_cols = std::max(max_cols, s.info.cols);
+		}
+		parallel_for(dev_ids.size(), opts.threads, [&](size_t k) {
+			const acm_batch_item &it = items[dev_ids[k]];
+			uint8_t *dst = h_files + file_off[dev_ids[k]];
+			memcpy(dst, it.data, it.len);
+			memset(dst + it.len, 0, round_up(it.len, 8) + 16 - it.len);
+		});
+		for (size_t i = 0; i < n; i++)
+			if (slots[i].ok && !on_dev[i])
+				host_ids.push_back(i);
+		if (!dev_ids.empty()) {
+			const auto tu0 = clk::now();
+			BTRY(acmhip_upload(dev, d_files, h_files, files_total));
+			BTRY(acmhip_upload(dev, d_jobs, h_jobs, jobs_bytes));
+			BTRY(acmhip_device_sync(dev));
+			h2d_files_s = secs(tu0, clk::now());
+			rc = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_idx_cm,
+					       d_idx, d_hdr, reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes), max_blocks,
+					       max_cols, acmhip_device_stream(dev));
+			if (rc != 0) {
+				cleanup();
+				return ACMHIP_ERR_HIP;
+			}
+			BTRY(acmhip_download(dev, results, d_jobs + jobs_bytes, res_bytes));
+			BTRY(acmhip_device_sync(dev));
+			for (size_t k = 0; k < dev_ids.size(); k++) {
+				const size_t i = dev_ids[k];
+				Slot &s = slots[i];
+				if (results[k].status != 0 || results[k].blocks_done != s.need_blocks) {
+					host_ids.push_back(i);
+					continue;
+				}
+				s.info.blocks = (uint32_t)s.need_blocks;
+				s.info.end_status = ACM_OK;
+				items[i].status = ACM_OK;
+				items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols,
+								   s.info.channels, s.need_blocks);
+				tm.device_parsed++;
+			}
+		}
+	}
+	tm.host_parsed = host_ids.size();
+	parallel_for(host_ids.size(), opts.threads, [&](size_t k) { host_stage(host_ids[k]); });
 	const auto t1 = clk::now();
-	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t1);
+	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t1) - h2d_files_s;
 
 	/* 3. descriptors */
 	std::vector<acmhip_stream_desc> descs;
@@ -203,11 +297,22 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	}
 
 	/* 4. device round trip */
-	BTRY(acmhip_upload(dev, d_idx, h_idx, idx_total * sizeof(int16_t)));
-	BTRY(acmhip_upload(dev, d_hdr, h_hdr, hdr_total * sizeof(acmhip_blkhdr)));
+	if (!dev_parse) {
+		BTRY(acmhip_upload(dev, d_idx, h_idx, idx_total * sizeof(int16_t)));
+		BTRY(acmhip_upload(dev, d_hdr, h_hdr, hdr_total * sizeof(acmhip_blkhdr)));
+	} else {
+		for (size_t i : host_ids) {             /* only what the host reader had to stage itself */
+			const Slot &s = slots[i];
+			if (!s.ok || s.info.blocks == 0)
+				continue;
+			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+			BTRY(acmhip_upload(dev, d_idx + s.idx_off, h_idx + s.idx_off, s.info.blocks * bl * sizeof(int16_t)));
+			BTRY(acmhip_upload(dev, d_hdr + s.hdr_off, h_hdr + s.hdr_off, s.info.blocks * sizeof(acmhip_blkhdr)));
+		}
+	}
 	BTRY(acmhip_device_sync(dev));
 	const auto t2 = clk::now();
-	tm.h2d_s = secs(t1, t2);
+	tm.h2d_s = secs(t1, t2) + h2d_files_s;
 	BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &plan));
 	BTRY(acmhip_plan_launch(plan, d_idx, d_hdr, d_pcm, opts.fmt));
 	BTRY(acmhip_device_sync(dev));

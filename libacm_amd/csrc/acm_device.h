@@ -37,6 +37,23 @@ struct AcmDevPatch {
 	uint32_t pad;
 };
 
+/* device-side bit parsing (acm_parse.hip): one stream = one lane */
+struct AcmParseJob {
+	uint64_t file_off;     /* bytes into the file arena; multiple of 8, >= 16 zero bytes behind every file */
+	uint64_t idx_off;      /* int16 units into the staged-index arenas */
+	uint64_t hdr_off;      /* blkhdr units */
+	uint32_t file_len;     /* bytes */
+	uint32_t data_start;   /* first bitstream byte (14, or 42 behind a WAVC prefix) */
+	uint32_t level;
+	uint32_t rows;
+	uint32_t blocks;       /* blocks to parse */
+	uint32_t pad;
+};
+struct AcmParseResult {
+	uint32_t blocks_done;
+	uint32_t status;       /* 0 = every block parsed cleanly; else the host must re-parse this stream */
+};
+
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
 #define ACM_K1_MAX_LEVEL 11
@@ -44,10 +61,14 @@ struct AcmDevPatch {
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* grow-only staging arenas owned by a device handle (acm_hip_api.cpp): pinned host slots 0-2, device slots 3-5.
- * hipHostMalloc of gigabytes costs ~0.1 s; the batch front end reuses them across calls.  A device handle
- * serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
-enum { ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_SLOTS };
+/* grow-only staging arenas owned by a device handle (acm_hip_api.cpp): pinned host slots first, device slots
+ * from ACM_ARENA_D_IDX on.  hipHostMalloc of gigabytes costs ~0.1 s; the batch front end reuses them across
+ * calls.  A device handle serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
+enum {
+	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS,
+	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_IDX_CM, ACM_ARENA_D_JOBS,
+	ACM_ARENA_SLOTS
+};
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
 void acmhip_arena_lock(acmhip_device *dev);
 void acmhip_arena_unlock(acmhip_device *dev);
@@ -62,6 +83,9 @@ int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, ui
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);
 int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		      uint32_t level, uint32_t k, const int32_t *d_in, int32_t *d_out, void *stream);
+int acmk_parse_supported(uint32_t level, uint32_t rows);
+int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, int16_t *d_idx_cm, int16_t *d_idx_rm,
+		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t max_blocks, uint32_t max_cols, void *stream);
 int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
 		     const int32_t *d_x, int16_t *d_pcm, unsigned fmt, void *stream);
 #ifdef __cplusplus

@@ -167,8 +167,9 @@ def test_many_short_streams_stress_shape(dev):
         dev.free(p)
 
 
-def test_batch_decode_c_api(dev):
-    """acm_batch_decode: threaded host parsing -> one arena -> one launch; statuses and word counts follow
+@pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE])
+def test_batch_decode_c_api(dev, parse):
+    """acm_batch_decode: threaded host parsing (or device lanes with the host reader as fallback) -> one arena -> one launch; statuses and word counts follow
     what an acm_read_loop() caller of the reference would see (truncated, corrupt, non-ACM, odd stereo)"""
     from helpers import golden, golden_file
     files = [make_stream(3100 + i, [5, 7, 9, 0, 12][i % 5], [16, 3, 1][i % 3], 2 + i % 5, channels=1 + i % 2, cut=i % 3)
@@ -176,9 +177,11 @@ def test_batch_decode_c_api(dev):
     files += [golden_file(c["file"]) for c in golden()["F3_corrupt"]]
     files += [files[1][:len(files[1]) // 2], b"garbage", golden_file("f1_l0_r3_c2"), golden_file("f6_level0_rows1")]
     for fmt in (capi.FMT_S16LE, capi.FMT_U16BE):
-        res, tm = capi.batch_decode(dev, files, fmt=fmt, threads=4)
+        res, tm = capi.batch_decode(dev, files, fmt=fmt, threads=4, parse=parse)
         be, sg = fmt_args(fmt)
         total = 0
+        if parse == capi.PARSE_DEVICE:
+            assert tm.device_parsed >= 10 and tm.host_parsed >= 3      # clean streams on the GPU, broken ones not
         for (st, pcm), f in zip(res, files):
             import oracle_api as O
             o = O.Oracle(f)
@@ -193,3 +196,25 @@ def test_batch_decode_c_api(dev):
                 assert wst <= 0 and want.size < len(f) * 8
             total += want.size
         assert tm.samples == total
+
+
+def test_device_parser_every_filler(dev):
+    """ACM_BATCH_PARSE_DEVICE stages exactly what the host reader stages: every filler code, WAVC prefix, ragged
+    rows, hazard-H1 streams (flagged -> host), and many streams at once (more lanes than one wavefront)"""
+    from helpers import golden, golden_file
+    g = golden()
+    files = [golden_file(c["file"]) for fam in ("F1_matrix", "F2_codes", "F6_headers") for c in g[fam] if c["open"] == 0]
+    files += [golden_file("f5_wavc"), golden_file("f5_plain")]
+    files += [make_stream(5200 + i, [5, 6, 7, 8, 3, 10][i % 6], [16, 7, 1, 33, 512, 600][i % 6], 1 + i % 4,
+                          channels=1 + i % 2, cut=i % 5) for i in range(300)]
+    files += [make_stream(5900 + i, 6, 8, 3, prime_table=1, allow_out_of_range=1) for i in range(6)]
+    assert len(files) > 300
+    host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
+    devr, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE)
+    assert tm.device_parsed > 250
+    for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, devr)):
+        assert hs == ds and np.array_equal(hp, dp), k
+    import oracle_api as O
+    for k in range(0, len(files), 7):
+        want, _ = oracle_pcm(files[k])
+        assert np.array_equal(devr[k][1], want), k
