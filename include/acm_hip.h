@@ -184,7 +184,8 @@ int  acm_stage_file(const uint8_t *data, size_t len, int force_chans,
 /* ------------------------------------------------------------------------
  * Batch front end (no reference counterpart; BASELINE.json "batch-of-files").
  * Decodes n in-memory ACM files on ONE device: threaded host staging ->
- * pinned buffers -> H2D -> acmhip_plan_launch -> D2H.
+ * pinned buffers -> H2D -> acmhip_plan_launch -> D2H, pipelined in chunks of
+ * whole streams so that the five steps overlap.
  * ---------------------------------------------------------------------- */
 typedef struct acm_batch_item {
 	const uint8_t *data;     /* in:  file image */
@@ -211,8 +212,10 @@ typedef struct acm_batch_opts {
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
 
 typedef struct acm_batch_timing {
-	double stage_s;          /* host bit parsing (all threads), headers included */
-	double h2d_s, kernel_s, d2h_s, total_s;
+	double stage_s;          /* wall clock until the last stream was bit-parsed (headers included, allocation not) */
+	double h2d_s, kernel_s, d2h_s;   /* device-side durations summed over the pipeline's chunks; they overlap
+	                                    each other and the parsing, so they do not add up to total_s */
+	double total_s;          /* wall clock of the whole call */
 	uint64_t samples;
 	double alloc_s;          /* pinned + device arena allocation */
 	uint64_t device_parsed;  /* ACM_BATCH_PARSE_DEVICE: streams staged by the device parser ... */

@@ -2,11 +2,15 @@
  * acm_batch.cpp - batch-of-files front end on one device (include/acm_hip.h).
  *
  * No counterpart in the reference (it decodes one stream at a time on one
- * thread); this is the piece BASELINE.json's north_star adds:
- * independent streams are bit-parsed by a pool of host threads straight into
- * one pinned staging arena, shipped to HBM in one copy, synthesised by one
- * acmhip_plan_launch, and the PCM comes back in one copy.
+ * thread); this is the piece BASELINE.json's north_star adds.
+ * Independent streams are bit-parsed by a pool of host threads straight into one
+ * pinned staging arena, in arena order.  The arena is cut into chunks of whole
+ * streams; as soon as a chunk is parsed it goes H2D, is synthesised by one
+ * acmhip_plan_launch and read back on a second HIP stream, while the pool parses
+ * the next chunks and then hands finished PCM out to the callers' buffers.  So
+ * parsing, H2D, synthesis, D2H and the final copies all overlap.
  */
+#include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +18,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -53,24 +60,81 @@ int default_threads()
 	return std::min(hw, 64);
 }
 
-template <typename F>
-void parallel_for(size_t n, int threads, F fn)
-{
-	if (threads <= 0)
-		threads = default_threads();
-	threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n));
-	std::atomic<size_t> next{ 0 };
-	auto work = [&]() {
-		for (size_t i; (i = next.fetch_add(1)) < n;)
+/* A fixed set of worker threads that lives for one acm_batch_decode call.  run() is a blocking parallel-for
+ * (the caller works too); start()/wait() leave the caller free to drive the device meanwhile. */
+class Pool {
+public:
+	explicit Pool(int threads)
+	{
+		for (int t = 0; t < threads; t++)
+			workers_.emplace_back([this]() { loop(); });
+	}
+	~Pool()
+	{
+		{
+			std::lock_guard<std::mutex> g(m_);
+			quit_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_)
+			t.join();
+	}
+	void start(size_t n, std::function<void(size_t)> fn)
+	{
+		std::lock_guard<std::mutex> g(m_);
+		fn_ = std::move(fn);
+		n_ = n;
+		next_.store(0);
+		active_ = workers_.size();
+		gen_++;
+		cv_.notify_all();
+	}
+	void wait()
+	{
+		std::unique_lock<std::mutex> g(m_);
+		done_.wait(g, [this]() { return active_ == 0; });
+	}
+	void run(size_t n, const std::function<void(size_t)> &fn)
+	{
+		if (workers_.empty() || n <= 1) {
+			for (size_t i = 0; i < n; i++)
+				fn(i);
+			return;
+		}
+		start(n, fn);
+		for (size_t i; (i = next_.fetch_add(1)) < n;)
 			fn(i);
-	};
-	std::vector<std::thread> pool;
-	for (int t = 1; t < threads; t++)
-		pool.emplace_back(work);
-	work();
-	for (auto &t : pool)
-		t.join();
-}
+		wait();
+	}
+
+private:
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> g(m_);
+				cv_.wait(g, [&]() { return quit_ || gen_ != seen; });
+				if (quit_)
+					return;
+				seen = gen_;
+			}
+			for (size_t i; (i = next_.fetch_add(1)) < n_;)
+				fn_(i);
+			std::lock_guard<std::mutex> g(m_);
+			if (--active_ == 0)
+				done_.notify_all();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex m_;
+	std::condition_variable cv_, done_;
+	std::function<void(size_t)> fn_;
+	std::atomic<size_t> next_{ 0 };
+	size_t n_ = 0, active_ = 0;
+	uint64_t gen_ = 0;
+	bool quit_ = false;
+};
 
 inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
@@ -78,8 +142,22 @@ struct Slot {
 	acm_stage_info info{};
 	uint64_t need_blocks = 0;
 	uint64_t idx_off = 0, hdr_off = 0, pcm_off = 0;
+	uint64_t idx_len = 0;           /* arena words reserved (multiple of 64) */
 	std::vector<acmhip_patch> patches;
+	uint32_t chunk = 0;
 	bool ok = false;
+	bool host_staged = false;       /* staged by the host reader (its arena slice has to go H2D) */
+};
+
+/* a run of whole streams that travels through the device as one unit */
+struct Chunk {
+	size_t first = 0, last = 0;             /* stream index range [first, last) */
+	uint64_t idx_begin = 0, idx_end = 0;    /* arena ranges (int16 units; the PCM arena has the same layout) */
+	uint64_t hdr_begin = 0, hdr_end = 0;
+	std::atomic<int> unparsed{ 0 };
+	std::atomic<int> back{ 0 };             /* 1 = PCM is in the pinned arena, -1 = the read-back failed */
+	acmhip_plan *plan = nullptr;
+	hipEvent_t ev[5] = {};                  /* h2d begin, h2d end, kernel end (device stream); d2h begin, d2h end (copy stream) */
 };
 
 } // namespace
@@ -96,10 +174,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		return ACMHIP_ERR_ARG;
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
+	int threads = opts.threads > 0 ? opts.threads : default_threads();
+	threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n));
+	Pool pool(threads);
 
 	/* 1. headers -> arena layout */
 	std::vector<Slot> slots(n);
-	parallel_for(n, opts.threads, [&](size_t i) {
+	pool.run(n, [&](size_t i) {
 		Slot &s = slots[i];
 		acm_batch_item &it = items[i];
 		it.words = 0;
@@ -113,19 +194,50 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		if (s.ok) {
 			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
 			s.need_blocks = ((uint64_t)s.info.total_values + bl - 1) / bl;
+			s.idx_len = round_up(s.need_blocks * bl, 64);
 		}
 	});
-	uint64_t idx_total = 0, hdr_total = 0, pcm_total = 0;
+	uint64_t idx_total = 0, hdr_total = 0;
 	for (Slot &s : slots) {
 		if (!s.ok)
 			continue;
-		const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
-		s.idx_off = idx_total;
+		s.idx_off = s.pcm_off = idx_total;
 		s.hdr_off = hdr_total;
-		s.pcm_off = pcm_total;
-		idx_total += round_up(s.need_blocks * bl, 64);
+		idx_total += s.idx_len;
 		hdr_total += s.need_blocks;
-		pcm_total += round_up(s.need_blocks * bl, 64);
+	}
+	const uint64_t pcm_total = idx_total;
+
+	/* chunks of whole streams: about 1/16 of the batch each, but not below 8 MiB of staged indices */
+	const uint64_t chunk_target = std::max<uint64_t>(4u << 20, idx_total / 16);
+	std::vector<size_t> starts{ 0 };
+	{
+		uint64_t cut_at = 0;
+		for (size_t i = 0; i < n; i++)
+			if (slots[i].ok && slots[i].idx_off - cut_at >= chunk_target) {
+				starts.push_back(i);
+				cut_at = slots[i].idx_off;
+			}
+	}
+	std::vector<Chunk> chunks(starts.size());
+	for (size_t c = 0; c < chunks.size(); c++) {
+		Chunk &ch = chunks[c];
+		ch.first = starts[c];
+		ch.last = (c + 1 < chunks.size()) ? starts[c + 1] : n;
+		bool any = false;
+		for (size_t i = ch.first; i < ch.last; i++) {
+			Slot &s = slots[i];
+			if (!s.ok)
+				continue;
+			s.chunk = (uint32_t)c;
+			if (!any) {
+				ch.idx_begin = s.idx_off;
+				ch.hdr_begin = s.hdr_off;
+				any = true;
+			}
+			ch.idx_end = s.idx_off + s.idx_len;
+			ch.hdr_end = s.hdr_off + s.need_blocks;
+		}
 	}
 
 	const bool dev_parse = (opts.parse == ACM_BATCH_PARSE_DEVICE);
@@ -148,15 +260,39 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr, *d_idx_cm = nullptr;
 	acmhip_blkhdr *h_hdr = nullptr, *d_hdr = nullptr;
 	uint8_t *h_files = nullptr, *d_files = nullptr, *h_jobs = nullptr, *d_jobs = nullptr;
-	acmhip_plan *plan = nullptr;
+	hipStream_t st_main = (hipStream_t)acmhip_device_stream(dev), st_copy = nullptr;
 	int rc = ACMHIP_OK;
+	std::mutex m;
+	std::condition_variable cv;
+	std::atomic<size_t> issued{ 0 };                /* chunks whose read-back has been queued */
+	bool aborted = false;
+	bool pool_busy = false;
+
 	auto cleanup = [&]() {
-		acmhip_plan_destroy(plan);
+		if (pool_busy) {
+			{
+				std::lock_guard<std::mutex> g(m);
+				aborted = true;
+			}
+			cv.notify_all();
+			pool.wait();
+		}
+		(void)hipStreamSynchronize(st_main);
+		if (st_copy)
+			(void)hipStreamSynchronize(st_copy);
+		for (Chunk &ch : chunks) {
+			acmhip_plan_destroy(ch.plan);
+			for (hipEvent_t e : ch.ev)
+				if (e)
+					(void)hipEventDestroy(e);
+		}
 		acmhip_arena_unlock(dev);
 	};
 #define BTRY(call) do { rc = (call); if (rc != ACMHIP_OK) { cleanup(); return rc; } } while (0)
+#define HTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = acmhip_report_hip((int)e_, #call); cleanup(); return rc; } } while (0)
 	/* arenas live in the device handle and are reused by the next batch */
 	acmhip_arena_lock(dev);
+	BTRY(acmhip_copy_stream(dev, (void **)&st_copy));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
@@ -172,10 +308,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, jobs_bytes + res_bytes, (void **)&h_jobs));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, jobs_bytes + res_bytes, (void **)&d_jobs));
 	}
+	for (Chunk &ch : chunks)
+		for (hipEvent_t &e : ch.ev)
+			HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
 	const auto t_alloc = clk::now();
 	tm.alloc_s = secs(t_hdr, t_alloc);
 
-	/* 2. bit parsing, one stream per task: the exact host reader ... */
+	/* the exact host reader, one stream */
 	auto host_stage = [&](size_t i) {
 		Slot &s = slots[i];
 		acm_batch_item &it = items[i];
@@ -194,17 +333,19 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			return;
 		}
 		s.info = info;
+		s.host_staged = true;
 		it.status = info.end_status;
 		it.words = deliverable_words(info.total_values, (uint64_t)info.rows * info.cols, info.channels, info.blocks);
 	};
-	std::vector<size_t> host_ids;                   /* streams the host reader stages */
+
+	/* 2a. device lanes parse the clean streams (optional); whatever they flag joins the host list */
+	std::vector<size_t> host_ids;
 	double h2d_files_s = 0;
 	if (!dev_parse) {
 		for (size_t i = 0; i < n; i++)
 			if (slots[i].ok)
 				host_ids.push_back(i);
 	} else {
-		/* ... or one device lane per stream, with the host reader behind it for everything unusual */
 		std::vector<char> on_dev(n, 0);
 		AcmParseJob *jobs = reinterpret_cast<AcmParseJob *>(h_jobs);
 		AcmParseResult *results = reinterpret_cast<AcmParseResult *>(h_jobs + jobs_bytes);
@@ -225,113 +366,175 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			max_blocks = std::max(max_blocks, j.blocks);
 			max_cols = std::max(max_cols, s.info.cols);
 		}
-		parallel_for(dev_ids.size(), opts.threads, [&](size_t k) {
+		pool.run(dev_ids.size(), [&](size_t k) {
 			const acm_batch_item &it = items[dev_ids[k]];
 			uint8_t *dst = h_files + file_off[dev_ids[k]];
 			memcpy(dst, it.data, it.len);
 			memset(dst + it.len, 0, round_up(it.len, 8) + 16 - it.len);
 		});
-		for (size_t i = 0; i < n; i++)
-			if (slots[i].ok && !on_dev[i])
-				host_ids.push_back(i);
 		if (!dev_ids.empty()) {
 			const auto tu0 = clk::now();
-			BTRY(acmhip_upload(dev, d_files, h_files, files_total));
-			BTRY(acmhip_upload(dev, d_jobs, h_jobs, jobs_bytes));
-			BTRY(acmhip_device_sync(dev));
+			HTRY(hipMemcpyAsync(d_files, h_files, files_total, hipMemcpyHostToDevice, st_main));
+			HTRY(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, st_main));
+			HTRY(hipStreamSynchronize(st_main));
 			h2d_files_s = secs(tu0, clk::now());
-			rc = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_idx_cm,
-					       d_idx, d_hdr, reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes), max_blocks,
-					       max_cols, acmhip_device_stream(dev));
-			if (rc != 0) {
-				cleanup();
-				return ACMHIP_ERR_HIP;
-			}
-			BTRY(acmhip_download(dev, results, d_jobs + jobs_bytes, res_bytes));
-			BTRY(acmhip_device_sync(dev));
-			for (size_t k = 0; k < dev_ids.size(); k++) {
-				const size_t i = dev_ids[k];
-				Slot &s = slots[i];
-				if (results[k].status != 0 || results[k].blocks_done != s.need_blocks) {
-					host_ids.push_back(i);
-					continue;
-				}
-				s.info.blocks = (uint32_t)s.need_blocks;
-				s.info.end_status = ACM_OK;
-				items[i].status = ACM_OK;
-				items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols,
-								   s.info.channels, s.need_blocks);
-				tm.device_parsed++;
-			}
+			const int e = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files,
+							d_idx_cm, d_idx, d_hdr, reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes),
+							max_blocks, max_cols, st_main);
+			HTRY((hipError_t)e);
+			HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_main));
+			HTRY(hipStreamSynchronize(st_main));
 		}
+		for (size_t k = 0; k < dev_ids.size(); k++) {
+			const size_t i = dev_ids[k];
+			Slot &s = slots[i];
+			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks) {
+				on_dev[i] = 0;
+				continue;
+			}
+			s.info.blocks = (uint32_t)s.need_blocks;
+			s.info.end_status = ACM_OK;
+			items[i].status = ACM_OK;
+			items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols,
+							   s.info.channels, s.need_blocks);
+			tm.device_parsed++;
+		}
+		for (size_t i = 0; i < n; i++)
+			if (slots[i].ok && !on_dev[i])
+				host_ids.push_back(i);              /* ascending, i.e. arena order */
 	}
 	tm.host_parsed = host_ids.size();
-	parallel_for(host_ids.size(), opts.threads, [&](size_t k) { host_stage(host_ids[k]); });
-	const auto t1 = clk::now();
-	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t1) - h2d_files_s;
+	for (size_t i : host_ids)
+		chunks[slots[i].chunk].unparsed.fetch_add(1);
 
-	/* 3. descriptors */
-	std::vector<acmhip_stream_desc> descs;
-	std::vector<acmhip_patch> patches;
-	std::vector<size_t> owner;
-	for (size_t i = 0; i < n; i++) {
-		Slot &s = slots[i];
-		if (!s.ok || items[i].words == 0)
-			continue;
-		acmhip_stream_desc d{};
-		d.idx_off = s.idx_off;
-		d.hdr_off = s.hdr_off;
-		d.pcm_off = s.pcm_off;
-		d.level = s.info.level;
-		d.rows = s.info.rows;
-		d.nrows = s.info.blocks * s.info.rows;
-		d.row_begin = 0;
-		d.n_emit = items[i].words;
-		for (acmhip_patch p : s.patches) {
-			p.stream = (uint32_t)descs.size();
-			patches.push_back(p);
-		}
-		descs.push_back(d);
-		owner.push_back(i);
-		tm.samples += d.n_emit;
-	}
-
-	/* 4. device round trip */
-	if (!dev_parse) {
-		BTRY(acmhip_upload(dev, d_idx, h_idx, idx_total * sizeof(int16_t)));
-		BTRY(acmhip_upload(dev, d_hdr, h_hdr, hdr_total * sizeof(acmhip_blkhdr)));
-	} else {
-		for (size_t i : host_ids) {             /* only what the host reader had to stage itself */
-			const Slot &s = slots[i];
-			if (!s.ok || s.info.blocks == 0)
-				continue;
-			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
-			BTRY(acmhip_upload(dev, d_idx + s.idx_off, h_idx + s.idx_off, s.info.blocks * bl * sizeof(int16_t)));
-			BTRY(acmhip_upload(dev, d_hdr + s.hdr_off, h_hdr + s.hdr_off, s.info.blocks * sizeof(acmhip_blkhdr)));
-		}
-	}
-	BTRY(acmhip_device_sync(dev));
-	const auto t2 = clk::now();
-	tm.h2d_s = secs(t1, t2) + h2d_files_s;
-	BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &plan));
-	BTRY(acmhip_plan_launch(plan, d_idx, d_hdr, d_pcm, opts.fmt));
-	BTRY(acmhip_device_sync(dev));
-	const auto t3 = clk::now();
-	tm.kernel_s = secs(t2, t3);
-	BTRY(acmhip_download(dev, h_pcm, d_pcm, pcm_total * sizeof(int16_t)));
-	BTRY(acmhip_device_sync(dev));
-	const auto t4 = clk::now();
-	tm.d2h_s = secs(t3, t4);
-#undef BTRY
-
-	/* 5. hand the PCM out */
-	parallel_for(owner.size(), opts.threads, [&](size_t k) {
-		acm_batch_item &it = items[owner[k]];
-		if (!it.pcm)
+	/* 2b. the pool: parse in arena order, then copy finished PCM out as the chunks come back */
+	std::vector<size_t> out_ids;
+	for (size_t i = 0; i < n; i++)
+		if (slots[i].ok && items[i].pcm)
+			out_ids.push_back(i);
+	std::atomic<size_t> parsed{ 0 };
+	clk::time_point t_parsed = clk::now();
+	const size_t nparse = host_ids.size();
+	pool_busy = true;
+	pool.start(nparse + out_ids.size(), [&](size_t task) {
+		if (task < nparse) {
+			const size_t i = host_ids[task];
+			const uint32_t c = slots[i].chunk;
+			host_stage(i);
+			if (parsed.fetch_add(1) + 1 == nparse)
+				t_parsed = clk::now();
+			if (chunks[c].unparsed.fetch_sub(1) == 1) {
+				std::lock_guard<std::mutex> g(m);
+				cv.notify_all();
+			}
 			return;
-		const uint64_t w = std::min<uint64_t>(it.words, it.pcm_cap);
-		memcpy(it.pcm, h_pcm + slots[owner[k]].pcm_off, w * sizeof(int16_t));
+		}
+		const size_t i = out_ids[task - nparse];
+		const Slot &s = slots[i];
+		Chunk &ch = chunks[s.chunk];
+		if (ch.back.load(std::memory_order_acquire) == 0) {     /* first one here waits for the chunk */
+			if (issued.load(std::memory_order_acquire) <= s.chunk) {
+				std::unique_lock<std::mutex> g(m);
+				cv.wait(g, [&]() { return aborted || issued.load() > s.chunk; });
+				if (aborted)
+					return;
+			}
+			const bool good = hipEventSynchronize(ch.ev[4]) == hipSuccess;
+			ch.back.store(good ? 1 : -1, std::memory_order_release);
+		}
+		if (ch.back.load(std::memory_order_acquire) < 0 || !s.ok || items[i].words == 0)
+			return;
+		const uint64_t w = std::min<uint64_t>(items[i].words, items[i].pcm_cap);
+		memcpy(items[i].pcm, h_pcm + s.pcm_off, w * sizeof(int16_t));
 	});
+
+	/* 3. this thread feeds the device, chunk by chunk */
+	for (size_t c = 0; c < chunks.size(); c++) {
+		Chunk &ch = chunks[c];
+		{
+			std::unique_lock<std::mutex> g(m);
+			cv.wait(g, [&]() { return ch.unparsed.load() == 0; });
+		}
+		std::vector<acmhip_stream_desc> descs;
+		std::vector<acmhip_patch> patches;
+		for (size_t i = ch.first; i < ch.last; i++) {
+			Slot &s = slots[i];
+			if (!s.ok || items[i].words == 0)
+				continue;
+			acmhip_stream_desc d{};
+			d.idx_off = s.idx_off;
+			d.hdr_off = s.hdr_off;
+			d.pcm_off = s.pcm_off;
+			d.level = s.info.level;
+			d.rows = s.info.rows;
+			d.nrows = s.info.blocks * s.info.rows;
+			d.row_begin = 0;
+			d.n_emit = items[i].words;
+			for (acmhip_patch p : s.patches) {
+				p.stream = (uint32_t)descs.size();
+				patches.push_back(p);
+			}
+			descs.push_back(d);
+			tm.samples += d.n_emit;
+		}
+		if (!descs.empty()) {
+			BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan));
+			HTRY(hipEventRecord(ch.ev[0], st_main));
+			if (!dev_parse) {
+				HTRY(hipMemcpyAsync(d_idx + ch.idx_begin, h_idx + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
+						    hipMemcpyHostToDevice, st_main));
+				HTRY(hipMemcpyAsync(d_hdr + ch.hdr_begin, h_hdr + ch.hdr_begin, (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr),
+						    hipMemcpyHostToDevice, st_main));
+			} else {
+				for (size_t i = ch.first; i < ch.last; i++) {   /* only what the host reader staged itself */
+					const Slot &s = slots[i];
+					if (!s.ok || !s.host_staged || s.info.blocks == 0)
+						continue;
+					const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+					HTRY(hipMemcpyAsync(d_idx + s.idx_off, h_idx + s.idx_off, s.info.blocks * bl * sizeof(int16_t),
+							    hipMemcpyHostToDevice, st_main));
+					HTRY(hipMemcpyAsync(d_hdr + s.hdr_off, h_hdr + s.hdr_off, s.info.blocks * sizeof(acmhip_blkhdr),
+							    hipMemcpyHostToDevice, st_main));
+				}
+			}
+			HTRY(hipEventRecord(ch.ev[1], st_main));
+			BTRY(acmhip_plan_launch(ch.plan, d_idx, d_hdr, d_pcm, opts.fmt));
+			HTRY(hipEventRecord(ch.ev[2], st_main));
+			HTRY(hipStreamWaitEvent(st_copy, ch.ev[2], 0));
+			HTRY(hipEventRecord(ch.ev[3], st_copy));
+			HTRY(hipMemcpyAsync(h_pcm + ch.idx_begin, d_pcm + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
+					    hipMemcpyDeviceToHost, st_copy));
+		}
+		HTRY(hipEventRecord(ch.ev[4], st_copy));
+		{
+			std::lock_guard<std::mutex> g(m);
+			issued.store(c + 1, std::memory_order_release);
+		}
+		cv.notify_all();
+	}
+	pool.wait();
+	pool_busy = false;
+	HTRY(hipStreamSynchronize(st_copy));
+	HTRY(hipStreamSynchronize(st_main));
+#undef BTRY
+#undef HTRY
+
+	/* the phases overlap; report the device-side time each one took (summed over chunks) and the wall clock */
+	for (Chunk &ch : chunks) {
+		if (!ch.plan)
+			continue;
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, ch.ev[0], ch.ev[1]) == hipSuccess)
+			tm.h2d_s += ms * 1e-3;
+		if (hipEventElapsedTime(&ms, ch.ev[1], ch.ev[2]) == hipSuccess)
+			tm.kernel_s += ms * 1e-3;
+		if (hipEventElapsedTime(&ms, ch.ev[3], ch.ev[4]) == hipSuccess)
+			tm.d2h_s += ms * 1e-3;
+	}
+	tm.h2d_s += h2d_files_s;
+	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t_parsed) - h2d_files_s;
+	if (tm.stage_s < 0)
+		tm.stage_s = 0;
 	tm.total_s = secs(t0, clk::now());
 	if (timing)
 		*timing = tm;

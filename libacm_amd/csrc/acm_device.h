@@ -72,6 +72,8 @@ enum {
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
 void acmhip_arena_lock(acmhip_device *dev);
 void acmhip_arena_unlock(acmhip_device *dev);
+int acmhip_copy_stream(acmhip_device *dev, void **out);          /* second stream for overlapped read-back */
+int acmhip_report_hip(int hip_error, const char *what);          /* records the text, returns ACMHIP_ERR_HIP */
 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */

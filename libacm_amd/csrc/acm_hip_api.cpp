@@ -44,6 +44,7 @@ struct acmhip_device {
 	int ordinal;
 	hipStream_t stream;
 	bool own_stream;
+	hipStream_t copy_stream = nullptr;      /* read-back stream of the batch pipeline, created on first use */
 	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
@@ -141,6 +142,8 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 		else
 			(void)hipFree(dev->arena[k]);
 	}
+	if (dev->copy_stream)
+		(void)hipStreamDestroy(dev->copy_stream);
 	if (dev->own_stream)
 		(void)hipStreamDestroy(dev->stream);
 	delete dev;
@@ -172,6 +175,22 @@ extern "C" int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void
 	}
 	*out = dev->arena[slot];
 	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_copy_stream(acmhip_device *dev, void **out)
+{
+	if (!dev || !out)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipSetDevice(dev->ordinal));             /* also makes the device current for the calling thread */
+	if (!dev->copy_stream)
+		HIPTRY(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
+	*out = (void *)dev->copy_stream;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_report_hip(int hip_error, const char *what)
+{
+	return hip_fail((hipError_t)hip_error, what);
 }
 
 extern "C" void acmhip_arena_lock(acmhip_device *dev)
