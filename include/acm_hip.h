@@ -208,7 +208,7 @@ typedef struct acm_batch_opts {
 /* where the bit parsing of a batch runs */
 #define ACM_BATCH_PARSE_HOST   0u   /* host thread pool (default; the exact reader, any stream) */
 #define ACM_BATCH_PARSE_DEVICE 1u   /* one GPU lane per stream for clean streams; streams the device parser is not
-                                       sure about (data running out, corrupt symbols, hazard H1, rows > 512) are
+                                       sure about (data running out, corrupt symbols, hazard H1, files >= 512 MiB) are
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
 
 typedef struct acm_batch_timing {

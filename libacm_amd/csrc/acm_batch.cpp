@@ -241,23 +241,25 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	}
 
 	const bool dev_parse = (opts.parse == ACM_BATCH_PARSE_DEVICE);
-	uint64_t files_total = 0;
+	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
 	if (dev_parse) {
 		file_off.resize(n);
 		for (size_t i = 0; i < n; i++) {
 			const Slot &s = slots[i];
-			if (!s.ok || s.need_blocks == 0 || items[i].len >= 0xFFFFFFF0u || !acmk_parse_supported(s.info.level, s.info.rows))
+			if (!s.ok || !acmk_parse_supported(s.info.level, s.info.rows, items[i].len, s.need_blocks))
 				continue;
 			file_off[i] = files_total;
-			files_total += round_up(items[i].len, 8) + 16;  /* zero tail: the device reader loads whole dwords */
+			files_total += round_up(items[i].len, 16) + 16; /* zero tail: the device readers load whole dwords */
+			cols_total += s.need_blocks << s.info.level;
 			dev_ids.push_back(i);
 		}
 	}
 
 	const auto t_hdr = clk::now();
-	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr, *d_idx_cm = nullptr;
+	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr;
+	uint32_t *d_colpos = nullptr;
 	acmhip_blkhdr *h_hdr = nullptr, *d_hdr = nullptr;
 	uint8_t *h_files = nullptr, *d_files = nullptr, *h_jobs = nullptr, *d_jobs = nullptr;
 	hipStream_t st_main = (hipStream_t)acmhip_device_stream(dev), st_copy = nullptr;
@@ -300,11 +302,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
 	const size_t jobs_bytes = round_up(dev_ids.size() * sizeof(AcmParseJob), 64);
-	const size_t res_bytes = dev_ids.size() * sizeof(AcmParseResult);
+	const size_t res_bytes = dev_ids.size() * (sizeof(AcmParseResult) + sizeof(uint32_t));  /* results, then flags */
 	if (!dev_ids.empty()) {
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_FILES, files_total, (void **)&h_files));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_FILES, files_total, (void **)&d_files));
-		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX_CM, idx_total * sizeof(int16_t), (void **)&d_idx_cm));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_COLPOS, cols_total * sizeof(uint32_t), (void **)&d_colpos));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, jobs_bytes + res_bytes, (void **)&h_jobs));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, jobs_bytes + res_bytes, (void **)&d_jobs));
 	}
@@ -349,7 +351,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		std::vector<char> on_dev(n, 0);
 		AcmParseJob *jobs = reinterpret_cast<AcmParseJob *>(h_jobs);
 		AcmParseResult *results = reinterpret_cast<AcmParseResult *>(h_jobs + jobs_bytes);
-		uint32_t max_blocks = 0, max_cols = 0;
+		const uint32_t *flags = reinterpret_cast<const uint32_t *>(results + dev_ids.size());
+		uint64_t max_columns = 0, col_off = 0;
 		for (size_t k = 0; k < dev_ids.size(); k++) {
 			const Slot &s = slots[dev_ids[k]];
 			on_dev[dev_ids[k]] = 1;
@@ -357,20 +360,21 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			j.file_off = file_off[dev_ids[k]];
 			j.idx_off = s.idx_off;
 			j.hdr_off = s.hdr_off;
+			j.col_off = col_off;
 			j.file_len = (uint32_t)items[dev_ids[k]].len;
 			j.data_start = (uint32_t)s.info.header_bytes;
 			j.level = s.info.level;
 			j.rows = s.info.rows;
 			j.blocks = (uint32_t)s.need_blocks;
 			j.pad = 0;
-			max_blocks = std::max(max_blocks, j.blocks);
-			max_cols = std::max(max_cols, s.info.cols);
+			col_off += s.need_blocks << s.info.level;
+			max_columns = std::max<uint64_t>(max_columns, s.need_blocks << s.info.level);
 		}
 		pool.run(dev_ids.size(), [&](size_t k) {
 			const acm_batch_item &it = items[dev_ids[k]];
 			uint8_t *dst = h_files + file_off[dev_ids[k]];
 			memcpy(dst, it.data, it.len);
-			memset(dst + it.len, 0, round_up(it.len, 8) + 16 - it.len);
+			memset(dst + it.len, 0, round_up(it.len, 16) + 16 - it.len);
 		});
 		if (!dev_ids.empty()) {
 			const auto tu0 = clk::now();
@@ -378,9 +382,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			HTRY(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, st_main));
 			HTRY(hipStreamSynchronize(st_main));
 			h2d_files_s = secs(tu0, clk::now());
+			AcmParseResult *d_res = reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes);
+			uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_res + dev_ids.size());
+			HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_main));
 			const int e = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files,
-							d_idx_cm, d_idx, d_hdr, reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes),
-							max_blocks, max_cols, st_main);
+							d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, st_main);
 			HTRY((hipError_t)e);
 			HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_main));
 			HTRY(hipStreamSynchronize(st_main));
@@ -388,7 +394,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		for (size_t k = 0; k < dev_ids.size(); k++) {
 			const size_t i = dev_ids[k];
 			Slot &s = slots[i];
-			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks) {
+			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0) {
 				on_dev[i] = 0;
 				continue;
 			}

@@ -39,9 +39,10 @@ struct AcmDevPatch {
 
 /* device-side bit parsing (acm_parse.hip): one stream = one lane */
 struct AcmParseJob {
-	uint64_t file_off;     /* bytes into the file arena; multiple of 8, >= 16 zero bytes behind every file */
+	uint64_t file_off;     /* bytes into the file arena; multiple of 16, >= 16 zero bytes behind every file */
 	uint64_t idx_off;      /* int16 units into the staged-index arenas */
 	uint64_t hdr_off;      /* blkhdr units */
+	uint64_t col_off;      /* uint32 units into the column-offset arena (blocks * cols entries per stream) */
 	uint32_t file_len;     /* bytes */
 	uint32_t data_start;   /* first bitstream byte (14, or 42 behind a WAVC prefix) */
 	uint32_t level;
@@ -51,7 +52,7 @@ struct AcmParseJob {
 };
 struct AcmParseResult {
 	uint32_t blocks_done;
-	uint32_t status;       /* 0 = every block parsed cleanly; else the host must re-parse this stream */
+	uint32_t status;       /* 0 = the scan walked every block; else the host must re-parse this stream */
 };
 
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
@@ -66,7 +67,7 @@ extern "C" {
  * calls.  A device handle serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
 enum {
 	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS,
-	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_IDX_CM, ACM_ARENA_D_JOBS,
+	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_COLPOS, ACM_ARENA_D_JOBS,
 	ACM_ARENA_SLOTS
 };
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
@@ -85,9 +86,9 @@ int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, ui
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);
 int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		      uint32_t level, uint32_t k, const int32_t *d_in, int32_t *d_out, void *stream);
-int acmk_parse_supported(uint32_t level, uint32_t rows);
-int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, int16_t *d_idx_cm, int16_t *d_idx_rm,
-		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t max_blocks, uint32_t max_cols, void *stream);
+int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file_len, uint64_t blocks);
+int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
+		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream);
 int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
 		     const int32_t *d_x, int16_t *d_pcm, unsigned fmt, void *stream);
 #ifdef __cplusplus
