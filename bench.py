@@ -271,14 +271,18 @@ def main():
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
         if not args.no_cpu and len(batch.files) > 4:
-            # informational: file bytes -> PCM in host memory through acm_batch_decode (host parsing on all
-            # cores + PCIe both ways); by contract this is NOT `value`
+            # informational: file bytes -> PCM in host memory through acm_batch_decode (bit parsing on the host pool
+            # or on device lanes, PCIe both ways, pipelined); by contract this is NOT `value`
             try:
-                res, tm = capi.batch_decode(dev, [f.tobytes() for f in batch.files], threads=0)
-                out["end_to_end"] = {"streams": len(batch.files), "msamples_s": round(tm.samples / tm.total_s / 1e6, 1),
-                                     "parse_s": round(tm.stage_s, 3), "alloc_s": round(tm.alloc_s, 3), "h2d_s": round(tm.h2d_s, 3),
-                                     "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
-                                     "total_s": round(tm.total_s, 3), "host_threads": workload_cpus()}
+                files = [f.tobytes() for f in batch.files]
+                e2e = {"streams": len(files), "host_threads": workload_cpus()}
+                for name, mode in (("host_parse", capi.PARSE_HOST), ("device_parse", capi.PARSE_DEVICE)):
+                    capi.batch_decode(dev, files, threads=0, parse=mode)          # first call sizes the arenas
+                    res, tm = capi.batch_decode(dev, files, threads=0, parse=mode)
+                    e2e[name] = {"msamples_s": round(tm.samples / tm.total_s / 1e6, 1), "parse_s": round(tm.stage_s, 3),
+                                 "h2d_s": round(tm.h2d_s, 3), "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
+                                 "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed}
+                out["end_to_end"] = e2e
             except Exception as e:
                 out["end_to_end"] = {"error": str(e)[:200]}
         if not args.no_cpu:

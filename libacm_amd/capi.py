@@ -338,7 +338,7 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
     return (res, st) if return_stats else res
 
 
-PARSE_HOST, PARSE_DEVICE = 0, 1
+PARSE_HOST, PARSE_DEVICE, PARSE_AUTO = 0, 1, 2
 
 
 def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST):

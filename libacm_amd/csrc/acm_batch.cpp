@@ -170,7 +170,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	acm_batch_opts opts{};
 	if (opts_in)
 		opts = *opts_in;
-	if (opts.fmt > 3 || opts.parse > ACM_BATCH_PARSE_DEVICE)
+	if (opts.fmt > 3 || opts.parse > ACM_BATCH_PARSE_AUTO)
 		return ACMHIP_ERR_ARG;
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
@@ -240,7 +240,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 	}
 
-	const bool dev_parse = (opts.parse == ACM_BATCH_PARSE_DEVICE);
+	const bool dev_parse = opts.parse == ACM_BATCH_PARSE_DEVICE || (opts.parse == ACM_BATCH_PARSE_AUTO && n >= 2048);
 	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */

@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int SCAN_THREADS = 64;
+constexpr uint32_t K_WALK = 0xFFFFFFFEu, BAD_CODE = 0xFFFFFFFFu;
 constexpr int COL_THREADS = 256;
 
 /* ---- bit window over a file image (arena slots are 16-byte aligned with >= 16 zero bytes behind the file) ---- */
@@ -158,6 +159,15 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 	DevBits bs;
 	bs.seek(reinterpret_cast<const uint32_t *>(files + job.file_off), job.data_start * 8u);
 
+	/* payload bits of a column by filler code, for this stream's row count; K_WALK = step through it, BAD_CODE = stop */
+	extern __shared__ uint32_t scan_lds[];
+	uint32_t *collen = scan_lds + threadIdx.x * 33;
+	for (uint32_t code = 0; code < 32; code++) {
+		const uint32_t cls = code_class(code);
+		collen[code] = cls == CLS_ZERO ? 0u : cls == CLS_LINEAR ? rows * code : cls == CLS_K ? K_WALK : cls == CLS_BAD ? BAD_CODE :
+			       code == 19 ? (rows + 2) / 3 * 5 : code == 22 ? (rows + 2) / 3 * 7 : (rows + 1) / 2 * 7;
+	}
+
 	uint32_t done = 0, status = 0;
 	uint32_t *cp = colpos + job.col_off;
 	for (uint32_t b = 0; b < job.blocks; b++) {
@@ -174,12 +184,10 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 			}
 			cp[c] = bs.bit;
 			const uint32_t code = bs.get(5);
-			const uint32_t cls = code_class(code);
-			if (cls == CLS_LINEAR) {
-				bs.skip(rows * code);
-			} else if (cls == CLS_TERN) {
-				bs.skip(code == 19 ? (rows + 2) / 3 * 5 : code == 22 ? (rows + 2) / 3 * 7 : (rows + 1) / 2 * 7);
-			} else if (cls == CLS_K) {
+			const uint32_t len = collen[code];
+			if (len < K_WALK) {
+				bs.skip(len);
+			} else if (len == K_WALK) {
 				const uint32_t tab = k_table_for(code);
 				uint32_t r = 0;
 				while (r < rows && bs.bit < safe) {
@@ -190,7 +198,7 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 				}
 				if (r < rows)
 					status = 1;                     /* ran out of data inside the column */
-			} else if (cls == CLS_BAD) {
+			} else {
 				status = 1;
 			}
 			if (status || bs.bit > safe) {                  /* the column must end inside the file */
@@ -366,7 +374,8 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 	hipStream_t st = (hipStream_t)stream;
 	const uint32_t full = (njobs + SCAN_THREADS - 1) / SCAN_THREADS;
 	const uint32_t scan_waves = njobs < 8192u ? njobs : full < 8192u ? 8192u : full;
-	hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), 0, st,
+	const uint32_t scan_lanes = (njobs + scan_waves - 1) / scan_waves;
+	hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
 			   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
 	ACMP_CHECK();
 	uint64_t gx = (max_columns + COL_THREADS - 1) / COL_THREADS;

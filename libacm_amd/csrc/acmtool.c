@@ -243,6 +243,7 @@ static int decode_batch(int nfiles, char **names)
 
 	memset(&opts, 0, sizeof(opts));
 	opts.force_chans = cfg.force_chans;
+	opts.parse = ACM_BATCH_PARSE_AUTO;
 	for (i = 0; i < nfiles; i++) {
 		unsigned char *data = NULL;
 		acm_stage_info si;

@@ -6,11 +6,15 @@ import numpy as np
 from libacm_amd import capi, synth
 
 dev = capi.Device(0)
+import os
+extra = {}
+if os.environ.get("SINGLE_CODE"):       # every column the same filler (isolates one parser path)
+    extra = dict(mix=synth.MIX_SINGLE, single_code=int(os.environ["SINGLE_CODE"]), pwr_min=12, pwr_max=12)
 shapes = [(int(a), int(b), int(c), int(d)) for a, b, c, d in
           (s.split("x") for s in (sys.argv[1:] or ["1024x7x16x250", "8192x7x16x32", "32768x7x16x8", "65536x5x8x16"]))]
 for n, level, rows, nblocks in shapes:
     with ThreadPoolExecutor(32) as ex:
-        files = list(ex.map(lambda i: synth.generate(seed=synth.BASE_SEED + i, level=level, rows=rows, nblocks=nblocks), range(n)))
+        files = list(ex.map(lambda i: synth.generate(seed=synth.BASE_SEED + i, level=level, rows=rows, nblocks=nblocks, **extra), range(n)))
     ref = None
     for parse, name in ((capi.PARSE_HOST, "host"), (capi.PARSE_DEVICE, "device")):
         for rep in range(2):

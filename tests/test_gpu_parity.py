@@ -218,3 +218,17 @@ def test_device_parser_every_filler(dev):
     for k in range(0, len(files), 7):
         want, _ = oracle_pcm(files[k])
         assert np.array_equal(devr[k][1], want), k
+
+
+def test_batch_parse_auto_many_streams(dev):
+    """ACM_BATCH_PARSE_AUTO switches to the device parser from 2048 streams on; tiny streams, a few broken ones"""
+    files = [make_stream(7000 + i, 5 + i % 2, 4, 1 + i % 3, channels=1 + i % 2, cut=i % 4) for i in range(2100)]
+    files[17] = files[17][:30]
+    files[1999] = b"nope"
+    auto, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_AUTO)
+    assert tm.device_parsed >= 2090 and tm.host_parsed >= 1
+    few, tm2 = capi.batch_decode(dev, files[:100], threads=4, parse=capi.PARSE_AUTO)
+    assert tm2.device_parsed == 0
+    host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
+    for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, auto)):
+        assert hs == ds and np.array_equal(hp, dp), k
