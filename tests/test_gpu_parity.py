@@ -232,3 +232,24 @@ def test_batch_parse_auto_many_streams(dev):
     host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
     for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, auto)):
         assert hs == ds and np.array_equal(hp, dp), k
+
+
+@pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE, capi.PARSE_AUTO])
+def test_batch_edge_cases(dev, parse):
+    """empty batch, nothing decodable, a single stream, one parser thread, repeated calls on the same handle"""
+    res, tm = capi.batch_decode(dev, [], parse=parse)
+    assert res == [] and tm.samples == 0
+    res, tm = capi.batch_decode(dev, [b"", b"x" * 13, b"garbage" * 10], parse=parse)
+    assert all(st < 0 and pcm.size == 0 for st, pcm in res) and tm.samples == 0
+    one = make_stream(8100, 7, 16, 40)
+    want, _ = oracle_pcm(one)
+    for threads in (1, 3):
+        for _ in range(2):
+            res, tm = capi.batch_decode(dev, [one], threads=threads, parse=parse)
+            assert res[0][0] == 0 and np.array_equal(res[0][1], want)
+    # many chunks: more streams than the 8 MiB chunk floor holds, so the pipeline really cycles
+    files = [make_stream(8200 + i, 8, 16, 24, cut=i) for i in range(96)]          # 96 x 98 K samples
+    res, tm = capi.batch_decode(dev, files, threads=5, parse=parse)
+    for k in (0, 31, 64, 95):
+        want, _ = oracle_pcm(files[k])
+        assert res[k][0] == 0 and np.array_equal(res[k][1], want), k
