@@ -195,6 +195,8 @@ typedef struct acm_batch_item {
 	uint64_t words;          /* out: words actually decoded (<= total_values) */
 	int32_t  status;         /* out: ACM_OK, or the ACM_ERR_* that ended the stream / rejected the file */
 	uint32_t level, rows, channels, rate, total_values;   /* out */
+	uint32_t reserved;
+	uint64_t dev_off;        /* out: 16-bit word offset of this stream's PCM inside opts->d_pcm (device-resident output) */
 } acm_batch_item;
 
 typedef struct acm_batch_opts {
@@ -203,6 +205,11 @@ typedef struct acm_batch_opts {
 	int      threads;        /* host staging threads, 0 = hardware concurrency */
 	unsigned plan_flags;     /* ACMHIP_PLAN_* */
 	unsigned parse;          /* ACM_BATCH_PARSE_* */
+	unsigned reserved;
+	void    *d_pcm;          /* NULL: PCM goes to items[i].pcm in host memory.  Otherwise a device buffer of
+	                            d_pcm_words 16-bit words (>= acm_batch_pcm_words()): PCM stays in HBM, stream i at
+	                            d_pcm + items[i].dev_off, nothing is copied back (items[i].pcm is ignored) */
+	uint64_t d_pcm_words;
 } acm_batch_opts;
 
 /* where the bit parsing of a batch runs */
@@ -226,6 +233,10 @@ typedef struct acm_batch_timing {
 
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,
 		      const acm_batch_opts *opts, acm_batch_timing *timing);
+
+/* 16-bit words of device memory acm_batch_decode needs for the PCM of these files (headers only are read;
+ * every stream is padded to a multiple of 64 words) - the size of opts->d_pcm for device-resident output */
+uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, int force_chans);
 
 #ifdef __cplusplus
 }

@@ -43,46 +43,26 @@ class GpuDecoder:
     Device memory and the stream belong to torch (plumbing); parsing and synthesis are libacm_hip.so's.
     """
 
-    def __init__(self, ordinal=None, fmt=capi.FMT_S16LE):
+    def __init__(self, ordinal=None, fmt=capi.FMT_S16LE, parse=capi.PARSE_AUTO):
         import torch
         self.torch = torch
         if ordinal is None:
             ordinal = torch.cuda.current_device()
         self.ordinal = ordinal
         self.fmt = fmt
+        self.parse = parse
+        self.timing = None
         torch.cuda.set_device(ordinal)
         self.dev = capi.Device(ordinal, torch.cuda.current_stream().cuda_stream)
 
     def __call__(self, files):
+        """-> (pcm int16 tensor in HBM, per-file word offsets into it, per-file word counts, per-file statuses)"""
         torch = self.torch
-        staged, statuses = [], []
-        for f in files:
-            try:
-                s = capi.stage_file(f)
-                staged.append(s)
-                statuses.append(int(s.info.end_status))
-            except ValueError:
-                staged.append(None)
-                statuses.append(-3)                         # ACM_ERR_NOT_ACM
-        good = [s for s in staged if s is not None and s.words > 0]
-        words = [0 if s is None else s.words for s in staged]
-        if not good:
-            return torch.zeros(0, dtype=torch.int16, device="cuda"), [0] * len(files), words, statuses
-        ar = capi.Arena(good)
-        d_idx = torch.from_numpy(ar.idx).pin_memory().cuda(non_blocking=True)
-        d_hdr = torch.from_numpy(ar.hdr.view(np.int32)).pin_memory().cuda(non_blocking=True)
-        d_pcm = torch.empty(ar.pcm_words, dtype=torch.int16, device="cuda")
-        plan = capi.Plan(self.dev, ar.descs, ar.patches)
-        plan.launch(d_idx.data_ptr(), d_hdr.data_ptr(), d_pcm.data_ptr(), self.fmt)
-        torch.cuda.current_stream().synchronize()
-        plan.destroy()
-        offsets, k = [], 0
-        for s in staged:
-            if s is not None and s.words > 0:
-                offsets.append(ar.layout[k][2])
-                k += 1
-            else:
-                offsets.append(0)
+        cap = capi.batch_pcm_words(files)
+        d_pcm = torch.empty(max(cap, 1), dtype=torch.int16, device="cuda")
+        # one call: threaded (or device-side) bit parsing, pipelined H2D, synthesis; the PCM stays in d_pcm
+        statuses, words, offsets, self.timing = capi.batch_decode_device(
+            self.dev, files, d_pcm.data_ptr(), cap, fmt=self.fmt, parse=self.parse)
         return d_pcm, offsets, words, statuses
 
 

@@ -46,12 +46,13 @@ class StageInfo(C.Structure):
 class BatchItem(C.Structure):
     _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("pcm", C.c_void_p), ("pcm_cap", C.c_size_t),
                 ("words", C.c_uint64), ("status", C.c_int32), ("level", C.c_uint32), ("rows", C.c_uint32),
-                ("channels", C.c_uint32), ("rate", C.c_uint32), ("total_values", C.c_uint32)]
+                ("channels", C.c_uint32), ("rate", C.c_uint32), ("total_values", C.c_uint32), ("reserved", C.c_uint32),
+                ("dev_off", C.c_uint64)]
 
 
 class BatchOpts(C.Structure):
     _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint),
-                ("parse", C.c_uint)]
+                ("parse", C.c_uint), ("reserved", C.c_uint), ("d_pcm", C.c_void_p), ("d_pcm_words", C.c_uint64)]
 
 
 class BatchTiming(C.Structure):
@@ -66,7 +67,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
-    "acm_batch_decode",
+    "acm_batch_decode", "acm_batch_pcm_words",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -119,6 +120,8 @@ def lib():
     L.acm_stage_probe.argtypes = [vp, sz, C.c_int, C.POINTER(StageInfo)]
     L.acm_stage_file.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp, sz, C.POINTER(StageInfo)]
     L.acm_batch_decode.argtypes = [vp, C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(BatchTiming)]
+    L.acm_batch_pcm_words.argtypes = [C.POINTER(BatchItem), sz, C.c_int]
+    L.acm_batch_pcm_words.restype = C.c_uint64
     _lib = L
     return L
 
@@ -357,3 +360,32 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
     tm = BatchTiming()
     _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
     return [(items[k].status, outs[k][:items[k].words]) for k in range(n)], tm
+
+
+def _batch_items(files):
+    bufs = [_as_u8(f) for f in files]
+    items = (BatchItem * max(len(files), 1))()
+    for k, b in enumerate(bufs):
+        items[k].data = b.ctypes.data
+        items[k].len = b.size
+    return bufs, items
+
+
+def batch_pcm_words(files, force_chans=0):
+    """16-bit words of device memory batch_decode_device needs for these files."""
+    bufs, items = _batch_items(files)
+    return int(lib().acm_batch_pcm_words(items, len(files), force_chans))
+
+
+def batch_decode_device(dev, files, d_pcm, d_pcm_words, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO,
+                        parse=PARSE_AUTO):
+    """acm_batch_decode with device-resident output: PCM of stream k lands at d_pcm + 2*offsets[k] bytes.
+
+    Returns (statuses, words, offsets, BatchTiming); nothing is copied back to the host."""
+    bufs, items = _batch_items(files)
+    opts = BatchOpts(force_chans, fmt, threads, flags, parse, 0, d_pcm, d_pcm_words)
+    tm = BatchTiming()
+    _check(lib().acm_batch_decode(dev.h, items, len(files), C.byref(opts), C.byref(tm)), "acm_batch_decode")
+    n = len(files)
+    return ([int(items[k].status) for k in range(n)], [int(items[k].words) for k in range(n)],
+            [int(items[k].dev_off) for k in range(n)], tm)

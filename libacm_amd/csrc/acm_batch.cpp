@@ -162,6 +162,19 @@ struct Chunk {
 
 } // namespace
 
+extern "C" uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, int force_chans)
+{
+	uint64_t total = 0;
+	for (size_t i = 0; items && i < n; i++) {
+		acm_stage_info info;
+		if (acm_stage_probe(items[i].data, items[i].len, force_chans, &info) != ACM_OK)
+			continue;
+		const uint64_t bl = (uint64_t)info.rows * info.cols;
+		total += round_up(((uint64_t)info.total_values + bl - 1) / bl * bl, 64);
+	}
+	return total;
+}
+
 extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,
 				const acm_batch_opts *opts_in, acm_batch_timing *timing)
 {
@@ -184,6 +197,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		Slot &s = slots[i];
 		acm_batch_item &it = items[i];
 		it.words = 0;
+		it.dev_off = 0;
 		it.status = acm_stage_probe(it.data, it.len, opts.force_chans, &s.info);
 		it.level = s.info.level;
 		it.rows = s.info.rows;
@@ -207,6 +221,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		hdr_total += s.need_blocks;
 	}
 	const uint64_t pcm_total = idx_total;
+	const bool keep_on_device = opts.d_pcm != nullptr;
+	if (keep_on_device && opts.d_pcm_words < pcm_total)
+		return ACMHIP_ERR_ARG;
+	for (size_t i = 0; i < n; i++)
+		items[i].dev_off = slots[i].pcm_off;
 
 	/* chunks of whole streams: about 1/16 of the batch each, but not below 8 MiB of staged indices */
 	const uint64_t chunk_target = std::max<uint64_t>(4u << 20, idx_total / 16);
@@ -297,10 +316,14 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	BTRY(acmhip_copy_stream(dev, (void **)&st_copy));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
-	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
+	if (!keep_on_device)
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
-	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
+	if (keep_on_device)
+		d_pcm = static_cast<int16_t *>(opts.d_pcm);
+	else
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
 	const size_t jobs_bytes = round_up(dev_ids.size() * sizeof(AcmParseJob), 64);
 	const size_t res_bytes = dev_ids.size() * (sizeof(AcmParseResult) + sizeof(uint32_t));  /* results, then flags */
 	if (!dev_ids.empty()) {
@@ -416,7 +439,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	/* 2b. the pool: parse in arena order, then copy finished PCM out as the chunks come back */
 	std::vector<size_t> out_ids;
 	for (size_t i = 0; i < n; i++)
-		if (slots[i].ok && items[i].pcm)
+		if (slots[i].ok && items[i].pcm && !keep_on_device)
 			out_ids.push_back(i);
 	std::atomic<size_t> parsed{ 0 };
 	clk::time_point t_parsed = clk::now();
@@ -508,8 +531,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			HTRY(hipEventRecord(ch.ev[2], st_main));
 			HTRY(hipStreamWaitEvent(st_copy, ch.ev[2], 0));
 			HTRY(hipEventRecord(ch.ev[3], st_copy));
-			HTRY(hipMemcpyAsync(h_pcm + ch.idx_begin, d_pcm + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
-					    hipMemcpyDeviceToHost, st_copy));
+			if (!keep_on_device)
+				HTRY(hipMemcpyAsync(h_pcm + ch.idx_begin, d_pcm + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
+						    hipMemcpyDeviceToHost, st_copy));
 		}
 		HTRY(hipEventRecord(ch.ev[4], st_copy));
 		{

@@ -253,3 +253,25 @@ def test_batch_edge_cases(dev, parse):
     for k in (0, 31, 64, 95):
         want, _ = oracle_pcm(files[k])
         assert res[k][0] == 0 and np.array_equal(res[k][1], want), k
+
+
+def test_batch_device_resident_output(dev):
+    """opts.d_pcm: the PCM stays in HBM at items[i].dev_off (what the multi-GPU gather consumes); too small a
+    buffer is refused"""
+    files = [make_stream(8300 + i, [6, 7, 9][i % 3], 16, 2 + i % 4, channels=1 + i % 2, cut=3 * i) for i in range(40)]
+    files += [b"junk", files[3][:100]]
+    cap = capi.batch_pcm_words(files)
+    assert cap % 64 == 0 and cap > 0
+    d_pcm = dev.malloc(cap * 2)
+    host, _ = capi.batch_decode(dev, files, threads=4)
+    for parse in (capi.PARSE_HOST, capi.PARSE_DEVICE):
+        st, words, offs, tm = capi.batch_decode_device(dev, files, d_pcm, cap, threads=4, parse=parse)
+        out = np.zeros(cap, dtype=np.uint16)
+        dev.download(out, d_pcm)
+        dev.sync()
+        for k, (hs, hp) in enumerate(host):
+            assert st[k] == hs and words[k] == hp.size
+            assert np.array_equal(out[offs[k]:offs[k] + words[k]], hp), k
+    with pytest.raises(capi.AcmHipError):
+        capi.batch_decode_device(dev, files, d_pcm, cap - 64)
+    dev.free(d_pcm)
