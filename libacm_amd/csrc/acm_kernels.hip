@@ -792,14 +792,14 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
 		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
-	{	/* variant 1 */
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		entry<TileCfg<7, 256, 16384>, 2, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		entry<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
+	{	/* variant 1: 48 KB tiles, three workgroups per CU (3 waves per SIMD, 48 elements per thread) */
+		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
+		entry2<TileCfg<6, 256, 12288>, 3, 2, 2, 2>(),
+		entry2<TileCfg<7, 256, 12288>, 3, 2, 2, 3>(),
+		entry2<TileCfg<8, 256, 12288>, 3, 2, 3, 3>(),
+		entry2<TileCfg<9, 256, 12288>, 3, 2, 2, 2, 3>(),
+		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
+		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
 	{	/* variant 2: 128 KB tiles (one workgroup of 8 waves per CU): half the halo share of the 64 KB tiles */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
