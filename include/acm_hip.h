@@ -215,7 +215,7 @@ typedef struct acm_batch_opts {
 /* where the bit parsing of a batch runs */
 #define ACM_BATCH_PARSE_HOST   0u   /* host thread pool (default; the exact reader, any stream) */
 #define ACM_BATCH_PARSE_DEVICE 1u   /* one GPU lane per stream for clean streams; streams the device parser is not
-                                       sure about (data running out, corrupt symbols, hazard H1, files >= 512 MiB) are
+                                       sure about (data running out, corrupt symbols, hazard H1, files >= 256 MiB) are
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
 #define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch holds at least 2048 streams, HOST below that: walking a
                                        stream is sequential, and one GPU lane walks ~15x slower than one host core */

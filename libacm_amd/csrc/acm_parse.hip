@@ -33,7 +33,7 @@ constexpr int COL_THREADS = 256;
 /* ---- bit window over a file image (arena slots are 16-byte aligned with >= 16 zero bytes behind the file) ---- */
 struct DevBits {
 	const uint32_t *w;
-	uint32_t bit;            /* next unread bit (files are < 512 MiB) */
+	uint32_t bit;            /* next unread bit (files are < 256 MiB) */
 	uint32_t have;
 	uint64_t win;
 
@@ -357,8 +357,9 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 
 extern "C" int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file_len, uint64_t blocks)
 {
-	/* 32-bit bit offsets and column counts */
-	return rows >= 1 && blocks >= 1 && file_len < 0x1FFFFFF0ull && (blocks << level) < 0xFFFFFFFFull;
+	/* 32-bit bit offsets with headroom (a corrupt stream may step one column past the end of its file before
+	 * the walk notices, and must not wrap), 32-bit column counts */
+	return rows >= 1 && blocks >= 1 && file_len < 0x10000000ull && (blocks << level) < 0xFFFFFFFFull;
 }
 
 /*
