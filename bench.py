@@ -264,7 +264,7 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_extra and not args.stagewise:
             extra = []
-            for (lv, rw, bl, ns) in ((9, 16, 250, 512), (11, 64, 2, 2048)):
+            for (lv, rw, bl, ns) in ((9, 16, 250, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch
                 try:
                     extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(3, args.steps // 2)))
                 except Exception as e:   # a side measurement must never sink the headline line
