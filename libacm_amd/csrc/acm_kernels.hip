@@ -792,12 +792,12 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
 		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
-	{	/* variant 1: 48 KB tiles, three workgroups per CU (3 waves per SIMD, 48 elements per thread) */
+	{	/* variant 1: 64 KB tiles shared by 8 waves (4 waves per SIMD, 32 elements per thread) */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 256, 12288>, 3, 2, 2, 2>(),
-		entry2<TileCfg<7, 256, 12288>, 3, 2, 2, 3>(),
-		entry2<TileCfg<8, 256, 12288>, 3, 2, 3, 3>(),
-		entry2<TileCfg<9, 256, 12288>, 3, 2, 2, 2, 3>(),
+		entry2<TileCfg<6, 512, 16384>, 4, 2, 2, 2>(),
+		entry2<TileCfg<7, 512, 16384>, 4, 2, 2, 3>(),
+		entry2<TileCfg<8, 512, 16384>, 4, 2, 3, 3>(),
+		entry2<TileCfg<9, 512, 16384>, 4, 2, 2, 2, 3>(),
 		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
 		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
