@@ -103,7 +103,34 @@ def cpu_baseline(batch, budget_s):
             fw += o.getter("block_len")
         o.close()
     dt_fill = time.perf_counter() - t1
+    # the same decoder on all usable host cores, one stream per thread; big reads keep the GIL out of it
+    all_cores = None
+    if kind == "reference":
+        from concurrent.futures import ThreadPoolExecutor
+        ncpu = workload_cpus()
+        stop_at = time.perf_counter() + min(6.0, budget_s / 2)
+
+        def one(f):
+            if time.perf_counter() > stop_at:
+                return 0
+            s = O.LibacmStream(lib, f.tobytes())
+            big = (C.c_uint8 * (1 << 20))()
+            w = 0
+            while True:
+                rc = lib.acm_read_loop(s.h, big, 1 << 20, 0, 2, 1)
+                if rc <= 0:
+                    break
+                w += rc // 2
+            s.close()
+            return w
+        t2 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=ncpu) as ex:
+            aw = sum(ex.map(one, files))
+        dt_all = time.perf_counter() - t2
+        all_cores = {"value": round(aw / dt_all / 1e6, 1), "unit": "Msamples/s", "cores": ncpu,
+                     "sample": "%.1f Msamples in %.1f s, one stream per thread" % (aw / 1e6, dt_all)}
     return {
+        "all_cores": all_cores,
         "value": round(words / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
         "sample": "%d of the workload's streams (%.1f Msamples), whole decode path incl. bit parsing, 1 thread, %.1f s"
                   % (n, words / 1e6, dt),
@@ -262,6 +289,25 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        if not args.no_extra:
+            # the box's own device-to-device copy rate (read + write bytes), the practical HBM ceiling
+            try:
+                x = torch.empty(1 << 29, dtype=torch.int32, device="cuda")
+                y = torch.empty_like(x)
+                y.copy_(x)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5):
+                    y.copy_(x)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                out["roofline"]["d2d_copy_gbs"] = round(copy_gbs, 1)
+                out["roofline"]["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
+                del x, y
+            except Exception as e:
+                out["roofline"]["d2d_copy_gbs"] = None
         if not args.no_extra and not args.stagewise:
             extra = []
             for (lv, rw, bl, ns) in ((9, 16, 250, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch

@@ -1,0 +1,46 @@
+// Practical HBM ceiling of this box: device-to-device copy with 16 B/lane accesses (read + write bytes / time),
+// grid-stride persistent kernel vs one-shot grid, plus hipMemcpyDtoD for comparison.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__global__ void __launch_bounds__(256) copy_persist(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) copy_unroll4(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  size_t i = (blockIdx.x * 256ull + threadIdx.x);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) read_only(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  uint4 acc = {0, 0, 0, 0};
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { uint4 v = src[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) dst[0] = acc;
+}
+__global__ void __launch_bounds__(256) write_only(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  const uint4 v = {1, 2, 3, 4};
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
+}
+int main() {
+  const size_t bytes = 4ull << 30, n = bytes / 16;
+  uint4 *a, *b; (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  auto timeit = [&](const char *name, auto launch, double bytes_moved) {
+    launch(); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); for (int r = 0; r < 5; r++) launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-34s %8.1f GB/s\n", name, 5 * bytes_moved / (ms * 1e-3) / 1e9);
+  };
+  timeit("hipMemcpyDtoD (r+w)", [&]() { (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }, 2.0 * bytes);
+  for (int g : { 512, 1024, 2048, 4096, 16384 }) {
+    char nm[64]; snprintf(nm, sizeof nm, "copy grid-stride, %d WGs (r+w)", g);
+    timeit(nm, [&]() { hipLaunchKernelGGL(copy_persist, dim3(g), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+    snprintf(nm, sizeof nm, "copy unroll4, %d WGs (r+w)", g);
+    timeit(nm, [&]() { hipLaunchKernelGGL(copy_unroll4, dim3(g), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  }
+  timeit("read only, 2048 WGs", [&]() { hipLaunchKernelGGL(read_only, dim3(2048), dim3(256), 0, 0, a, b, n); }, 1.0 * bytes);
+  timeit("write only, 2048 WGs", [&]() { hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, a, b, n); }, 1.0 * bytes);
+  return 0;
+}
