@@ -217,8 +217,9 @@ typedef struct acm_batch_opts {
 #define ACM_BATCH_PARSE_DEVICE 1u   /* one GPU lane per stream for clean streams; streams the device parser is not
                                        sure about (data running out, corrupt symbols, hazard H1, files >= 256 MiB) are
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
-#define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch holds at least 2048 streams, HOST below that: walking a
-                                       stream is sequential, and one GPU lane walks ~15x slower than one host core */
+#define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch is worth at least 16 x threads streams of its longest
+                                       stream's size, HOST below that: walking a stream is sequential, and one GPU
+                                       lane walks ~16x slower than one host core parses */
 
 typedef struct acm_batch_timing {
 	double stage_s;          /* wall clock until the last stream was bit-parsed (headers included, allocation not) */

@@ -11,6 +11,7 @@
  * parsing, H2D, synthesis, D2H and the final copies all overlap.
  */
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,8 +57,18 @@ uint64_t deliverable_words(uint64_t total_values, uint64_t block_len, unsigned c
  * surplus), measured with profiles/e2e_probe.py. */
 int default_threads()
 {
-	const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-	return std::min(hw, 64);
+	int n = (int)std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0)
+		n = std::min(n, std::max(1, CPU_COUNT(&set)));
+	/* a cgroup-v2 CPU quota is invisible to the two calls above; threads beyond it only time-slice */
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		long long quota = 0, period = 0;
+		if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+			n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+		fclose(f);
+	}
+	return std::min(n, 64);
 }
 
 /* A fixed set of worker threads that lives for one acm_batch_decode call.  run() is a blocking parallel-for
@@ -187,8 +198,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		return ACMHIP_ERR_ARG;
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
-	int threads = opts.threads > 0 ? opts.threads : default_threads();
-	threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n));
+	const int threads_wanted = opts.threads > 0 ? opts.threads : default_threads();
+	const int threads = (int)std::min<size_t>((size_t)threads_wanted, std::max<size_t>(1, n));
 	Pool pool(threads);
 
 	/* 1. headers -> arena layout */
@@ -259,7 +270,17 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 	}
 
-	const bool dev_parse = opts.parse == ACM_BATCH_PARSE_DEVICE || (opts.parse == ACM_BATCH_PARSE_AUTO && n >= 2048);
+	/* AUTO: the device walk takes as long as the longest stream takes one GPU lane (~1/16 of a host core's
+	 * parsing rate), the host pool takes total / threads: device when the batch is worth more than
+	 * 16 x threads streams of the longest stream's size */
+	bool dev_parse = opts.parse == ACM_BATCH_PARSE_DEVICE;
+	if (opts.parse == ACM_BATCH_PARSE_AUTO) {
+		uint64_t longest = 0;
+		for (const Slot &s : slots)
+			if (s.ok)
+				longest = std::max(longest, s.idx_len);
+		dev_parse = longest > 0 && idx_total / longest >= 16ull * (uint64_t)threads_wanted;
+	}
 	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
