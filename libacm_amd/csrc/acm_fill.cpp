@@ -37,6 +37,7 @@ int pull_chunk(ACMStream *s)
 /* LSB-first bit cursor; the accumulator lives in registers while a block is
  * being parsed and is written back to the public struct on exit. */
 struct BitCursor {
+	static constexpr bool kTableDriven = false;     /* exact reader: every field through get() */
 	ACMStream *s;
 	uint32_t acc;
 	unsigned avail;
@@ -117,6 +118,7 @@ struct BitCursor {
  * the exact BitCursor above takes over.
  */
 struct FastCursor {
+	static constexpr bool kTableDriven = true;      /* the window can be peeked: k/t symbols come from a table */
 	const unsigned char *buf;
 	uint64_t bit;           /* offset of the next unread bit in buf */
 	uint64_t win;           /* the next `have` bits, LSB first */
@@ -179,13 +181,56 @@ inline unsigned code_reach(unsigned code)
 	return reach[code];
 }
 
-#define TAKE(var, n) do { const int t_ = bc.get(n); if (t_ < 0) return t_; (var) = (unsigned)t_; } while (0)
-
 /* symbol tables of the k-fillers (:168-171) */
 const int8_t kSign1[2] = { -1, 1 };
 const int8_t kNear2[4] = { -2, -1, 1, 2 };
 const int8_t kFar2[4] = { -3, -2, 2, 3 };
 const int8_t kWide3[8] = { -4, -3, -2, -1, 1, 2, 3, 4 };
+
+#define TAKE(var, n) do { const int t_ = bc.get(n); if (t_ < 0) return t_; (var) = (unsigned)t_; } while (0)
+
+/*
+ * Table-driven k/t fillers for the fast cursor.  One entry per (filler, next 7 bits) = the symbol at the head of
+ * those bits (:217-476): bits 0-2 length, 3-4 rows produced (1..3), 5-8 / 9-12 / 13-16 the indices + 8, bit 17 =
+ * the reference rejects this symbol (ternary value out of range).  Decoding a symbol is then one look-up and three
+ * unconditional stores - no data-dependent branch, where the bit grammar costs one mispredict per symbol.
+ */
+struct SymbolTable {
+	uint32_t e[11][128];
+	static int slot(unsigned code) { return code <= 24 ? (int)code - 17 : code <= 27 ? (int)code - 18 : 10; }
+	SymbolTable()
+	{
+		static const unsigned codes[11] = { 17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29 };
+		for (int k = 0; k < 11; k++)
+			for (unsigned bits = 0; bits < 128; bits++)
+				e[k][bits] = entry(codes[k], bits);
+	}
+	static uint32_t entry(unsigned code, unsigned bits)
+	{
+		const bool b0 = bits & 1, b1 = bits & 2, b2 = bits & 4;
+		unsigned len = 1, cnt = 1, bad = 0;
+		int v0 = 0, v1 = 0, v2 = 0;
+		switch (code) {
+		case 17: if (!b0) cnt = 2; else if (!b1) len = 2; else { len = 3; v0 = kSign1[b2]; } break;
+		case 18: if (b0) { len = 2; v0 = kSign1[b1]; } break;
+		case 19: { const unsigned b = bits & 31; len = 5; cnt = 3; bad = b >= 27;
+			   v0 = (int)(b % 3) - 1; v1 = (int)(b / 3 % 3) - 1; v2 = (int)(b / 9 % 3) - 1; break; }
+		case 20: if (!b0) cnt = 2; else if (!b1) len = 2; else { len = 4; v0 = kNear2[(bits >> 2) & 3]; } break;
+		case 21: if (b0) { len = 3; v0 = kNear2[(bits >> 1) & 3]; } break;
+		case 22: { const unsigned b = bits & 127; len = 7; cnt = 3; bad = b >= 125;
+			   v0 = (int)(b % 5) - 2; v1 = (int)(b / 5 % 5) - 2; v2 = (int)(b / 25 % 5) - 2; break; }
+		case 23: if (!b0) cnt = 2; else if (!b1) len = 2;
+			 else if (!b2) { len = 4; v0 = kSign1[(bits >> 3) & 1]; } else { len = 5; v0 = kFar2[(bits >> 3) & 3]; } break;
+		case 24: if (b0) { if (!b1) { len = 3; v0 = kSign1[b2]; } else { len = 4; v0 = kFar2[(bits >> 2) & 3]; } } break;
+		case 26: if (!b0) cnt = 2; else if (!b1) len = 2; else { len = 5; v0 = kWide3[(bits >> 2) & 7]; } break;
+		case 27: if (b0) { len = 4; v0 = kWide3[(bits >> 1) & 7]; } break;
+		default: { const unsigned b = bits & 127; len = 7; cnt = 2; bad = b >= 121;
+			   v0 = (int)(b % 11) - 5; v1 = (int)(b / 11 % 11) - 5; break; }
+		}
+		return len | cnt << 3 | (uint32_t)(v0 + 8) << 5 | (uint32_t)(v1 + 8) << 9 | (uint32_t)(v2 + 8) << 13 | bad << 17;
+	}
+};
+
 
 /*
  * One column.  `col` points at idx[0*cols + c]; consecutive rows are `pitch`
@@ -206,6 +251,32 @@ __attribute__((always_inline)) inline int parse_column(Cursor &bc, unsigned code
 		for (; r < rows; r++, col += pitch) {
 			TAKE(b, code);
 			*col = (int16_t)((int)b - mid);
+		}
+		return 1;
+	}
+
+	if constexpr (Cursor::kTableDriven) {
+		if (code < 17 || code > 29 || code == 25 || code == 28)
+			return ACM_ERR_CORRUPT;                         /* 1, 2, 25, 28, 30, 31 */
+		static const SymbolTable table;
+		const uint32_t *const tab = table.e[SymbolTable::slot(code)];
+		int16_t sink;                                           /* rows past the column's end land here */
+		while (r < rows) {
+			if (bc.have < 7)
+				bc.refill();
+			const uint32_t e = tab[(uint32_t)bc.win & 127u];
+			if (e & (1u << 17))
+				return ACM_ERR_CORRUPT;
+			const unsigned len = e & 7u, cnt = (e >> 3) & 3u;
+			bc.win >>= len;
+			bc.have -= len;
+			bc.bit += len;
+			/* all three stores always: a surplus one writes the 0 a later symbol overwrites, or the sink */
+			col[0] = (int16_t)((int)((e >> 5) & 15u) - 8);
+			*(r + 1 < rows ? col + pitch : &sink) = (int16_t)((int)((e >> 9) & 15u) - 8);
+			*(r + 2 < rows ? col + 2 * pitch : &sink) = (int16_t)((int)((e >> 13) & 15u) - 8);
+			col += cnt * pitch;
+			r += cnt;
 		}
 		return 1;
 	}
