@@ -27,8 +27,14 @@ struct AcmDevStream {
 /* one workgroup of the fused kernel: `T` payload rows starting at row0 */
 struct AcmTile {
 	uint32_t stream;
-	uint32_t row0;
+	int32_t row0;          /* first payload row (a carry-mode lead-in tile may start before row 0) */
+	uint32_t flags;        /* ACM_TILE_*: carry-mode kernels only */
+	uint32_t pad;
 };
+/* carry mode: consecutive tiles of a stream hand the tail of every pass's input to the next tile through LDS instead
+ * of recomputing two halo rows; a workgroup walks a contiguous run of the tile table */
+#define ACM_TILE_FRESH   1u    /* nothing in front of this tile: the carries start from zero (stream row 0, or a lead-in) */
+#define ACM_TILE_DISCARD 2u    /* lead-in: run the passes to build the carries, store no PCM */
 
 /* resolved H1 patch for the stage-wise path: scratch[dst] = value */
 struct AcmDevPatch {
@@ -79,8 +85,10 @@ int acmhip_report_hip(int hip_error, const char *what);          /* records the 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
 int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */
-int acmk_launch_fused(uint32_t level, int variant, int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
-		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
+int acmk_fused_has_carry(uint32_t level, int variant);           /* does a carry-mode build of this geometry exist? */
+int acmk_fused_grid(uint32_t level, int variant, int cus);       /* persistent workgroups the launch uses at most */
+int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const AcmDevStream *d_streams, const AcmTile *d_tiles,
+		      uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);

@@ -56,6 +56,7 @@ struct LevelGroup {
 	uint32_t level = 0;
 	AcmTile *d_tiles = nullptr;
 	uint32_t ntiles = 0;
+	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
 	uint32_t *d_list = nullptr;
 	uint32_t nlist = 0;
 	uint64_t max_elems = 0;     /* stage-wise: longest plane run in the group */
@@ -295,6 +296,15 @@ bool fused_ok(const acmhip_stream_desc &s)
 	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL;
 }
 
+/* ACM_K1_CARRY=0/1 forces the halo / carry flavour of the tile kernel (tests, measurements); default: carry when
+ * a workgroup's run of the tile table is at least 32 tiles long */
+bool carry_wanted(size_t ntiles, size_t grid)
+{
+	if (const char *e = getenv("ACM_K1_CARRY"))
+		return atoi(e) != 0;
+	return grid > 0 && ntiles >= 32 * grid;
+}
+
 /* tuning knob: ACM_K1_VARIANT=n picks another built-in tile geometry (default: the measured-best one) */
 int pick_variant()
 {
@@ -346,7 +356,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		has_patch[patches[p].stream] = 1;
 	}
 
-	std::vector<std::vector<AcmTile>> tiles(16);
+	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16);
 	std::vector<std::vector<uint32_t>> lists(16);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
@@ -386,7 +396,18 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const uint64_t cols = 1ull << s.level;
 			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
 			for (uint64_t r = 0; r < emit_rows; r += T)
-				tiles[s.level].push_back(AcmTile{ (uint32_t)i, (uint32_t)(s.row_begin + r) });
+				tiles[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), 0u, 0u });
+			if (acmk_fused_has_carry(s.level, variant)) {
+				/* carry mode: T + 2 payload rows per tile; a stream that does not start at its row 0 gets a
+				 * lead-in tile in front (rows that do not exist count as zeros, which is exact: no output
+				 * depends on anything further back than two rows) */
+				const uint32_t TC = T + 2;
+				std::vector<AcmTile> &tc = tiles_carry[s.level];
+				if (s.row_begin > 0)
+					tc.push_back(AcmTile{ (uint32_t)i, (int32_t)s.row_begin - (int32_t)TC, ACM_TILE_FRESH | ACM_TILE_DISCARD, 0u });
+				for (uint64_t r = 0; r < emit_rows; r += TC)
+					tc.push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), (r == 0 && s.row_begin == 0) ? ACM_TILE_FRESH : 0u, 0u });
+			}
 			st.fused_streams++;
 		} else {
 			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
@@ -422,8 +443,12 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		if (!tiles[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
-			g.ntiles = (uint32_t)tiles[lv].size();
-			rc = to_device(dev, tiles[lv], &g.d_tiles);
+			/* carry mode pays one lead-in tile per workgroup: only when every workgroup has a long run */
+			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
+			g.carry = !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid);
+			const std::vector<AcmTile> &use = g.carry ? tiles_carry[lv] : tiles[lv];
+			g.ntiles = (uint32_t)use.size();
+			rc = to_device(dev, use, &g.d_tiles);
 			pl->fused.push_back(g);
 			st.tiles += g.ntiles;
 			st.launches += 1;
@@ -485,7 +510,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	void *st = (void *)pl->dev->stream;
 
 	for (const LevelGroup &g : pl->fused)
-		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
 
 	if (pl->n_sw_all) {
 		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,

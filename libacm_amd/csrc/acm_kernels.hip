@@ -346,6 +346,7 @@ struct TileCtx {
 	int nrows;
 	int row_begin;
 	uint32_t rows;           /* acm_rows */
+	bool fresh, discard;     /* carry mode: ACM_TILE_* of this tile */
 };
 
 /*
@@ -417,9 +418,11 @@ struct FirstPass {
 	}
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
+	template <bool CARRY = false>
 	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NRAW], uint32_t *tile, const int32_t *rowval,
 						       const int row_first, const int tid)
 	{
+		constexpr int LR_MIN = CARRY ? -2 : 0;          /* carry mode: the two rows above the tile carry weight */
 		const int seg = tid / TPS;
 		const int i0 = (tid % TPS) * W;
 		const int lr_seg = seg * RPS;
@@ -435,8 +438,8 @@ struct FirstPass {
 			const int lr0 = lr_seg + 2 * b;
 			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
-			const uint32_t b0 = (i0 == 0 && lr0 >= 0 && row_first + lr0 >= 0) ? ONE : 0u;
-			const uint32_t b1 = (i0 == 0 && lr0 + 1 >= 0 && row_first + lr0 + 1 >= 0) ? ONE : 0u;
+			const uint32_t b0 = (i0 == 0 && lr0 >= LR_MIN && row_first + lr0 >= 0) ? ONE : 0u;
+			const uint32_t b1 = (i0 == 0 && lr0 + 1 >= LR_MIN && row_first + lr0 + 1 >= 0) ? ONE : 0u;
 			uint32_t v[W][BODY];
 #pragma unroll
 			for (int w = 0; w < W; w++) {
@@ -466,8 +469,11 @@ struct FirstPass {
  * packed two per dword and parked at the start of the thread's own (already
  * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
  */
-template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true, bool BIGEND = true>
-__device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt)
+/* padded size of a carry buffer holding the BS elements in front of a tile (same pad rule as P::off) */
+constexpr int carry_words(int bs) { return bs + bs / 64 + 2; }
+
+template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true, bool BIGEND = true, bool CARRY = false>
+__device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt, uint32_t *carry = nullptr)
 {
 	using P = PassGeo<C, K0, G>;
 	constexpr int L = C::L;
@@ -499,14 +505,30 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	if (!(ABL & 32))
 		__syncthreads();
 	uint32_t w[BODY];
+	uint32_t tail = 0;
 	{
 		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= 64 ? BS / 64 : 1)) : tile + lds_at(m_seg - BS);
+		if constexpr (CARRY) {
+			/* segment 0's history is what the previous tile of this stream left behind: the last BS elements
+			 * of its input to this pass, kept in `carry` with the same pad rule (element j at j + off-pad) */
+			static_assert(BS <= C::NT, "one thread per carried element");
+			if (seg == 0)
+				pw = carry + i;
+			if (tid < BS)
+				tail = tile[lds_at(C::NELEM - BS + tid)];       /* this tile's bequest, read before it is overwritten */
+		}
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
 			w[u] = pw[P::off(u)];
 	}
 	if (!(ABL & 32))
 		__syncthreads();
+	if constexpr (CARRY) {
+		if (tid < BS) {
+			const int u_sigma = (tid / SIGMA) * SIGMA;
+			carry[tid + (u_sigma >> 6)] = tail;                     /* next read: this pass of the next tile */
+		}
+	}
 
 	/* software pipeline: the reads of body k+1 are in flight while body k is computed */
 	constexpr int NBODY = P::NJ / BODY;
@@ -564,18 +586,20 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #endif
 
 /* the passes after the first: stage groups G, Rest... starting at stage K0; the last one emits PCM */
-template <class C, int ABL, int K0, int G, int... Rest>
-__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt)
+template <class C, int ABL, bool CARRY, int CW, int K0, int G, int... Rest>
+__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt, uint32_t (*carry)[CW] = nullptr)
 {
 	constexpr bool last = sizeof...(Rest) == 0;
 	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
+	static_assert(!CARRY || carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA) <= CW, "carry buffer too small");
+	uint32_t *cb = CARRY ? carry[0] : nullptr;
 	if constexpr (!last) {
-		lds_pass<C, K0, G, false, ABL>(tile, tid, fmt);
-		run_lds_passes<C, ABL, K0 + G, Rest...>(tile, tid, fmt);
+		lds_pass<C, K0, G, false, ABL, true, true, CARRY>(tile, tid, fmt, cb);
+		run_lds_passes<C, ABL, CARRY, CW, K0 + G, Rest...>(tile, tid, fmt, CARRY ? carry + 1 : nullptr);
 	} else if (fmt == ACMHIP_FMT_S16LE) {
-		lds_pass<C, K0, G, true, ABL, false, false>(tile, tid, fmt);   /* the common layout: no xor, no byte swap */
+		lds_pass<C, K0, G, true, ABL, false, false, CARRY>(tile, tid, fmt, cb);   /* the common layout: no xor, no byte swap */
 	} else {
-		lds_pass<C, K0, G, true, ABL, true, true>(tile, tid, fmt);     /* any other layout through the general path */
+		lds_pass<C, K0, G, true, ABL, true, true, CARRY>(tile, tid, fmt, cb);     /* any other layout through the general path */
 	}
 }
 
@@ -586,7 +610,7 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
  * C: tile configuration; G0, Gs...: how the `level` stages are grouped into passes (first pass fed from
  * HBM, the others in LDS).
  */
-template <class C, int WAVES_PER_SIMD, int ABL, int W0, int G0, int... Gs>
+template <class C, int WAVES_PER_SIMD, int ABL, int W0, bool CARRY, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WAVES_PER_SIMD)
 acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restrict__ tiles, const uint32_t ntiles,
 	       const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
@@ -601,6 +625,13 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	__shared__ uint32_t tile_mem[GUARD + NELEM + NELEM / 64];
 	__shared__ int32_t rowval[2][TR + 2];                   // [buf][lr + 2]; two leading zeros for segment 0's warm-up
 	uint32_t *const tile = tile_mem + GUARD;
+	/* carry mode: per LDS pass, the tail of the previous tile's input to that pass (the first LDS pass has the
+	 * widest: two bodies of its smallest stride) */
+	constexpr int NCARRY = CARRY ? (int)sizeof...(Gs) : 1;
+	constexpr int CW = CARRY ? carry_words(2 * (COLS >> G0)) : 1;
+	__shared__ uint32_t carry_mem[NCARRY][CW];
+	/* payload rows of a tile: all of them in carry mode, all but the two halo rows otherwise */
+	constexpr int HALO = CARRY ? 0 : 2;
 
 	const int tid = threadIdx.x;
 
@@ -612,10 +643,12 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		c.hdr = hdr + s.hdr_off;
 		c.dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
 		c.n_emit = s.n_emit;
-		c.row_first = (int)tl.row0 - 2;
+		c.row_first = (int)tl.row0 - HALO;
 		c.nrows = (int)s.nrows;
 		c.row_begin = (int)s.row_begin;
 		c.rows = s.rows;
+		c.fresh = tl.flags & ACM_TILE_FRESH;
+		c.discard = tl.flags & ACM_TILE_DISCARD;
 		return c;
 	};
 	/* the block's val (decode.c:589) of every tile row, pre-scaled and signed per the stage-0 convention */
@@ -625,7 +658,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 			const int lr = tid + k * NT - 2;
 			const int rho = c.row_first + lr;
 			hv[k] = 0;
-			if (lr >= 0 && lr < TR && rho >= 0 && rho < c.nrows)
+			if (lr >= -2 + HALO && lr < TR && rho >= 0 && rho < c.nrows)
 				hv[k] = (int32_t)c.hdr[(uint32_t)rho / c.rows].val;
 		}
 	};
@@ -642,12 +675,29 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		}
 	};
 
-	uint32_t t = blockIdx.x;
-	if (t >= ntiles)
+	/* which tiles: every gridDim.x-th one, or in carry mode a contiguous run of the table (a run that starts in
+	 * the middle of a stream first replays the tile in front of it as a lead-in: one tile is enough for the carries
+	 * to be exact, every pass reaches back less than a tile) */
+	uint32_t t = blockIdx.x, t_end = ntiles;
+	bool lead_in = false;
+	if constexpr (CARRY) {
+		const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+		t = blockIdx.x * per;
+		t_end = t + per < ntiles ? t + per : ntiles;
+		if (t < ntiles && !(tiles[t].flags & ACM_TILE_FRESH)) {
+			lead_in = true;
+			t--;
+		}
+	}
+	if (t >= t_end)
 		return;
 	for (int k = tid; k < GUARD; k += NT)
 		tile_mem[k] = 0u;                               /* never written again */
 	TileCtx cur = fetch_ctx(t);
+	if (lead_in) {
+		cur.fresh = true;
+		cur.discard = true;
+	}
 	uint32_t raw[FP::NRAW];
 	int32_t hv[NRV];
 	fetch_vals(hv, cur);
@@ -660,14 +710,19 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 #endif
 
 	for (;;) {
+		if constexpr (CARRY) {
+			if (cur.fresh)                          /* nothing in front of this tile: history is zeros (util.c:241) */
+				for (int k = tid; k < NCARRY * CW; k += NT)
+					(&carry_mem[0][0])[k] = 0u;
+		}
 		__syncthreads();                                /* rowval[buf] complete; previous write-out done with the tile */
 		ACM_STAMP(0);
-		FP::compute(raw, tile, rowval[buf], cur.row_first, tid);
+		FP::template compute<CARRY>(raw, tile, rowval[buf], cur.row_first, tid);
 		ACM_STAMP(1);
 
 		/* prefetch the next tile: context (scalar), headers and staged indices (registers) */
-		const uint32_t tn = t + gridDim.x;
-		const bool more = tn < ntiles;
+		const uint32_t tn = CARRY ? t + 1 : t + gridDim.x;
+		const bool more = tn < t_end;
 		TileCtx nxt = cur;
 		if (more) {
 			nxt = fetch_ctx(tn);
@@ -677,18 +732,18 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 
 		ACM_STAMP(2);
 		if (!(ABL & 8))
-			run_lds_passes<C, ABL, G0, Gs...>(tile, tid, fmt);
+			run_lds_passes<C, ABL, CARRY, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
 		ACM_STAMP(3);
 		__syncthreads();
 		ACM_STAMP(4);
 
 		/* write-out of the payload rows (tile rows 2..TR-1): 8 samples (16 B) per lane per step,
 		 * gathered from the per-thread parking areas of the last pass */
-		{
-			constexpr int NVEC = (TR - 2) * COLS / 8;       /* 16-byte pieces of the payload */
+		if (!(CARRY && cur.discard)) {
+			constexpr int NVEC = (TR - HALO) * COLS / 8;    /* 16-byte pieces of the payload */
 			constexpr int PER_OWNER = NJ_LAST / 8;          /* pieces per parking area */
-			const uint64_t g0 = (uint64_t)(uint32_t)(cur.row_first + 2 - cur.row_begin) << L;   /* first payload sample */
-			const bool whole = (cur.row_first + TR <= cur.nrows) && (g0 + (uint64_t)(TR - 2) * COLS <= cur.n_emit);
+			const uint64_t g0 = (uint64_t)(uint32_t)(cur.row_first + HALO - cur.row_begin) << L;   /* first payload sample */
+			const bool whole = (cur.row_first + TR <= cur.nrows) && (g0 + (uint64_t)(TR - HALO) * COLS <= cur.n_emit);
 			if (whole) {
 				/* interior tile (the common case): no per-piece checks, 32-bit offsets from a uniform base */
 				uint4 *out = reinterpret_cast<uint4 *>(cur.dst + g0);
@@ -696,8 +751,8 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 				for (int k = 0; k < (NVEC + NT - 1) / NT; k++) {
 					const int vec = tid + k * NT;
 					if (k < NVEC / NT || vec < NVEC) {      /* only the last round can be partial */
-						const int owner = (2 * COLS / 8 + vec) / PER_OWNER;
-						const int piece = (2 * COLS / 8 + vec) % PER_OWNER;
+						const int owner = (HALO * COLS / 8 + vec) / PER_OWNER;
+						const int piece = (HALO * COLS / 8 + vec) % PER_OWNER;
 						const uint32_t *q = tile + lds_at(owner * NJ_LAST) + piece * 4;
 						uint4 o;
 						o.x = q[0];
@@ -710,7 +765,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 				}
 			} else {
 				for (int vec = tid; vec < NVEC; vec += NT) {
-					const int ml = 2 * COLS + vec * 8;
+					const int ml = HALO * COLS + vec * 8;
 					const int lr = ml >> L;
 					const int col = ml & (COLS - 1);
 					const int rho = cur.row_first + lr;
@@ -762,19 +817,24 @@ struct FusedEntry {
 	int threads;
 	int tile_rows;
 	int wg_per_cu;       /* resident workgroups per CU (LDS-limited) */
+	void (*fn_carry)(const AcmDevStream *, const AcmTile *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
 };
 
 template <class C, int W, int... Gs>
-constexpr FusedEntry entry() { return FusedEntry{ acm_fused_tile<C, W, 0, 1, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry entry() { return FusedEntry{ acm_fused_tile<C, W, 0, 1, false, Gs...>, C::NT, C::TR, W * 256 / C::NT, nullptr }; }
 /* same with two adjacent columns per lane in the first pass (4-byte HBM loads) */
 template <class C, int W, int... Gs>
-constexpr FusedEntry entry2() { return FusedEntry{ acm_fused_tile<C, W, 0, 2, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry entry2() { return FusedEntry{ acm_fused_tile<C, W, 0, 2, false, Gs...>, C::NT, C::TR, W * 256 / C::NT, nullptr }; }
+/* ... plus the carry-mode build of the same geometry (no halo rows; see ACM_TILE_*) */
+template <class C, int W, int... Gs>
+constexpr FusedEntry entry2c() { return FusedEntry{ acm_fused_tile<C, W, 0, 2, false, Gs...>, C::NT, C::TR, W * 256 / C::NT,
+						     acm_fused_tile<C, W, 0, 2, true, Gs...> }; }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-7 and level-9 kernels with parts removed (wrong output by design) */
 template <class C, int W, int ABL, int... Gs>
-constexpr FusedEntry abl2() { return FusedEntry{ acm_fused_tile<C, W, ABL, 2, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry abl2() { return FusedEntry{ acm_fused_tile<C, W, ABL, 2, false, Gs...>, C::NT, C::TR, W * 256 / C::NT, nullptr }; }
 template <class C, int W, int ABL, int... Gs>
-constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, Gs...>, C::NT, C::TR, W * 256 / C::NT }; }
+constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, false, Gs...>, C::NT, C::TR, W * 256 / C::NT, nullptr }; }
 #endif
 
 #ifdef ACM_ABLATION
@@ -784,13 +844,13 @@ constexpr int NVARIANTS = 9;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
-		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
-		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
-		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		entry2<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
-		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
+		entry2c<TileCfg<5, 128, 8192>, 2, 2, 3>(),
+		entry2c<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
+		entry2c<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
+		entry2c<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
+		entry2c<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
+		entry2c<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
+		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 	},
 	{	/* variant 1: 64 KB tiles shared by 8 waves (4 waves per SIMD, 32 elements per thread) */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
@@ -987,7 +1047,21 @@ extern "C" int acmk_fused_tile_rows(uint32_t level, int variant)
 	return g_fused[variant][level - ACM_K1_MIN_LEVEL].tile_rows;
 }
 
-extern "C" int acmk_launch_fused(uint32_t level, int variant, int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles,
+extern "C" int acmk_fused_has_carry(uint32_t level, int variant)
+{
+	if (level < ACM_K1_MIN_LEVEL || level > ACM_K1_MAX_LEVEL || variant < 0 || variant >= NVARIANTS)
+		return 0;
+	return g_fused[variant][level - ACM_K1_MIN_LEVEL].fn_carry != nullptr;
+}
+
+extern "C" int acmk_fused_grid(uint32_t level, int variant, int cus)
+{
+	if (level < ACM_K1_MIN_LEVEL || level > ACM_K1_MAX_LEVEL || variant < 0 || variant >= NVARIANTS)
+		return 0;
+	return (cus > 0 ? cus : 256) * g_fused[variant][level - ACM_K1_MIN_LEVEL].wg_per_cu;
+}
+
+extern "C" int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const AcmDevStream *d_streams, const AcmTile *d_tiles,
 				 uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
 				 int16_t *d_pcm, unsigned fmt, void *stream)
 {
@@ -1001,7 +1075,9 @@ extern "C" int acmk_launch_fused(uint32_t level, int variant, int cus, const Acm
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream,
+	if (carry && !e.fn_carry)
+		return -1;
+	hipLaunchKernelGGL(carry ? e.fn_carry : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream,
 			   d_streams, d_tiles, ntiles, d_idx, d_hdr, d_pcm, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
