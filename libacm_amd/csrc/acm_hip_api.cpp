@@ -296,13 +296,14 @@ bool fused_ok(const acmhip_stream_desc &s)
 	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL;
 }
 
-/* ACM_K1_CARRY=0/1 forces the halo / carry flavour of the tile kernel (tests, measurements); default: carry when
- * a workgroup's run of the tile table is at least 32 tiles long */
-bool carry_wanted(size_t ntiles, size_t grid)
+/* ACM_K1_CARRY=0/1 forces the halo / carry flavour of the tile kernel (tests, measurements).  Default: carry mode
+ * saves 2 of every tile_rows rows and costs one lead-in tile per workgroup, so it pays from tile_rows/2 tiles per
+ * workgroup on; it is taken from tile_rows tiles per workgroup */
+bool carry_wanted(size_t ntiles, size_t grid, size_t tile_rows)
 {
 	if (const char *e = getenv("ACM_K1_CARRY"))
 		return atoi(e) != 0;
-	return grid > 0 && ntiles >= 32 * grid;
+	return grid > 0 && ntiles >= tile_rows * grid;
 }
 
 /* tuning knob: ACM_K1_VARIANT=n picks another built-in tile geometry (default: the measured-best one) */
@@ -443,9 +444,8 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		if (!tiles[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
-			/* carry mode pays one lead-in tile per workgroup: only when every workgroup has a long run */
-			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
-			g.carry = !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid);
+					const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
+			g.carry = !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
 			rc = to_device(dev, use, &g.d_tiles);
