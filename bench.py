@@ -197,15 +197,17 @@ def main():
     # every rank keeps a few file images for the setup-time self check; rank 0 at N=1 keeps the CPU baseline's sample
     keep = 4 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 1024)
     t0 = time.perf_counter()
+    stage_threads = max(4, min(64, workload_cpus() // world))      # ranks of one node share the host cores
     if args.workload == "corpus":
         # configs[2]/[3]: the SAME corpus whatever N; rank r decodes its longest-first shard of the file list
         from libacm_amd import batch as fe
         shapes = workload.corpus_shapes(args.files)
         mine = fe.shard_longest_first([s["total_values"] for s in shapes], world)[rank]
-        batch = workload.build_corpus(len(mine), shapes=[shapes[i] for i in mine], seed0=0, keep_files=keep)
+        batch = workload.build_corpus(len(mine), shapes=[shapes[i] for i in mine], seed0=0, keep_files=keep,
+                                      threads=stage_threads)
     else:
         batch = workload.build_uniform(args.streams, args.level, args.rows, args.blocks, channels=args.channels,
-                                       seed0=rank * args.streams, keep_files=keep)
+                                       seed0=rank * args.streams, keep_files=keep, threads=stage_threads)
     t_stage = time.perf_counter() - t0
     bufs = batch.upload(dev)
     plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
