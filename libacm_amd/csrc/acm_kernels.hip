@@ -505,17 +505,20 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	if (!(ABL & 32))
 		__syncthreads();
 	uint32_t w[BODY];
-	uint32_t tail = 0;
+	constexpr int NTAIL = CARRY ? (BS + C::NT - 1) / C::NT : 1;     /* carried elements per thread (1 for every default geometry) */
+	uint32_t tail[NTAIL];
 	{
 		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= 64 ? BS / 64 : 1)) : tile + lds_at(m_seg - BS);
 		if constexpr (CARRY) {
 			/* segment 0's history is what the previous tile of this stream left behind: the last BS elements
 			 * of its input to this pass, kept in `carry` with the same pad rule (element j at j + off-pad) */
-			static_assert(BS <= C::NT, "one thread per carried element");
 			if (seg == 0)
 				pw = carry + i;
-			if (tid < BS)
-				tail = tile[lds_at(C::NELEM - BS + tid)];       /* this tile's bequest, read before it is overwritten */
+#pragma unroll
+			for (int k = 0; k < NTAIL; k++) {
+				const int j = tid + k * C::NT;
+				tail[k] = (j < BS) ? tile[lds_at(C::NELEM - BS + j)] : 0u;      /* this tile's bequest, read before it is overwritten */
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
@@ -524,9 +527,11 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	if (!(ABL & 32))
 		__syncthreads();
 	if constexpr (CARRY) {
-		if (tid < BS) {
-			const int u_sigma = (tid / SIGMA) * SIGMA;
-			carry[tid + (u_sigma >> 6)] = tail;                     /* next read: this pass of the next tile */
+#pragma unroll
+		for (int k = 0; k < NTAIL; k++) {
+			const int j = tid + k * C::NT;
+			if (j < BS)
+				carry[j + (((j / SIGMA) * SIGMA) >> 6)] = tail[k];     /* next read: this pass of the next tile */
 		}
 	}
 
