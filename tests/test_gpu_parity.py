@@ -300,3 +300,29 @@ def test_random_batch_fuzz(dev):
             assert np.array_equal(host[k][1], want), (k, fmt)
             assert np.array_equal(devr[k][1], want), (k, fmt)
             assert host[k][0] == devr[k][0]
+
+
+@pytest.mark.parametrize("carry", ["0", "1"])
+def test_tile_kernel_flavours(dev, carry, monkeypatch):
+    """the halo kernel and the carry-mode kernel (ACM_K1_CARRY forces either) give the oracle's PCM: long streams
+    (many tiles per stream, lead-in tiles where a workgroup's run starts mid-stream), ragged ends, stereo, every fused
+    level, windows that start at row_begin > 0, all four output formats"""
+    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    files = [make_stream(9500 + lv, lv, rows, nb, channels=1 + lv % 2, cut=7 * lv)
+             for lv, rows, nb in ((5, 16, 700), (6, 7, 300), (7, 16, 120), (8, 33, 40), (9, 16, 30), (10, 5, 20), (11, 64, 3))]
+    for fmt in (capi.FMT_S16LE, capi.FMT_U16BE):
+        be, sg = fmt_args(fmt)
+        staged = [capi.stage_file(f) for f in files]
+        got = capi.synth(dev, staged, fmt=fmt)
+        for f, g in zip(files, got):
+            want, _ = oracle_pcm(f, 0, be, sg)
+            assert np.array_equal(g, want)
+    for lv, rows in ((7, 16), (9, 16), (11, 4)):
+        f = make_stream(9600 + lv, lv, rows, 40)
+        s = capi.stage_file(f)
+        want, _ = oracle_pcm(f)
+        cols = 1 << lv
+        for row_begin in (1, 2, rows + 1, 17 * rows):
+            n_emit = (s.info.blocks * rows - row_begin) * cols - 5
+            got = capi.synth(dev, [s], windows=[(row_begin, n_emit)])[0]
+            assert np.array_equal(got, want[row_begin * cols: row_begin * cols + n_emit]), (lv, row_begin)
