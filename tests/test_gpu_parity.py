@@ -326,3 +326,42 @@ def test_tile_kernel_flavours(dev, carry, monkeypatch):
             n_emit = (s.info.blocks * rows - row_begin) * cols - 5
             got = capi.synth(dev, [s], windows=[(row_begin, n_emit)])[0]
             assert np.array_equal(got, want[row_begin * cols: row_begin * cols + n_emit]), (lv, row_begin)
+
+
+def test_concurrent_callers(dev):
+    """threads sharing one device handle: acm_batch_decode calls serialise on the handle's arenas; independent
+    ACMStreams of the drop-in API decode side by side on the shared default device (SURVEY 8b threading)"""
+    import threading
+    import oracle_api as O
+    files = [make_stream(9700 + i, 5 + i % 5, 16, 6 + i % 7, channels=1 + i % 2, cut=i) for i in range(24)]
+    wants = [oracle_pcm(f)[0] for f in files]
+    errors = []
+
+    def batch_worker(k):
+        try:
+            for rep in range(3):
+                mode = (capi.PARSE_HOST, capi.PARSE_DEVICE)[(k + rep) % 2]
+                res, _ = capi.batch_decode(dev, files[k::3], threads=2, parse=mode)
+                for (st, pcm), want in zip(res, wants[k::3]):
+                    assert st == 0 and np.array_equal(pcm, want)
+        except Exception as e:      # noqa: BLE001 - collected for the main thread
+            errors.append(("batch", k, repr(e)))
+
+    def stream_worker(k):
+        try:
+            lib = O.bind_libacm(capi.lib())
+            for f, want in list(zip(files, wants))[k::4]:
+                s = O.LibacmStream(lib, f)
+                pcm, rc = s.decode_all()
+                s.close()
+                assert pcm == want.tobytes()
+        except Exception as e:      # noqa: BLE001
+            errors.append(("stream", k, repr(e)))
+
+    threads = [threading.Thread(target=batch_worker, args=(k,)) for k in range(3)]
+    threads += [threading.Thread(target=stream_worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
