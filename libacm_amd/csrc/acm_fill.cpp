@@ -550,6 +550,16 @@ fail:
 	return rc;
 }
 
+int skip_bits(ACMStream *s, unsigned n)
+{
+	if (n == 0)
+		return 0;
+	BitCursor bc(s);
+	const int v = bc.get(n);
+	bc.commit();
+	return v < 0 ? v : 0;
+}
+
 void reset_reader(ACMStream *s)
 {
 	s->file_eof = 0;

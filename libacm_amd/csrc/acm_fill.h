@@ -63,6 +63,9 @@ inline unsigned raw_position(const ACMStream *s) { return s->buf_start_ofs + s->
 /* rewind bookkeeping of acm_seek_pcm (util.c:230-239); the caller has already repositioned the data source */
 void reset_reader(ACMStream *s);
 
+/* consume n (< 32) bits through the exact reader (used to re-enter the stream at a remembered bit offset); 0 or error */
+int skip_bits(ACMStream *s, unsigned n);
+
 } // namespace acmfill
 
 #endif

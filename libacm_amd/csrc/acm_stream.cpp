@@ -87,6 +87,15 @@ struct HipStream {
 	std::vector<unsigned> tell_after;
 	std::vector<acmhip_patch> patches;
 
+	/* block index, built while parsing: where every block seen so far starts in the file
+	 * and what its header was.  A backward seek re-enters the stream just in front of its target instead of
+	 * re-parsing from the first block (util.c:219-242 has no index: block sizes are data dependent). */
+	std::vector<uint64_t> mark_bit;         /* true file bit offset of block b's first bit */
+	std::vector<acmhip_blkhdr> hdr_log;     /* (val, pwr) of block b: all the stale-table history needs */
+	uint64_t next_block_no = 0;             /* number of the block the parser reads next */
+	int64_t ofs_delta = 0;                  /* true file offset of the refill buffer minus buf_start_ofs
+	                                           (after a seek the reference counts from 14 even behind a WAVC prefix) */
+
 	acmhip_device *dev = nullptr;
 	int16_t *d_idx = nullptr;
 	acmhip_blkhdr *d_hdr = nullptr;
@@ -167,11 +176,16 @@ int fill_window(HipStream *hs)
 	for (uint32_t i = 0; i < want; i++) {
 		const size_t slot = hs->carry + i;
 		sink.base_sample = (uint64_t)slot * bl;
+		if (hs->next_block_no == hs->mark_bit.size())
+			hs->mark_bit.push_back(8ull * (uint64_t)((int64_t)a->buf_start_ofs + hs->ofs_delta + a->buf_pos) - a->bit_avail);
 		const int rc = acmfill::parse_block(a, &hs->tab, hs->h_idx + slot * bl, hs->h_hdr + slot, &sink);
 		if (rc != 1) {
 			hs->pending = rc;
 			break;
 		}
+		if (hs->next_block_no == hs->hdr_log.size())
+			hs->hdr_log.push_back(hs->h_hdr[slot]);
+		hs->next_block_no++;
 		hs->tell_after[i] = acmfill::raw_position(a);
 		hs->win_blocks++;
 	}
@@ -518,17 +532,43 @@ extern "C" int acm_seek_pcm(ACMStream *acm, unsigned pcm_pos)
 	const unsigned word_pos = pcm_pos * acm->info.channels;
 
 	if (word_pos < acm->stream_pos) {
-		/* no block index exists (block sizes are data dependent): rewind and re-parse (util.c:219-242) */
+		/* the reference rewinds and re-parses from the first block (util.c:219-242).  Same observable result,
+		 * without the re-parse: re-enter at the remembered start of the block `halo` blocks in front of the
+		 * target (those blocks are the synthesis history of the target block; they are parsed, their PCM is
+		 * never delivered), on the 4-byte grid the reference's reader would be on after its rewind, and bring
+		 * the stale-table history to where re-parsing the skipped blocks would have left it. */
 		if (acm->io.seek_func == NULL)
 			return ACM_ERR_NOT_SEEKABLE;
-		const int start = 14 + (acm->wavc_file ? 28 : 0);
-		if (acm->io.seek_func(acm->io_arg, start, SEEK_SET) < 0)
+		const unsigned start = 14 + (acm->wavc_file ? 28 : 0);
+		const uint64_t bl = acm->block_len;
+		const uint64_t halo = acm->info.acm_rows >= 2 ? 1 : 2;
+		const uint64_t target = word_pos / bl;
+		const uint64_t enter = target > halo ? target - halo : 0;
+		const bool indexed = enter >= 1 && enter < hs->mark_bit.size() && enter <= hs->hdr_log.size() &&
+				     bl % acm->info.channels == 0 && getenv("ACM_NO_SEEK_INDEX") == NULL;
+		uint64_t at = start;
+		if (indexed) {
+			at = hs->mark_bit[enter] >> 3;
+			at -= (at - start) & 3u;
+		}
+		if (acm->io.seek_func(acm->io_arg, (int)at, SEEK_SET) < 0)
 			return ACM_ERR_NOT_SEEKABLE;
 		acmfill::reset_reader(acm);
+		hs->ofs_delta = (int64_t)start - 14;
 		acm->stream_pos = 0;
 		acm->block_pos = 0;
 		acm->block_ready = 0;
 		drop_window(hs);                        /* history = zeros again (util.c:241) */
+		hs->next_block_no = 0;
+		if (indexed) {
+			acm->buf_start_ofs = 14 + (unsigned)(at - start);
+			if (acmfill::skip_bits(acm, (unsigned)(hs->mark_bit[enter] - 8 * at)) < 0)
+				return ACM_ERR_OTHER;           /* the data source no longer holds what was indexed */
+			for (uint64_t b = 0; b < enter; b++)
+				hs->tab.note_block(hs->hdr_log[b].pwr, hs->hdr_log[b].val);
+			acm->stream_pos = (unsigned)(enter * bl);
+			hs->next_block_no = enter;
+		}
 		hs->tell_now = acmfill::raw_position(acm);
 	}
 	while (acm->stream_pos < word_pos) {

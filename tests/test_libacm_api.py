@@ -65,6 +65,48 @@ def test_seek_and_discard_bookkeeping():
     s.close()
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref)")
+@pytest.mark.parametrize("shape", [(5, 4, 60, 1, 0), (7, 16, 25, 2, 0), (3, 1, 90, 1, 0), (6, 5, 40, 2, 1), (0, 3, 50, 1, 0), (7, 16, 500, 1, 1)])
+def test_random_seek_walk_matches_reference(shape, monkeypatch):
+    """a walk of forward/backward acm_seek_pcm / acm_seek_time calls and discard reads: return values, acm_pcm_tell,
+    acm_raw_tell and acm_time_tell equal the reference's at every step - with the block index (backward seeks re-enter
+    the stream near the target) and without it (ACM_NO_SEEK_INDEX: rewind and re-parse, as the reference does)"""
+    import numpy as np
+    from libacm_amd import synth
+    level, rows, nb, ch, wavc = shape
+    f = synth.generate(seed=synth.BASE_SEED + 4200 + level, level=level, rows=rows, nblocks=nb, channels=ch, wavc=wavc,
+                       total_values=nb * (rows << level) - 3 * ch)
+    total_pcm = (nb * (rows << level) - 3 * ch) // ch
+    reads_with_index = None
+    for no_index in (False, True):
+        if no_index:
+            monkeypatch.setenv("ACM_NO_SEEK_INDEX", "1")
+        rng = np.random.default_rng(level * 100 + rows)
+        r = O.LibacmStream(O.ref_lib(), f)
+        s = ours(f)
+        for step in range(60):
+            op = int(rng.integers(0, 3))
+            if op == 0:
+                n = int(rng.integers(1, 4000)) * 2
+                got, want = s.read(n, discard=True)[0], r.read(n, discard=True)[0]
+            elif op == 1:
+                pos = int(rng.integers(0, total_pcm + 50))
+                got, want = s.seek_pcm(pos), r.seek_pcm(pos)
+            else:
+                ms = int(rng.integers(0, total_pcm * 1000 // 22050 + 20))
+                got, want = s.seek_time(ms), r.seek_time(ms)
+            state = [(x.getter("pcm_tell"), x.getter("raw_tell"), x.getter("time_tell")) for x in (s, r)]
+            assert got == want and state[0] == state[1], (shape, no_index, step, op, got, want, state)
+        if no_index:
+            # the index must have saved re-parsing: fewer refill calls than the rewind-and-re-parse flavour (long files)
+            if len(f) > 200000:
+                assert reads_with_index < len(s.io.read_calls)
+        else:
+            reads_with_index = len(s.io.read_calls)
+        s.close()
+        r.close()
+
+
 def discard_all(s):
     words = 0
     while True:
@@ -255,3 +297,31 @@ def test_interleaved_reads_on_two_streams(dev):
     a.close()
     b.close()
     assert b"".join(ga) == wa and b"".join(gb) == wb
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref)")
+@pytest.mark.parametrize("shape", [(7, 16, 120, 1, 0), (5, 1, 300, 2, 1), (9, 16, 12, 2, 0), (6, 3, 80, 1, 0)])
+def test_random_seek_walk_pcm(shape):
+    """seeks forward and backward (block index in use) followed by real reads: the PCM bytes and all positions equal
+    the reference's"""
+    import numpy as np
+    from libacm_amd import synth
+    level, rows, nb, ch, wavc = shape
+    total = nb * (rows << level) - 5 * ch
+    f = synth.generate(seed=synth.BASE_SEED + 4300 + level, level=level, rows=rows, nblocks=nb, channels=ch, wavc=wavc,
+                       total_values=total)
+    rng = np.random.default_rng(level * 7 + rows)
+    r = O.LibacmStream(O.ref_lib(), f)
+    s = ours(f)
+    for step in range(50):
+        if step % 2 == 0:
+            pos = int(rng.integers(0, total // ch))
+            assert s.seek_pcm(pos) == r.seek_pcm(pos), (shape, step, pos)
+        n = int(rng.integers(1, 3000)) * 2 * ch
+        be, sg = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        got, want = s.read(n, be=be, sgned=sg), r.read(n, be=be, sgned=sg)
+        assert got == want, (shape, step, n)
+        assert [s.getter(k) for k in ("pcm_tell", "raw_tell")] == [r.getter(k) for k in ("pcm_tell", "raw_tell")]
+    s.close()
+    r.close()
