@@ -64,6 +64,8 @@ struct AcmParseResult {
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
 #define ACM_K1_MAX_LEVEL 11
+/* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
+#define ACM_SMALL_MAX_LEVEL 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -97,6 +99,8 @@ int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uin
 int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file_len, uint64_t blocks);
 int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream);
+int acmk_launch_small(uint32_t level, const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
+		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
 		     const int32_t *d_x, int16_t *d_pcm, unsigned fmt, void *stream);
 #ifdef __cplusplus

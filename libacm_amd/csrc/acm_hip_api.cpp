@@ -66,7 +66,7 @@ struct LevelGroup {
 struct acmhip_plan {
 	acmhip_device *dev = nullptr;
 	AcmDevStream *d_streams = nullptr;
-	std::vector<LevelGroup> fused, stagewise;
+	std::vector<LevelGroup> fused, stagewise, small;   /* small: levels 0-4, one register-cascade launch */
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
 	uint64_t sw_max_elems = 0;
@@ -332,6 +332,8 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		(void)hipFree(g.d_tiles);
 	for (auto &g : plan->stagewise)
 		(void)hipFree(g.d_list);
+	for (auto &g : plan->small)
+		(void)hipFree(g.d_list);
 	(void)hipFree(plan->d_sw_all);
 	(void)hipFree(plan->d_patches);
 	(void)hipFree(plan->d_plane[0]);
@@ -358,7 +360,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	}
 
 	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16);
-	std::vector<std::vector<uint32_t>> lists(16);
+	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
 	uint64_t plane = 0, sw_max = 0;
@@ -410,6 +412,10 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 					tc.push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), (r == 0 && s.row_begin == 0) ? ACM_TILE_FRESH : 0u, 0u });
 			}
 			st.fused_streams++;
+		} else if (!(flags & ACMHIP_PLAN_STAGEWISE) && s.level <= ACM_SMALL_MAX_LEVEL && !has_patch[i]) {
+			small_lists[s.level].push_back((uint32_t)i);
+			grp_max_emit[s.level] = std::max(grp_max_emit[s.level], (uint64_t)s.n_emit);
+			st.fused_streams++;
 		} else {
 			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
 			d.scratch_off = plane;
@@ -451,6 +457,15 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			rc = to_device(dev, use, &g.d_tiles);
 			pl->fused.push_back(g);
 			st.tiles += g.ntiles;
+			st.launches += 1;
+		}
+		if (lv <= ACM_SMALL_MAX_LEVEL && !small_lists[lv].empty() && rc == ACMHIP_OK) {
+			LevelGroup g;
+			g.level = lv;
+			g.nlist = (uint32_t)small_lists[lv].size();
+			g.max_emit = grp_max_emit[lv];
+			rc = to_device(dev, small_lists[lv], &g.d_list);
+			pl->small.push_back(g);
 			st.launches += 1;
 		}
 		if (!lists[lv].empty() && rc == ACMHIP_OK) {
@@ -511,6 +526,9 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 
 	for (const LevelGroup &g : pl->fused)
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+
+	for (const LevelGroup &g : pl->small)
+		LAUNCHTRY(acmk_launch_small(g.level, pl->d_streams, g.d_list, g.nlist, g.max_emit, d_idx, d_hdr, d_pcm, fmt, st));
 
 	if (pl->n_sw_all) {
 		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,

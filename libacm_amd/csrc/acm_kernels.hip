@@ -122,6 +122,125 @@ acm_sw_emit(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// small levels (cols <= 16): the whole cascade in one thread's registers
+// ---------------------------------------------------------------------------
+/*
+ * For level <= 4 an output depends on fewer than 2*cols - 2 <= 30 earlier samples, so one thread can own SL_K = 32
+ * consecutive outputs, load them and the 32 samples in front of them (two aligned 64-byte runs), run every stage over
+ * that register array and write 64 bytes of PCM - one launch, 2 B in + 2 B out per sample, instead of the stage-wise
+ * family's launch per stage over int32 planes.  Coordinates are the stage-wise family's: e counts from the first
+ * staged sample the kernels may read (row halo_row), samples before it are zeros (exact: the reach is < 2 rows).
+ * Because chunks start on multiples of 32 >= cols, column, sign and the "+1" of an element are compile-time
+ * functions of its position in the register array.
+ */
+constexpr int SL_K = 32;                 /* outputs per thread */
+/* history the stages 0..k need in front of a position, in samples */
+constexpr int sl_reach(int cols, int k) { int r = 0; for (int i = 0; i <= k; i++) r += 2 * (cols >> (i + 1)); return r; }
+template <int L, int K> struct SlStage {
+	static constexpr int ST = (1 << L) >> (K + 1), LO = sl_reach(1 << L, K);
+};
+constexpr int SL_THREADS = 256;
+
+template <int L, int K>
+__device__ __forceinline__ void sl_stages(uint32_t (&x)[2 * SL_K], const int64_t e0)
+{
+	if constexpr (K < L) {
+		constexpr int ST = SlStage<L, K>::ST, LO = SlStage<L, K>::LO, COLS = 1 << L, N = 2 * SL_K;
+		/* positions below LO lack history inside the array: never used by a valid output */
+#pragma unroll
+		for (int jj = N - 1; jj >= LO; jj--) {
+			const uint32_t a = x[jj - 2 * ST], z = x[jj - ST], c = x[jj];
+			uint32_t y = ((jj / ST) & 1) ? 2u * z - (a + c) : 2u * z + (a + c);     /* decode.c:518-519 */
+			if (K == 0 && (jj & (COLS / 2 - 1)) == 0 && e0 + jj >= 0)
+				y += 1u;                                                /* :561-564, rows that exist only */
+			x[jj] = y;
+		}
+		sl_stages<L, K + 1>(x, e0);
+	}
+}
+
+template <int L>
+__global__ void __launch_bounds__(SL_THREADS)
+acm_small_level(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
+		const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
+		int16_t *__restrict__ pcm, unsigned fmt)
+{
+	constexpr int COLS = 1 << L, N = 2 * SL_K;
+	const AcmDevStream s = streams[list[blockIdx.y]];
+	const int64_t n_in = (int64_t)(s.nrows - s.halo_row) << L;                  /* staged samples the stream has, from e = 0 */
+	const int64_t e_emit = (int64_t)(s.row_begin - s.halo_row) << L;            /* e of the first emitted sample */
+	const int16_t *src = idx + s.idx_off + ((uint64_t)s.halo_row << L);
+	const acmhip_blkhdr *h = hdr + s.hdr_off;
+	uint16_t *dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
+	const uint64_t nchunks = (s.n_emit + SL_K - 1) / SL_K;
+
+	for (uint64_t q = (uint64_t)blockIdx.x * SL_THREADS + threadIdx.x; q < nchunks; q += (uint64_t)gridDim.x * SL_THREADS) {
+		const int64_t e0 = e_emit + (int64_t)q * SL_K - SL_K;               /* e of x[0]; a multiple of cols */
+		const uint64_t g0 = q * SL_K;                                       /* first output of the chunk */
+		/* staged indices, sign-extended: 64 samples; zeros outside [0, n_in) */
+		int32_t ix[N];
+		const bool inside = e0 >= 0 && e0 + N <= n_in && (reinterpret_cast<uintptr_t>(src + e0) & 15u) == 0;
+		if (inside) {
+#pragma unroll
+			for (int v = 0; v < N / 8; v++) {
+				const uint4 w = *reinterpret_cast<const uint4 *>(src + e0 + v * 8);
+				const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					ix[v * 8 + 2 * k] = (int32_t)(int16_t)(ww[k] & 0xFFFFu);
+					ix[v * 8 + 2 * k + 1] = (int32_t)ww[k] >> 16;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < N; k++)
+				ix[k] = (e0 + k >= 0 && e0 + k < n_in) ? (int32_t)src[e0 + k] : 0;
+		}
+		/* unpack: value = idx * val of the sample's block (decode.c:592-600); one header look-up per row */
+		uint32_t x[N];
+		{
+			const int64_t row0 = (int64_t)s.halo_row + (e0 >> L);             /* stream row of x[0] (may be negative) */
+			uint32_t blk = row0 > 0 ? (uint32_t)row0 / s.rows : 0u;
+			uint32_t rem = row0 > 0 ? (uint32_t)row0 % s.rows : 0u;
+#pragma unroll
+			for (int r = 0; r < N / COLS; r++) {
+				const int64_t row = row0 + r;
+				int32_t val = 0;
+				if (row >= 0 && row < (int64_t)s.nrows) {
+					val = (int32_t)h[blk].val;
+					if (++rem == s.rows) {
+						rem = 0;
+						blk++;
+					}
+				}
+#pragma unroll
+				for (int c = 0; c < COLS; c++)
+					x[r * COLS + c] = (uint32_t)__mul24(ix[r * COLS + c], val);  /* |idx| < 2^15, val < 2^16 */
+			}
+		}
+		/* the stages, highest position first so that every tap is still the previous stage's value */
+		sl_stages<L, 0>(x, e0);
+		/* write-out (decode.c:617-655): 32 samples = 64 bytes */
+		if (g0 + SL_K <= s.n_emit) {
+			uint4 *o = reinterpret_cast<uint4 *>(dst + g0);
+#pragma unroll
+			for (int v = 0; v < SL_K / 8; v++) {
+				uint32_t w[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					w[k] = pcm16((int32_t)x[SL_K + v * 8 + 2 * k], L, fmt) | pcm16((int32_t)x[SL_K + v * 8 + 2 * k + 1], L, fmt) << 16;
+				o[v] = make_uint4(w[0], w[1], w[2], w[3]);
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < SL_K; k++)
+				if (g0 + k < s.n_emit)
+					dst[g0 + k] = (uint16_t)pcm16((int32_t)x[SL_K + k], L, fmt);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // fused tile kernel
 // ---------------------------------------------------------------------------
 /* tile configuration: level, threads per workgroup, tile elements held in LDS */
@@ -1119,6 +1238,29 @@ extern "C" int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *
 		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
 		hipLaunchKernelGGL(acm_sw_stage, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
 				   d_streams, d_list + at, level, k, d_in, d_out);
+		ACMK_CHECK_LAUNCH();
+	}
+	return 0;
+}
+
+extern "C" int acmk_launch_small(uint32_t level, const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
+				 uint64_t max_emit, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm,
+				 unsigned fmt, void *stream)
+{
+	if (level > ACM_SMALL_MAX_LEVEL)
+		return -1;
+	uint64_t gx = (max_emit + (uint64_t)SL_THREADS * SL_K - 1) / ((uint64_t)SL_THREADS * SL_K);
+	gx = gx < 1 ? 1 : gx > 4096 ? 4096 : gx;
+	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
+		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
+		const dim3 grid((unsigned)gx, n, 1);
+		switch (level) {
+		case 0: hipLaunchKernelGGL(acm_small_level<0>, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, d_streams, d_list + at, d_idx, d_hdr, d_pcm, fmt); break;
+		case 1: hipLaunchKernelGGL(acm_small_level<1>, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, d_streams, d_list + at, d_idx, d_hdr, d_pcm, fmt); break;
+		case 2: hipLaunchKernelGGL(acm_small_level<2>, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, d_streams, d_list + at, d_idx, d_hdr, d_pcm, fmt); break;
+		case 3: hipLaunchKernelGGL(acm_small_level<3>, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, d_streams, d_list + at, d_idx, d_hdr, d_pcm, fmt); break;
+		default: hipLaunchKernelGGL(acm_small_level<4>, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, d_streams, d_list + at, d_idx, d_hdr, d_pcm, fmt); break;
+		}
 		ACMK_CHECK_LAUNCH();
 	}
 	return 0;
