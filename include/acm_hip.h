@@ -89,7 +89,7 @@ typedef struct acmhip_device acmhip_device;   /* one HIP device + the stream wor
 typedef struct acmhip_plan acmhip_plan;       /* device-resident launch tables for a fixed set of stream descs */
 
 /* which kernel family a plan may use */
-#define ACMHIP_PLAN_AUTO      0u    /* one-launch kernels where they apply (levels 0-11 without H1 patches), stage-wise kernels elsewhere */
+#define ACMHIP_PLAN_AUTO      0u    /* one-launch kernels where they apply (levels 0-12 without H1 patches), stage-wise kernels elsewhere */
 #define ACMHIP_PLAN_STAGEWISE 1u    /* force the generic stage-wise kernels (bring-up / cross-check) */
 
 const char *acmhip_last_error(void);          /* thread-local text of the last failure */
@@ -132,7 +132,7 @@ int  acmhip_plan_launch(acmhip_plan *plan, const int16_t *d_idx, const acmhip_bl
 typedef struct acmhip_plan_stats {
 	uint64_t samples;        /* total n_emit */
 	uint64_t tiles;          /* fused-kernel workgroups */
-	uint32_t fused_streams;  /* streams handled by a one-launch kernel (fused tile kernel, levels 5-11; register kernel, levels 0-4) */
+	uint32_t fused_streams;  /* streams handled by a one-launch kernel (fused tile kernel, levels 5-12; register kernel, levels 0-4) */
 	uint32_t stagewise_streams;
 	uint32_t launches;       /* kernel launches per acmhip_plan_launch */
 	uint32_t reserved;

@@ -63,7 +63,7 @@ struct AcmParseResult {
 
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
-#define ACM_K1_MAX_LEVEL 11
+#define ACM_K1_MAX_LEVEL 12
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 

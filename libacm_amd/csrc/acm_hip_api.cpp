@@ -291,9 +291,9 @@ int to_device(acmhip_device *dev, const std::vector<T> &v, T **out)
 	return ACMHIP_OK;
 }
 
-bool fused_ok(const acmhip_stream_desc &s)
+bool fused_ok(const acmhip_stream_desc &s, int variant)
 {
-	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL;
+	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL && acmk_fused_tile_rows(s.level, variant) > 2;
 }
 
 /* ACM_K1_CARRY=0/1 forces the halo / carry flavour of the tile kernel (tests, measurements).  Default: carry mode
@@ -393,7 +393,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		if (s.n_emit == 0)
 			continue;
 
-		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s) && !has_patch[i];
+		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s, variant) && !has_patch[i];
 		if (fused) {
 			const uint32_t T = (uint32_t)acmk_fused_tile_rows(s.level, variant) - 2;
 			const uint64_t cols = 1ull << s.level;

@@ -975,6 +975,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2c<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
 		entry2c<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
 		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
+		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
 	},
 	{	/* variant 1: 64 KB tiles shared by 8 waves (4 waves per SIMD, 32 elements per thread) */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),

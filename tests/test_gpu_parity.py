@@ -69,8 +69,8 @@ def test_mixed_batch(dev):
     """one plan, streams of different level / rows / length / channels, ragged tails"""
     files = []
     for i in range(40):
-        lv = [0, 3, 5, 7, 8, 9, 11, 12][i % 8]
-        rows = [1, 2, 16, 17, 33][i % 5]
+        lv = [0, 3, 5, 7, 8, 9, 11, 12, 13][i % 9]
+        rows = [1, 2, 16, 17, 33][i % 5] if lv < 13 else 2
         nb = 1 + (i * 7) % 9
         files.append(make_stream(500 + i, lv, rows, nb, channels=1 + i % 2, cut=i % 4))
     st = check_streams(dev, files)
