@@ -93,3 +93,29 @@ def test_cli_batch_mode(dev):
             single = [open(p[:-4] + ext, "rb").read() for p in names]
             assert batch == single
             assert b"adding filler_samples" in berr and berr == r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_batch_decode(tmp_path):
+    """examples/batch_decode.c compiles as plain C99 against include/acm_hip.h and decodes what the oracle decodes"""
+    import subprocess, glob
+    import numpy as np
+    import oracle_api as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "batch_decode")
+    libdir = os.path.join(root, "libacm_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "examples", "batch_decode.c"), "-L", libdir, "-lacm_hip",
+                        "-Wl,-rpath," + libdir, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    files = sorted(glob.glob(os.path.join(root, "tests", "golden", "acm", "f1_*.acm")))[:12]
+    r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files)
+    for path, line in zip(files, lines):
+        pcm, st = O.Oracle.decode_all(open(path, "rb").read())
+        h = 2166136261
+        for b in pcm.tobytes():
+            h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+        assert line.split()[1:] == ["status", "0", "words", str(pcm.size), "fnv1a", "%08x" % h], (path, line)
