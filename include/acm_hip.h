@@ -218,8 +218,9 @@ typedef struct acm_batch_opts {
                                        sure about (data running out, corrupt symbols, hazard H1, files >= 256 MiB) are
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
 #define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch is worth at least 16 x threads streams of its longest
-                                       stream's size, HOST below that: walking a stream is sequential, and one GPU
-                                       lane walks ~16x slower than one host core parses */
+                                       stream's size (9 x threads up to 2048 streams, which are walked on the scalar
+                                       unit), HOST below that: walking a stream is sequential, and one GPU lane walks
+                                       9-16x slower than one host core parses */
 
 typedef struct acm_batch_timing {
 	double stage_s;          /* wall clock until the last stream was bit-parsed (headers included, allocation not) */

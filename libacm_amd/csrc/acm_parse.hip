@@ -142,31 +142,30 @@ __device__ __forceinline__ uint32_t k_table_for(uint32_t code)
 }
 
 /* ---- kernel 1: walk the streams ---- */
-__global__ void __launch_bounds__(SCAN_THREADS)
-acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
-	       uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
+
+/* payload bits of a column by filler code for `rows` rows; K_WALK = step through it, BAD_CODE = stop */
+__device__ __forceinline__ uint32_t column_bits(uint32_t code, uint32_t rows)
 {
-	/* Streams are dealt out across wavefronts first, lanes second: a walk is a chain of dependent steps and
-	 * lanes of one wavefront serialise each other's branches, so with few streams each one gets a wavefront
-	 * (nearly) to itself and only big batches fill the lanes. */
-	const uint32_t j = blockIdx.x + threadIdx.x * gridDim.x;
-	if (j >= njobs)
-		return;
-	const AcmParseJob job = jobs[j];
+	const uint32_t cls = code_class(code);
+	return cls == CLS_ZERO ? 0u : cls == CLS_LINEAR ? rows * code : cls == CLS_K ? K_WALK : cls == CLS_BAD ? BAD_CODE :
+	       code == 19 ? (rows + 2) / 3 * 5 : code == 22 ? (rows + 2) / 3 * 7 : (rows + 1) / 2 * 7;
+}
+
+/*
+ * One stream.  LONE = this wavefront has no other stream: everything about the walk is then wave-uniform, the
+ * compiler keeps it on the scalar unit (s_load through the scalar cache for the window, SALU for the bit
+ * arithmetic) and a step costs a few cycles instead of the ~8 per dependent VALU instruction plus an exposed vector
+ * memory round trip per window refill.  Otherwise `collen` is this lane's 32-entry table in LDS.
+ */
+template <bool LONE>
+__device__ __forceinline__ void scan_stream(const AcmParseJob &job, const uint8_t *__restrict__ files, uint32_t *__restrict__ colpos,
+					    acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ out, const uint32_t *collen)
+{
 	const uint32_t rows = job.rows, cols = 1u << job.level;
 	const uint32_t safe = job.file_len * 8u;                /* bits that really belong to the file */
 
 	DevBits bs;
 	bs.seek(reinterpret_cast<const uint32_t *>(files + job.file_off), job.data_start * 8u);
-
-	/* payload bits of a column by filler code, for this stream's row count; K_WALK = step through it, BAD_CODE = stop */
-	extern __shared__ uint32_t scan_lds[];
-	uint32_t *collen = scan_lds + threadIdx.x * 33;
-	for (uint32_t code = 0; code < 32; code++) {
-		const uint32_t cls = code_class(code);
-		collen[code] = cls == CLS_ZERO ? 0u : cls == CLS_LINEAR ? rows * code : cls == CLS_K ? K_WALK : cls == CLS_BAD ? BAD_CODE :
-			       code == 19 ? (rows + 2) / 3 * 5 : code == 22 ? (rows + 2) / 3 * 7 : (rows + 1) / 2 * 7;
-	}
 
 	uint32_t done = 0, status = 0;
 	uint32_t *cp = colpos + job.col_off;
@@ -184,17 +183,24 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 			}
 			cp[c] = bs.bit;
 			const uint32_t code = bs.get(5);
-			const uint32_t len = collen[code];
+			const uint32_t len = LONE ? column_bits(code, rows) : collen[code];
 			if (len < K_WALK) {
 				bs.skip(len);
 			} else if (len == K_WALK) {
 				const uint32_t tab = k_table_for(code);
 				uint32_t r = 0;
+				/* four symbols per trip (<= 5 bits each), predicated on the rows left: the loop control and the
+				 * window check are paid once per trip */
 				while (r < rows && bs.bit < safe) {
-					bs.need(5);
-					const uint32_t e = (tab >> (((uint32_t)bs.win & 7u) * 4)) & 15u;
-					bs.drop(e & 7u);
-					r += 1 + (e >> 3);
+					bs.need(20);
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const bool go = r < rows;
+						const uint32_t e = (tab >> (((uint32_t)bs.win & 7u) * 4)) & 15u;
+						const uint32_t len1 = go ? (e & 7u) : 0u;
+						bs.drop(len1);
+						r += go ? 1 + (e >> 3) : 0u;
+					}
 				}
 				if (r < rows)
 					status = 1;                     /* ran out of data inside the column */
@@ -212,7 +218,35 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 		cp += cols;
 		done++;
 	}
-	res[j] = AcmParseResult{ done, status };
+	*out = AcmParseResult{ done, status };
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
+	       uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
+{
+	/* Streams are dealt out across wavefronts first, lanes second: a walk is a chain of dependent steps and
+	 * lanes of one wavefront serialise each other's branches. */
+	const uint32_t j = blockIdx.x + threadIdx.x * gridDim.x;
+	if (j >= njobs)
+		return;
+	const AcmParseJob job = jobs[j];
+	extern __shared__ uint32_t scan_lds[];
+	uint32_t *collen = scan_lds + threadIdx.x * 33;
+	for (uint32_t code = 0; code < 32; code++)
+		collen[code] = column_bits(code, job.rows);
+	scan_stream<false>(job, files, colpos, hdr, res + j, collen);
+}
+
+/* few streams: one per wavefront, walked on the scalar unit */
+__global__ void __launch_bounds__(SCAN_THREADS)
+acm_parse_scan_lone(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
+		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
+{
+	if (threadIdx.x != 0 || blockIdx.x >= njobs)
+		return;
+	const AcmParseJob job = jobs[blockIdx.x];
+	scan_stream<true>(job, files, colpos, hdr, res + blockIdx.x, nullptr);
 }
 
 /* ---- kernel 2: decode the columns ---- */
@@ -376,8 +410,14 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 	const uint32_t full = (njobs + SCAN_THREADS - 1) / SCAN_THREADS;
 	const uint32_t scan_waves = njobs < 8192u ? njobs : full < 8192u ? 8192u : full;
 	const uint32_t scan_lanes = (njobs + scan_waves - 1) / scan_waves;
-	hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
-			   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
+	/* one scalar unit serves the four SIMDs of a CU: the scalar walk wins while there are at most ~8 streams per CU
+	 * (17 ms against 30 ms for 1024 streams of 512 K samples; level at ~3000 streams; behind at 8192) */
+	if (njobs <= 2048)
+		hipLaunchKernelGGL(acm_parse_scan_lone, dim3(njobs), dim3(SCAN_THREADS), 0, st,
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
+	else
+		hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
 	ACMP_CHECK();
 	uint64_t gx = (max_columns + COL_THREADS - 1) / COL_THREADS;
 	if (gx < 1)
