@@ -221,13 +221,14 @@ def test_device_parser_every_filler(dev):
 
 
 def test_batch_parse_auto_many_streams(dev):
-    """ACM_BATCH_PARSE_AUTO switches to the device parser from 2048 streams on; tiny streams, a few broken ones"""
+    """ACM_BATCH_PARSE_AUTO switches to the device parser when the batch is worth enough streams per parser thread;
+    tiny streams, a few broken ones"""
     files = [make_stream(7000 + i, 5 + i % 2, 4, 1 + i % 3, channels=1 + i % 2, cut=i % 4) for i in range(2100)]
     files[17] = files[17][:30]
     files[1999] = b"nope"
     auto, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_AUTO)
     assert tm.device_parsed >= 2090 and tm.host_parsed >= 1
-    few, tm2 = capi.batch_decode(dev, files[:100], threads=4, parse=capi.PARSE_AUTO)
+    few, tm2 = capi.batch_decode(dev, files[:20], threads=4, parse=capi.PARSE_AUTO)     # < 9 x threads streams' worth
     assert tm2.device_parsed == 0
     host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
     for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, auto)):
