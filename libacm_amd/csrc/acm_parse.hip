@@ -9,6 +9,8 @@
  *
  *   acm_parse_scan     one LANE per stream walks its stream and writes colpos[block][column] (the bit offset
  *                      of every column's 5-bit code) and the block headers.  Sequential per stream, light.
+ *                      Up to 2048 streams: acm_parse_scan_lone, one stream per WAVEFRONT - then the walk is
+ *                      wave-uniform and runs on the scalar unit (s_load + SALU), ~1.7x faster per stream.
  *   acm_parse_columns  one LANE per COLUMN decodes `rows` indices from its bit offset.  64 adjacent columns
  *                      per wavefront, all lanes produce row r in the same iteration, so every store is a
  *                      contiguous run of the row-major staged form the synthesis kernels read.  Symbols of
