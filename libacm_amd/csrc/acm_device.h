@@ -36,6 +36,17 @@ struct AcmTile {
 #define ACM_TILE_FRESH   1u    /* nothing in front of this tile: the carries start from zero (stream row 0, or a lead-in) */
 #define ACM_TILE_DISCARD 2u    /* lead-in: run the passes to build the carries, store no PCM */
 
+/* one tile of the lean kernel (acm_tile2): tile_rows consecutive rows of a stream decoded from its row 0, all of them
+ * present and emitted.  Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH. */
+struct AcmTile2 {
+	uint64_t idx_off;      /* int16 units: staged index of (tile row 0, column 0) */
+	uint64_t pcm_off;      /* int16 units: where sample (tile row 0, column 0) goes */
+	uint32_t hdr_blk;      /* blkhdr index of the block that holds tile row -2 (tile row 0 in a stream's first tile) */
+	uint32_t rowpos;       /* position of that row inside its block */
+	uint32_t magic;        /* ceil(2^32 / acm_rows); 0 for acm_rows == 1 */
+	uint32_t flags;        /* ACM_TILE_FRESH */
+};
+
 /* resolved H1 patch for the stage-wise path: scratch[dst] = value */
 struct AcmDevPatch {
 	uint64_t dst;
@@ -64,6 +75,9 @@ struct AcmParseResult {
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
 #define ACM_K1_MAX_LEVEL 12
+/* levels the lean tile kernel (acm_tile2) covers */
+#define ACM_K2_MIN_LEVEL 7
+#define ACM_K2_MAX_LEVEL 9
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 
@@ -91,6 +105,10 @@ int acmk_fused_has_carry(uint32_t level, int variant);           /* does a carry
 int acmk_fused_grid(uint32_t level, int variant, int cus);       /* persistent workgroups the launch uses at most */
 int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const AcmDevStream *d_streams, const AcmTile *d_tiles,
 		      uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
+int acmk_tile2_rows(uint32_t level);                            /* rows per acm_tile2 tile, 0 if the level is not covered */
+int acmk_tile2_grid(uint32_t level, int cus);
+int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
+		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);

@@ -57,6 +57,8 @@ struct LevelGroup {
 	AcmTile *d_tiles = nullptr;
 	uint32_t ntiles = 0;
 	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
+	AcmTile2 *d_tiles2 = nullptr;   /* whole tiles of streams decoded from row 0: the lean kernel (acm_tile2) */
+	uint32_t ntiles2 = 0;
 	uint32_t *d_list = nullptr;
 	uint32_t nlist = 0;
 	uint64_t max_elems = 0;     /* stage-wise: longest plane run in the group */
@@ -328,8 +330,10 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		(void)hipStreamSynchronize(plan->dev->stream);
 	}
 	(void)hipFree(plan->d_streams);
-	for (auto &g : plan->fused)
+	for (auto &g : plan->fused) {
 		(void)hipFree(g.d_tiles);
+		(void)hipFree(g.d_tiles2);
+	}
 	for (auto &g : plan->stagewise)
 		(void)hipFree(g.d_list);
 	for (auto &g : plan->small)
@@ -359,7 +363,9 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		has_patch[patches[p].stream] = 1;
 	}
 
-	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16);
+	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16), tiles_rest(16);
+	std::vector<std::vector<AcmTile2>> tiles2(16);
+	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
@@ -400,6 +406,23 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
 			for (uint64_t r = 0; r < emit_rows; r += T)
 				tiles[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), 0u, 0u });
+			/* the lean kernel takes the whole tiles of a stream that is decoded from its row 0; the ragged tail
+			 * (and every other kind of stream) stays with the general kernel, as halo tiles */
+			const uint32_t T2 = (uint32_t)acmk_tile2_rows(s.level);
+			uint64_t rows2 = 0;
+			if (k2_allowed && T2 && s.row_begin == 0) {
+				const uint64_t full_rows = std::min<uint64_t>(s.nrows, s.n_emit >> s.level);
+				rows2 = full_rows / T2 * T2;
+				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
+				for (uint64_t r = 0; r < rows2; r += T2) {
+					const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
+					tiles2[s.level].push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
+									    (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
+									    r == 0 ? ACM_TILE_FRESH : 0u });
+				}
+			}
+			for (uint64_t r = rows2; r < emit_rows; r += T)
+				tiles_rest[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), 0u, 0u });
 			if (acmk_fused_has_carry(s.level, variant)) {
 				/* carry mode: T + 2 payload rows per tile; a stream that does not start at its row 0 gets a
 				 * lead-in tile in front (rows that do not exist count as zeros, which is exact: no output
@@ -450,11 +473,22 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		if (!tiles[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
-					const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
-			g.carry = !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
-			const std::vector<AcmTile> &use = g.carry ? tiles_carry[lv] : tiles[lv];
+			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
+			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
+			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
+			const bool k2 = grid2 && (getenv("ACM_K2") ? !tiles2[lv].empty() : tiles2[lv].size() >= 8 * grid2);
+			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
+			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
 			rc = to_device(dev, use, &g.d_tiles);
+			if (k2 && rc == ACMHIP_OK) {
+				g.ntiles2 = (uint32_t)tiles2[lv].size();
+				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
+				st.tiles += g.ntiles2;
+				st.launches += 1;
+				if (g.ntiles == 0)
+					st.launches -= 1;
+			}
 			pl->fused.push_back(g);
 			st.tiles += g.ntiles;
 			st.launches += 1;
@@ -524,8 +558,10 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		return ACMHIP_ERR_ARG;
 	void *st = (void *)pl->dev->stream;
 
-	for (const LevelGroup &g : pl->fused)
+	for (const LevelGroup &g : pl->fused) {
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, fmt, st));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+	}
 
 	for (const LevelGroup &g : pl->small)
 		LAUNCHTRY(acmk_launch_small(g.level, pl->d_streams, g.d_list, g.nlist, g.max_emit, d_idx, d_hdr, d_pcm, fmt, st));

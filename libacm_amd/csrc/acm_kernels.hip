@@ -252,6 +252,8 @@ struct TileCfg {
 	static constexpr int COLS = 1 << L_;
 	static constexpr int TR = NELEM_ / COLS;          // tile rows incl. the 2 halo rows
 	static constexpr int NJ_LAST = NELEM_ / NT_;      // samples per thread in the last pass
+	static constexpr int PS = NJ_LAST >= 64 ? 6 : 5;  // LDS pad: one dword per 2^PS elements (= one last-pass walk)
+	static_assert(NJ_LAST == 64 || NJ_LAST == 32 || NJ_LAST == 128, "walk length of the last pass");
 	static_assert(TR >= 4 && (TR % 2) == 0, "tile must hold the halo and at least two payload rows");
 };
 
@@ -264,9 +266,13 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	if constexpr (EXACT32) {
 		return t - (z << 1);
 	} else {
+#ifdef ACM_NO_ASM
+		return (uint32_t)(__mul24((int32_t)z, -2) + (int32_t)t);
+#else
 		int32_t y;
 		asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(y) : "v"((int32_t)z), "v"((int32_t)t));
 		return (uint32_t)y;
+#endif
 	}
 }
 
@@ -277,6 +283,11 @@ __device__ __forceinline__ uint32_t mul_idx_val(uint32_t loaded, int32_t val, in
 {
 	/* SDWA: operand 0 = one sign-extended 16-bit word of the loaded register (low word, or either word of a
 	 * 4-byte load holding two adjacent columns), so no extraction / extension op is needed */
+#ifdef ACM_NO_ASM
+	if (PAIR && word == 1)
+		return (uint32_t)__mul24((int32_t)loaded >> 16, val);
+	return (uint32_t)__mul24((int32_t)(int16_t)(uint16_t)loaded, val);
+#endif
 	uint32_t y;
 	if (PAIR && word == 1)
 		asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
@@ -287,9 +298,28 @@ __device__ __forceinline__ uint32_t mul_idx_val(uint32_t loaded, int32_t val, in
 	return y;
 }
 
+/* four loaded registers (two adjacent columns each) -> eight values, as ONE asm statement: the compiler puts an s_nop
+ * between an asm statement and a VALU op that reads its result (it cannot see that the destination is a whole dword),
+ * and every instruction, s_nop included, costs a SIMD ~3 cycles of issue */
+__device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t r1, const uint32_t r2, const uint32_t r3, const int32_t val,
+					       uint32_t (&lo)[4], uint32_t (&hi)[4])
+{
+#define ACM_SDWA_MUL(D, S, WORD) "v_mul_i32_i24_sdwa " D ", sext(" S "), %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WORD " src1_sel:DWORD\n\t"
+	asm(ACM_SDWA_MUL("%0", "%8", "WORD_0") ACM_SDWA_MUL("%1", "%8", "WORD_1")
+	    ACM_SDWA_MUL("%2", "%9", "WORD_0") ACM_SDWA_MUL("%3", "%9", "WORD_1")
+	    ACM_SDWA_MUL("%4", "%10", "WORD_0") ACM_SDWA_MUL("%5", "%10", "WORD_1")
+	    ACM_SDWA_MUL("%6", "%11", "WORD_0") ACM_SDWA_MUL("%7", "%11", "WORD_1")
+	    : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+	    : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(val));
+#undef ACM_SDWA_MUL
+}
+
 /* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
 __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
+#ifdef ACM_NO_ASM
+	return t + (z << 1);
+#endif
 	uint32_t y;
 	asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(y) : "v"(z), "v"(t));
 	return y;
@@ -317,7 +347,8 @@ struct StageKind {
  * sigma < 64 touches 64/sigma walk segments whose starts are 64*sigma apart -
  * all on the same banks without the pad, rotated by sigma banks each with it.
  */
-__device__ __forceinline__ int lds_at(int m) { return m + (m >> 6); }
+template <int PS = 6>
+__device__ __forceinline__ int lds_at(int m) { return m + (m >> PS); }
 
 /*
  * Write-out without per-sample shifts where possible.  The whole cascade is linear mod 2^32 and only bits
@@ -389,7 +420,7 @@ struct PassGeo {
 	static_assert(NJ % BODY == 0 && NJ >= BODY, "segment must be whole bodies");
 	/* LDS offset of walk element u relative to the body's first element (which is
 	 * aligned to BODY*SIGMA, and 64 | BODY*SIGMA or BODY*SIGMA | 64) */
-	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> 6); }
+	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> C::PS); }
 };
 
 /*
@@ -490,7 +521,7 @@ struct FirstPass {
 	static_assert(SIGMA % W == 0 && TPS <= NT && NT % TPS == 0, "segment geometry");
 	static_assert(RPS >= 2 && RPS % 2 == 0 && NSEG * RPS == C::TR, "segments are whole row pairs");
 	/* LDS offset of the residue's q-th column / second row relative to (first row, first column) of the body */
-	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> 6); }
+	static constexpr int off(int u) { return u * SIGMA + ((u * SIGMA) >> C::PS); }
 
 	/* every staged index of this thread's walk, issued back to back (one HBM round trip): 2-byte loads for
 	 * W = 1, 4-byte loads (two adjacent columns) for W = 2.  Rows that do not exist are read from a clamped
@@ -560,18 +591,33 @@ struct FirstPass {
 			const uint32_t b0 = (i0 == 0 && lr0 >= LR_MIN && row_first + lr0 >= 0) ? ONE : 0u;
 			const uint32_t b1 = (i0 == 0 && lr0 + 1 >= LR_MIN && row_first + lr0 + 1 >= 0) ? ONE : 0u;
 			uint32_t v[W][BODY];
+			if constexpr (W == 2 && U % 4 == 0) {
 #pragma unroll
-			for (int w = 0; w < W; w++) {
+				for (int u = 0; u < BODY; u += 4) {
+					const uint32_t *r = &raw[(b + (WARM ? 1 : 0)) * BODY + u];
+					uint32_t lo[4], hi[4];
+					mul_idx_val_x4(r[0], r[1], r[2], r[3], u < U ? v0 : v1, lo, hi);
 #pragma unroll
-				for (int u = 0; u < BODY; u++)
-					v[w][u] = mul_idx_val<W == 2>(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1, w);
+					for (int k = 0; k < 4; k++) {
+						v[0][u + k] = lo[k];
+						v[W - 1][u + k] = hi[k];
+					}
+				}
+			} else {
+#pragma unroll
+				for (int w = 0; w < W; w++)
+#pragma unroll
+					for (int u = 0; u < BODY; u++)
+						v[w][u] = mul_idx_val<W == 2>(raw[(b + (WARM ? 1 : 0)) * BODY + u], u < U ? v0 : v1, w);
+			}
+#pragma unroll
+			for (int w = 0; w < W; w++)
 				if (!(ABL & 4))
 					pass_body<L, 0, G>(v[w], h[w], w == 0 ? b0 : 0u, w == 0 ? b1 : 0u);
-			}
 			if (b >= 0) {
 				/* rows of a segment start on a multiple of 64 elements: body b sits at a constant offset */
 				static_assert((2 * COLS) % 64 == 0 && (RPS * COLS) % 64 == 0, "row pairs are whole 64-element groups");
-				uint32_t *o = tile + lds_at(lr_seg * COLS + i0) + b * (2 * COLS + 2 * COLS / 64);
+				uint32_t *o = tile + lds_at<C::PS>(lr_seg * COLS + i0) + b * (2 * COLS + ((2 * COLS) >> C::PS));
 #pragma unroll
 				for (int u = 0; u < BODY; u++)
 #pragma unroll
@@ -589,7 +635,7 @@ struct FirstPass {
  * consumed) segment: sample e of thread `tid` -> dword lds_at(tid*NJ) + e/2.
  */
 /* padded size of a carry buffer holding the BS elements in front of a tile (same pad rule as P::off) */
-constexpr int carry_words(int bs) { return bs + bs / 64 + 2; }
+constexpr int carry_words(int bs, int ps = 6) { return bs + (bs >> ps) + 2; }
 
 template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true, bool BIGEND = true, bool CARRY = false>
 __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt, uint32_t *carry = nullptr)
@@ -605,14 +651,15 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	const PcmFmt pf = make_pcm_fmt<L>(fmt);
 	/* one runtime address per thread; every body of the walk (and the warm-up body in front of it) sits at a
 	 * compile-time offset from it: NJ*SIGMA is a multiple of 64 and bodies never straddle a pad dword */
-	uint32_t *const base = tile + lds_at(m_seg);
+	constexpr int PS = C::PS, PG = 1 << PS;
+	uint32_t *const base = tile + lds_at<PS>(m_seg);
 	constexpr int BS = BODY * SIGMA;
-	constexpr bool ALIGNED = (P::NJ * SIGMA) % 64 == 0;     // segments start on a 64-element group (not so for 32-sample walks at stride 1)
+	constexpr bool ALIGNED = (P::NJ * SIGMA) % PG == 0;     // segments start on a pad group
 	auto body_ptr = [&](int it) -> uint32_t * {
 		if constexpr (ALIGNED)
-			return base + (it * BS + ((it * BS) >> 6));
+			return base + (it * BS + ((it * BS) >> PS));
 		else
-			return tile + lds_at(m_seg + it * BS);
+			return tile + lds_at<PS>(m_seg + it * BS);
 	};
 	uint32_t h[G][U];
 	clear_hist<G>(h);
@@ -627,7 +674,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	constexpr int NTAIL = CARRY ? (BS + C::NT - 1) / C::NT : 1;     /* carried elements per thread (1 for every default geometry) */
 	uint32_t tail[NTAIL];
 	{
-		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= 64 ? BS / 64 : 1)) : tile + lds_at(m_seg - BS);
+		const uint32_t *pw = ALIGNED ? base - (BS + (BS >= PG ? BS / PG : 1)) : tile + lds_at<PS>(m_seg - BS);
 		if constexpr (CARRY) {
 			/* segment 0's history is what the previous tile of this stream left behind: the last BS elements
 			 * of its input to this pass, kept in `carry` with the same pad rule (element j at j + off-pad) */
@@ -636,7 +683,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 #pragma unroll
 			for (int k = 0; k < NTAIL; k++) {
 				const int j = tid + k * C::NT;
-				tail[k] = (j < BS) ? tile[lds_at(C::NELEM - BS + j)] : 0u;      /* this tile's bequest, read before it is overwritten */
+				tail[k] = (j < BS) ? tile[lds_at<PS>(C::NELEM - BS + j)] : 0u;      /* this tile's bequest, read before it is overwritten */
 			}
 		}
 #pragma unroll
@@ -650,7 +697,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 		for (int k = 0; k < NTAIL; k++) {
 			const int j = tid + k * C::NT;
 			if (j < BS)
-				carry[j + (((j / SIGMA) * SIGMA) >> 6)] = tail[k];     /* next read: this pass of the next tile */
+				carry[j + (((j / SIGMA) * SIGMA) >> PS)] = tail[k];     /* next read: this pass of the next tile */
 		}
 	}
 
@@ -715,7 +762,7 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
 {
 	constexpr bool last = sizeof...(Rest) == 0;
 	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
-	static_assert(!CARRY || carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA) <= CW, "carry buffer too small");
+	static_assert(!CARRY || carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA, C::PS) <= CW, "carry buffer too small");
 	uint32_t *cb = CARRY ? carry[0] : nullptr;
 	if constexpr (!last) {
 		lds_pass<C, K0, G, false, ABL, true, true, CARRY>(tile, tid, fmt, cb);
@@ -746,13 +793,13 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	using FP = FirstPass<C, G0, W0, ABL>;
 
 	constexpr int GUARD = NELEM / 32 + 64;                  // zeros in front of the tile: segment 0's warm-up reads land here
-	__shared__ uint32_t tile_mem[GUARD + NELEM + NELEM / 64];
+	__shared__ uint32_t tile_mem[GUARD + NELEM + (NELEM >> C::PS)];
 	__shared__ int32_t rowval[2][TR + 2];                   // [buf][lr + 2]; two leading zeros for segment 0's warm-up
 	uint32_t *const tile = tile_mem + GUARD;
 	/* carry mode: per LDS pass, the tail of the previous tile's input to that pass (the first LDS pass has the
 	 * widest: two bodies of its smallest stride) */
 	constexpr int NCARRY = CARRY ? (int)sizeof...(Gs) : 1;
-	constexpr int CW = CARRY ? carry_words(2 * (COLS >> G0)) : 1;
+	constexpr int CW = CARRY ? carry_words(2 * (COLS >> G0), C::PS) : 1;
 	__shared__ uint32_t carry_mem[NCARRY][CW];
 	/* payload rows of a tile: all of them in carry mode, all but the two halo rows otherwise */
 	constexpr int HALO = CARRY ? 0 : 2;
@@ -877,7 +924,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 					if (k < NVEC / NT || vec < NVEC) {      /* only the last round can be partial */
 						const int owner = (HALO * COLS / 8 + vec) / PER_OWNER;
 						const int piece = (HALO * COLS / 8 + vec) % PER_OWNER;
-						const uint32_t *q = tile + lds_at(owner * NJ_LAST) + piece * 4;
+						const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + piece * 4;
 						uint4 o;
 						o.x = q[0];
 						o.y = q[1];
@@ -899,7 +946,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 					if (g >= cur.n_emit)
 						break;
 					const int owner = ml / NJ_LAST;
-					const uint32_t *q = tile + lds_at(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
+					const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
 					const uint32_t w[4] = { q[0], q[1], q[2], q[3] };
 					if (g + 8 <= cur.n_emit) {
 						*reinterpret_cast<uint4 *>(cur.dst + g) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -962,9 +1009,9 @@ constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, fal
 #endif
 
 #ifdef ACM_ABLATION
-constexpr int NVARIANTS = 19;
+constexpr int NVARIANTS = 20;
 #else
-constexpr int NVARIANTS = 9;
+constexpr int NVARIANTS = 10;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
@@ -1048,6 +1095,16 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2<TileCfg<9, 128, 16384>, 1, 3, 3, 3>(),
 		entry2<TileCfg<10, 128, 16384>, 1, 3, 3, 4>(),
 		entry2<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
+	},
+	{	/* variant 9: 32 KB tiles, four workgroups per CU (4 waves per SIMD), carry mode */
+		entry2c<TileCfg<5, 128, 8192>, 2, 2, 3>(),
+		entry2c<TileCfg<6, 256, 8192>, 4, 2, 2, 2>(),
+		entry2c<TileCfg<7, 256, 8192>, 4, 2, 2, 3>(),
+		entry2c<TileCfg<8, 256, 8192>, 4, 3, 3, 2>(),
+		entry2c<TileCfg<9, 256, 8192>, 4, 3, 3, 3>(),
+		entry2c<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
+		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
+		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
 	},
 #ifdef ACM_ABLATION
 	{	/* timing only: default geometry without the barriers inside the LDS passes */
@@ -1141,6 +1198,172 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
 	},
 #endif
+};
+
+
+// ---------------------------------------------------------------------------
+// K2: the lean tile kernel for the bulk of a batch
+// ---------------------------------------------------------------------------
+/*
+ * Same passes as acm_fused_tile in carry mode, for the tiles that need no special handling: every tile row exists,
+ * every payload sample is emitted, the stream is decoded from its row 0 (AcmTile2 records, cut by the planner;
+ * whatever is left - the ragged tail of a stream, windows that start inside a stream - goes to acm_fused_tile).
+ * Measured on gfx950 (profiles/ubench/issue_model.hip): a SIMD issues ONE instruction at a time whatever its kind
+ * (simple VALU 2.25 cycles, other VALU 4.2, LDS 5-6.5, SALU / s_waitcnt / s_nop ~3, global_load_dword 6.6, with four
+ * waves per SIMD), so the tile loop is written for instruction count: 32 KB tiles at four workgroups per CU, all
+ * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
+ */
+template <class C, int G, int W>
+struct FirstPass2 : FirstPass<C, G, W, 0> {
+	using FP = FirstPass<C, G, W, 0>;
+	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
+	static_assert(FP::WARM, "K2 geometry: every segment re-runs the two rows in front of it");
+	/* byte offset of this thread's first staged index relative to tile row -2 */
+	static __device__ __forceinline__ uint32_t lane_offset(const int tid)
+	{
+		const int seg = tid / FP::TPS, i0 = (tid % FP::TPS) * W;
+		return (uint32_t)((seg * FP::RPS * COLS + i0) * 2);
+	}
+	/* base = staged index of (tile row -2, column 0); voff_warm = voff except for segment 0 of a stream's first tile,
+	 * whose two rows in front do not exist (they are read from rows 0..1 instead and weigh 0) */
+	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	{
+#pragma unroll
+		for (int b = -1; b < NB; b++)
+#pragma unroll
+			for (int half = 0; half < 2; half++)
+#pragma unroll
+				for (int q = 0; q < U; q++) {
+					const uint32_t imm = (uint32_t)((((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2);
+					const uint8_t *p = base + (size_t)((b < 0 ? voff_warm : voff) + imm);
+					raw[(b + 1) * BODY + half * U + q] = (W == 1) ? (uint32_t)*reinterpret_cast<const uint16_t *>(p)
+										       : *reinterpret_cast<const uint32_t *>(p);
+				}
+	}
+};
+
+template <class C, int G0, int... Gs>
+__global__ void __launch_bounds__(C::NT, 1024 / C::NT)
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
+	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, const unsigned fmt)
+{
+	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
+	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
+	using FP = FirstPass2<C, G0, 2>;
+	static_assert(TR + 2 <= NT, "one row value per thread");
+
+	__shared__ uint32_t tile_mem[8 + NELEM + (NELEM >> C::PS)];     /* no guard zone: segment 0 always reads the carry */
+	__shared__ int32_t rowval[2][TR + 2];
+	constexpr int NCARRY = (int)sizeof...(Gs);
+	constexpr int CW = carry_words(2 * (COLS >> G0), C::PS);
+	__shared__ uint32_t carry_mem[NCARRY][CW];
+	uint32_t *const tile = tile_mem + 8;
+
+	const int tid = threadIdx.x;
+	const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+	uint32_t t = blockIdx.x * per;
+	const uint32_t t_end = t + per < ntiles ? t + per : ntiles;
+	if (t >= t_end)
+		return;
+	/* a run that starts inside a stream first replays the tile in front of it without storing PCM */
+	bool discard = false;
+	if (!(tiles[t].flags & ACM_TILE_FRESH)) {
+		discard = true;
+		t--;
+	}
+
+	const uint32_t voff = FP::lane_offset(tid);
+	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
+	constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
+
+	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589) */
+	auto fetch_val = [&](const AcmTile2 &r) -> int32_t {
+		int32_t v = 0;
+		const bool fr = (r.flags & ACM_TILE_FRESH) != 0;                 /* no rows in front of the stream: they weigh 0 */
+		if (tid < TR + 2 && !(fr && tid < 2)) {
+			const uint32_t q = r.rowpos + (uint32_t)tid - (fr ? 2u : 0u);     /* rows counted from the record's reference row */
+			const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;     /* q / acm_rows (magic = ceil(2^32 / rows), 0 for rows == 1) */
+			v = (int32_t)hdr[r.hdr_blk + b].val;
+			v = (int32_t)((uint32_t)v << OutScale<L>::SHIFT);
+			if (NEG_ODD_ROWS && (tid & 1))
+				v = -v;
+		}
+		return v;
+	};
+	auto idx_base = [&](const AcmTile2 &r) -> const uint8_t * {
+		return reinterpret_cast<const uint8_t *>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
+	};
+	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
+		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
+	};
+
+	AcmTile2 cur = tiles[t];
+	uint32_t raw[FP::NRAW];
+	int32_t hv = fetch_val(cur);
+	FP::load(raw, idx_base(cur), voff, warm_off(cur));
+	if (tid < TR + 2)
+		rowval[0][tid] = hv;
+	int buf = 0;
+	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
+
+	for (;;) {
+		if (fresh)
+			for (int k = tid; k < NCARRY * CW; k += NT)
+				(&carry_mem[0][0])[k] = 0u;
+		__syncthreads();
+		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
+		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+
+		const uint32_t tn = t + 1;
+		const bool more = tn < t_end;
+		AcmTile2 nxt = cur;
+		if (more) {
+			nxt = tiles[tn];
+			hv = fetch_val(nxt);
+			FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
+		}
+
+		run_lds_passes<C, 0, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+		__syncthreads();
+
+		if (!discard) {
+			constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8;
+			static_assert(NVEC % NT == 0, "whole rounds");
+			uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
+#pragma unroll
+			for (int k = 0; k < NVEC / NT; k++) {
+				const int vec = tid + k * NT;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				uint4 o;
+				o.x = q[0];
+				o.y = q[1];
+				o.z = q[2];
+				o.w = q[3];
+				out[vec] = o;
+			}
+		}
+		if (!more)
+			break;
+		if (tid < TR + 2)
+			rowval[buf ^ 1][tid] = hv;
+		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
+		discard = false;
+		cur = nxt;
+		t = tn;
+		buf ^= 1;
+	}
+}
+
+struct Tile2Entry {
+	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
+	int threads, tile_rows, wg_per_cu;
+};
+template <class C, int... Gs>
+constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
+	entry_k2<TileCfg<7, 256, 8192>, 2, 2, 3>(),
+	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
+	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
 };
 
 inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
@@ -1276,5 +1499,35 @@ extern "C" int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d
 				   d_streams, d_list + at, d_x, d_pcm, fmt);
 		ACMK_CHECK_LAUNCH();
 	}
+	return 0;
+}
+
+extern "C" int acmk_tile2_rows(uint32_t level)
+{
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return 0;
+	return g_tile2[level - ACM_K2_MIN_LEVEL].tile_rows;
+}
+
+extern "C" int acmk_tile2_grid(uint32_t level, int cus)
+{
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return 0;
+	return (cus > 0 ? cus : 256) * g_tile2[level - ACM_K2_MIN_LEVEL].wg_per_cu;
+}
+
+extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
+				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream)
+{
+	if (ntiles == 0)
+		return 0;
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return -1;
+	const Tile2Entry &e = g_tile2[level - ACM_K2_MIN_LEVEL];
+	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
+	if (grid > ntiles)
+		grid = ntiles;
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, fmt);
+	ACMK_CHECK_LAUNCH();
 	return 0;
 }

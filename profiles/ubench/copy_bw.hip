@@ -23,6 +23,20 @@ __global__ void __launch_bounds__(256) write_only(const uint4 *__restrict__ src,
   const uint4 v = {1, 2, 3, 4};
   for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
 }
+/* the tile kernel's shape: 1024 workgroups, each streaming through its own contiguous region in 16 KB steps */
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <int NT_LOAD, int NT_STORE>
+__global__ void __launch_bounds__(256) copy_runs(const uint4 *__restrict__ src_, uint4 *__restrict__ dst_, size_t n) {
+  const size_t per = n / gridDim.x;
+  const v4u *s = reinterpret_cast<const v4u *>(src_) + blockIdx.x * per; v4u *d = reinterpret_cast<v4u *>(dst_) + blockIdx.x * per;
+  for (size_t i = threadIdx.x; i + 768 < per; i += 1024) {
+    v4u v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = NT_LOAD ? __builtin_nontemporal_load(&s[i + 256 * k]) : s[i + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (NT_STORE) __builtin_nontemporal_store(v[k], &d[i + 256 * k]); else d[i + 256 * k] = v[k]; }
+  }
+}
 int main() {
   const size_t bytes = 4ull << 30, n = bytes / 16;
   uint4 *a, *b; (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
@@ -39,6 +53,13 @@ int main() {
     timeit(nm, [&]() { hipLaunchKernelGGL(copy_persist, dim3(g), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
     snprintf(nm, sizeof nm, "copy unroll4, %d WGs (r+w)", g);
     timeit(nm, [&]() { hipLaunchKernelGGL(copy_unroll4, dim3(g), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  }
+  for (int rep = 0; rep < 2; rep++) {
+  timeit("contiguous runs, 1024 WGs (r+w)", [&]() { hipLaunchKernelGGL((copy_runs<0, 0>), dim3(1024), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  timeit("contiguous runs, nt loads", [&]() { hipLaunchKernelGGL((copy_runs<1, 0>), dim3(1024), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  timeit("contiguous runs, nt stores", [&]() { hipLaunchKernelGGL((copy_runs<0, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  timeit("contiguous runs, nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
+  timeit("contiguous runs, 2048 WGs nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(2048), dim3(256), 0, 0, a, b, n); }, 2.0 * bytes);
   }
   timeit("read only, 2048 WGs", [&]() { hipLaunchKernelGGL(read_only, dim3(2048), dim3(256), 0, 0, a, b, n); }, 1.0 * bytes);
   timeit("write only, 2048 WGs", [&]() { hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, a, b, n); }, 1.0 * bytes);
