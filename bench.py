@@ -52,6 +52,7 @@ def parse_args():
                     help="uniform = BASELINE configs[1]-style batch (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
     ap.add_argument("--files", type=int, default=4000)
+    ap.add_argument("--no-verify", action="store_true", help="timing experiments with deliberately wrong kernels: skip the oracle check (the line says so)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank - exercises the N>1 code path on a 1-GPU box")
     return ap.parse_args()
@@ -217,7 +218,7 @@ def main():
     # and repeated launches over the same resident input must keep producing exactly that (idempotence: the hot
     # path carries no state between launches; also catches races)
     verified = None
-    if batch.files:
+    if batch.files and not args.no_verify:
         try:
             import oracle_api as O
             nchk = min(4, len(batch.files))

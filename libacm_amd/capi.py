@@ -95,7 +95,7 @@ def lib():
         import torch  # noqa: F401
     except Exception:
         pass
-    path = _build.build_hip()
+    path = os.environ.get("ACM_HIP_LIB") or _build.build_hip()      # ACM_HIP_LIB: A/B runs of experimental builds
     L = C.CDLL(path)
     vp, sz = C.c_void_p, C.c_size_t
     L.acmhip_last_error.restype = C.c_char_p

@@ -75,8 +75,8 @@ struct AcmParseResult {
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
 #define ACM_K1_MIN_LEVEL 5
 #define ACM_K1_MAX_LEVEL 12
-/* levels the lean tile kernel (acm_tile2) covers */
-#define ACM_K2_MIN_LEVEL 7
+/* levels the lean tile kernel (acm_tile2) covers (measured: 32 KB tiles lose to the 64-128 KB tiles of acm_fused_tile from level 10 on) */
+#define ACM_K2_MIN_LEVEL 6
 #define ACM_K2_MAX_LEVEL 9
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4

@@ -583,8 +583,13 @@ struct FirstPass {
 		/* the loads were issued a whole tile ago: touching the YOUNGEST one first makes the compiler emit a
 		 * single s_waitcnt vmcnt for all of them instead of one per consumer */
 		asm volatile("" :: "v"(raw[NRAW - 1]));
+#ifdef ACM_EXP_NOWARM
+#define ACM_WARM_FROM 0
+#else
+#define ACM_WARM_FROM (WARM ? -1 : 0)
+#endif
 #pragma unroll
-		for (int b = (WARM ? -1 : 0); b < NB; b++) {
+		for (int b = ACM_WARM_FROM; b < NB; b++) {
 			const int lr0 = lr_seg + 2 * b;
 			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
@@ -1217,6 +1222,7 @@ template <class C, int G, int W>
 struct FirstPass2 : FirstPass<C, G, W, 0> {
 	using FP = FirstPass<C, G, W, 0>;
 	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
+	static constexpr bool WARM = FP::WARM;
 	static_assert(FP::WARM, "K2 geometry: every segment re-runs the two rows in front of it");
 	/* byte offset of this thread's first staged index relative to tile row -2 */
 	static __device__ __forceinline__ uint32_t lane_offset(const int tid)
@@ -1229,21 +1235,26 @@ struct FirstPass2 : FirstPass<C, G, W, 0> {
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 #pragma unroll
-		for (int b = -1; b < NB; b++)
+		for (int b = ACM_WARM_FROM; b < NB; b++)
 #pragma unroll
 			for (int half = 0; half < 2; half++)
 #pragma unroll
 				for (int q = 0; q < U; q++) {
 					const uint32_t imm = (uint32_t)((((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2);
 					const uint8_t *p = base + (size_t)((b < 0 ? voff_warm : voff) + imm);
+#ifdef ACM_K2_NT_LOADS
+					raw[(b + 1) * BODY + half * U + q] = (W == 1) ? (uint32_t)*reinterpret_cast<const uint16_t *>(p)
+										       : __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+#else
 					raw[(b + 1) * BODY + half * U + q] = (W == 1) ? (uint32_t)*reinterpret_cast<const uint16_t *>(p)
 										       : *reinterpret_cast<const uint32_t *>(p);
+#endif
 				}
 	}
 };
 
 template <class C, int G0, int... Gs>
-__global__ void __launch_bounds__(C::NT, 1024 / C::NT)
+__global__ void __launch_bounds__(C::NT, 4)
 acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, const unsigned fmt)
 {
@@ -1329,17 +1340,18 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		if (!discard) {
 			constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8;
 			static_assert(NVEC % NT == 0, "whole rounds");
-			uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
+			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+			v4u *out = reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
 #pragma unroll
 			for (int k = 0; k < NVEC / NT; k++) {
 				const int vec = tid + k * NT;
 				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
-				uint4 o;
-				o.x = q[0];
-				o.y = q[1];
-				o.z = q[2];
-				o.w = q[3];
+				const v4u o = { q[0], q[1], q[2], q[3] };
+#ifdef ACM_K2_PLAIN_STORES
 				out[vec] = o;
+#else
+				__builtin_nontemporal_store(o, &out[vec]);      /* PCM is written once and never read back here */
+#endif
 			}
 		}
 		if (!more)
@@ -1361,6 +1373,7 @@ struct Tile2Entry {
 template <class C, int... Gs>
 constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
+	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
 	entry_k2<TileCfg<7, 256, 8192>, 2, 2, 3>(),
 	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
 	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),

@@ -13,7 +13,7 @@ sys.path.insert(0, %r)
 from libacm_amd import capi, workload
 dev = capi.Device(0)
 out = {}
-for level, rows, blocks in ((5, 16, 4000), (6, 16, 2000), (7, 16, 1000), (8, 16, 500), (9, 16, 250), (10, 16, 125), (11, 64, 16)):
+for level, rows, blocks in ((5, 16, 4000), (6, 16, 2000), (7, 16, 1000), (8, 16, 500), (9, 16, 250), (10, 16, 125), (11, 64, 16), (12, 64, 8)):
     b = workload.build_uniform(int(sys.argv[1]), level, rows, blocks, seed0=level << 12)
     bufs = b.upload(dev)
     plan = capi.Plan(dev, b.descs)
@@ -38,7 +38,7 @@ for v in variants:
         rows[v] = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception:
         rows[v] = {}
-levels = [5, 6, 7, 8, 9, 10, 11]
+levels = [5, 6, 7, 8, 9, 10, 11, 12]
 print("Gsamples/s   " + "".join("L%-8d" % l for l in levels))
 for v, d in rows.items():
     print("variant %d    " % v + "".join("%-9s" % d.get(str(l), "-") for l in levels))

@@ -46,7 +46,7 @@ def force_k2(monkeypatch):
     monkeypatch.setenv("ACM_K2", "1")
 
 
-@pytest.mark.parametrize("level", [7, 8, 9])
+@pytest.mark.parametrize("level", [6, 7, 8, 9])
 @pytest.mark.parametrize("rows", [1, 3, 16, 17, 64, 700])
 def test_lean_tile_kernel_matrix(dev, force_k2, level, rows):
     """acm_tile2 (whole tiles of streams decoded from row 0) + the general kernel on the ragged tail, against the oracle:
@@ -63,7 +63,7 @@ def test_lean_tile_kernel_batch(dev, force_k2, fmt):
     """many streams in one plan: workgroups start inside streams (lead-in tiles) and cross stream boundaries"""
     files = []
     for i in range(37):
-        lv = 7 + i % 3
+        lv = 6 + i % 4
         rows = [16, 5, 33, 1][i % 4]
         files.append(make_stream(5000 + i, lv, rows, 2 + (i * 5) % 11 + ((8192 >> lv) * (1 + i % 3)) // rows,
                                  channels=1 + i % 2, cut=i % 3, val_max=65535 if i % 5 == 0 else 255, pwr_max=15 if i % 5 == 0 else 12))
