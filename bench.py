@@ -4,25 +4,37 @@
 One "step" = one pass of the hot path (amplitude-table unpack -> juggle_block
 synthesis -> 16-bit write-out: one acmhip_plan_launch) over one batch of
 synthetic ACM streams whose staged form is already resident in HBM.  Default
-workload = BASELINE.json configs[1]: 1024 mono streams, acm_level 7, acm_rows
-16, 1000 blocks each (2.097 Gsamples per GPU per step).  With --gpus N every
+workload = the configuration BASELINE.json's north_star quotes its target on:
+1024 mono streams, acm_level 9, acm_rows 16, 250 blocks each (2.097 Gsamples
+per GPU per step; the same sample count as configs[1], which is reported
+beside it under `other_levels_kernel_only`).
+
+`--gpus N` without a torchrun environment starts N fresh ranks itself (one
+process per GPU, before anything in this process touches a GPU); under
+`python -m torch.distributed.run` the ranks come from RANK / WORLD_SIZE.  Every
 rank decodes its own 1024 streams (independent streams: no data-path
 collective, weak scaling); `value` is the whole-job Msamples/s.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) including
-  roofline     - achieved algorithmic HBM GB/s of the fused kernel
+  roofline     - achieved algorithmic HBM GB/s of the tile kernel
                  (4 B/sample: 2 B staged index in + 2 B PCM out) against 8 TB/s,
                  from HIP events recorded on the launch stream
   cpu_baseline - the same decode on the host cores (the real reference if the
                  prebuilt oracle/_ref is present, else our oracle port), on a
                  bounded sample of the same workload, rank 0 / N=1 only.
+Every stream of the workload is compared with the CPU oracle (CRC of its PCM)
+before the warm-up and again after the timed region.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,35 +44,82 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 4   # 2 B idx16 read + 2 B PCM16 written
+PRECONDITION_S = 0.5        # untimed launches in front of the warm-up (clock ramp), whatever --warmup says
+SUSTAINED_STEPS = 300       # the long run reported beside the contract's K steps when K is short
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams", type=int, default=1024)
-    ap.add_argument("--level", type=int, default=7)
+    ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--rows", type=int, default=16)
-    ap.add_argument("--blocks", type=int, default=1000)
+    ap.add_argument("--blocks", type=int, default=250)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the level-9/level-11 side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other levels, D2D copy rate, end to end)")
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
     ap.add_argument("--workload", choices=["uniform", "corpus"], default="uniform",
-                    help="uniform = BASELINE configs[1]-style batch (default); corpus = configs[2]: --files mixed "
+                    help="uniform = one shape for every stream (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
     ap.add_argument("--files", type=int, default=4000)
-    ap.add_argument("--no-verify", action="store_true", help="timing experiments with deliberately wrong kernels: skip the oracle check (the line says so)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="timing experiments with deliberately wrong kernels: skip the oracle check (the line says so)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the PCM gather leg (C2) that is reported beside the headline")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank - exercises the N>1 code path on a 1-GPU box")
     return ap.parse_args()
 
 
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (this process never touches a GPU)."""
+    n = args.gpus
+    have = visible_gpus()
+    if have < n:
+        raise SystemExit("bench.py: %d GPUs requested, %d visible" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
+def pin_rank_cpus(local, local_world):
+    """Ranks of one node share the host: give each an equal slice of the usable CPUs (parser / staging threads
+    stay next to their GPU's copy engine instead of migrating over the whole box)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        if local_world > 1 and len(cpus) >= local_world:
+            per = len(cpus) // local_world
+            os.sched_setaffinity(0, cpus[local * per:(local + 1) * per])
+    except (AttributeError, OSError):
+        pass
+
+
 def workload_cpus():
     from libacm_amd import workload
     return workload.usable_cpus()
+
+
+def kernel_source_sha():
+    with open(os.path.join(ROOT, "libacm_amd", "csrc", "acm_kernels.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def cpu_baseline(batch, budget_s):
@@ -140,6 +199,46 @@ def cpu_baseline(batch, budget_s):
     }
 
 
+def oracle_crcs(batch, threads):
+    """CRC-32 of every stream's PCM as the CPU oracle decodes it (the checker; untimed setup)."""
+    import oracle_api as O
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(k):
+        pcm = O.Oracle.decode_all(batch.files[k].tobytes())[0]
+        return zlib.crc32(pcm.view(np.uint8)[:2 * batch.descs[k].n_emit])
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(one, range(len(batch.files))))
+
+
+def device_crcs(dev, batch, d_pcm, threads):
+    """CRC-32 of every stream's PCM as it sits in HBM (downloaded in slices of whole streams)."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = [0] * len(batch.descs)
+    order = sorted(range(len(batch.descs)), key=lambda k: batch.descs[k].pcm_off)
+    slab_words = 1 << 28
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        i = 0
+        while i < len(order):
+            lo = batch.descs[order[i]].pcm_off
+            j = i
+            while j < len(order) and batch.descs[order[j]].pcm_off + batch.descs[order[j]].n_emit - lo <= slab_words:
+                j += 1
+            j = max(j, i + 1)
+            hi = batch.descs[order[j - 1]].pcm_off + batch.descs[order[j - 1]].n_emit
+            host = np.empty(hi - lo, dtype=np.uint16)
+            dev.download(host, d_pcm + 2 * lo)
+            raw = host.view(np.uint8)
+
+            def one(k):
+                d = batch.descs[k]
+                return k, zlib.crc32(raw[2 * (d.pcm_off - lo): 2 * (d.pcm_off - lo + d.n_emit)])
+            for k, c in ex.map(one, order[i:j]):
+                out[k] = c
+            i = j
+    return out
+
+
 def time_plan(dev, plan, bufs, steps, warmup, barrier):
     """W warm-up + K timed launches; returns (wall seconds incl. sync brackets, device ms from HIP events)."""
     d_idx, d_hdr, d_pcm = bufs
@@ -154,31 +253,58 @@ def time_plan(dev, plan, bufs, steps, warmup, barrier):
     return time.perf_counter() - t0, ev_ms
 
 
+def precondition(dev, plan, bufs, seconds):
+    """untimed launches until `seconds` have passed (the chip reaches the clock it holds under this load)"""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            plan.launch(*bufs)
+        dev.sync()
+        n += 10
+    return n
+
+
 def side_measure(dev, capi, workload, level, rows, blocks, streams, steps):
-    """kernel-only rate of another configuration (north_star quotes level 9; stress config is level 11)"""
+    """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11)"""
     b = workload.build_uniform(streams, level, rows, blocks, seed0=1 << 20)
     bufs = b.upload(dev)
     plan = capi.Plan(dev, b.descs)
-    _, ms = time_plan(dev, plan, bufs, steps, 2, lambda: None)
+    precondition(dev, plan, bufs, 0.2)
+    _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None)
     plan.destroy()
     for p in bufs:
         dev.free(p)
     rate = b.samples * steps / (ms * 1e-3)
-    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks,
+    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "steps": steps,
             "msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
             "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                  # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    have = visible_gpus()
+    if have < local_world:
+        raise SystemExit("bench.py: %d GPUs requested, %d visible" % (local_world, have))
+    pin_rank_cpus(local, local_world)
 
     import torch
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "RANK" not in os.environ:                       # --force-dist outside a launcher: a world of one
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+            s.close()
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -195,10 +321,10 @@ def main():
             torch.cuda.synchronize()
 
     # ---- stage the workload (untimed): synth -> host bit parsing -> HBM ----
-    # every rank keeps a few file images for the setup-time self check; rank 0 at N=1 keeps the CPU baseline's sample
-    keep = 4 if (args.no_cpu or rank != 0 or world != 1) else min(args.streams, 1024)
+    # file images are kept for the oracle check of EVERY stream (and, on rank 0 at N=1, for the CPU baseline)
     t0 = time.perf_counter()
-    stage_threads = max(4, min(64, workload_cpus() // world))      # ranks of one node share the host cores
+    stage_threads = max(4, min(64, workload_cpus()))       # the rank's own slice of the host (pin_rank_cpus)
+    keep = 0 if args.no_verify and (args.no_cpu or world != 1) else 1 << 30
     if args.workload == "corpus":
         # configs[2]/[3]: the SAME corpus whatever N; rank r decodes its longest-first shard of the file list
         from libacm_amd import batch as fe
@@ -210,86 +336,141 @@ def main():
         batch = workload.build_uniform(args.streams, args.level, args.rows, args.blocks, channels=args.channels,
                                        seed0=rank * args.streams, keep_files=keep, threads=stage_threads)
     t_stage = time.perf_counter() - t0
-    bufs = batch.upload(dev)
+    if dist is not None:
+        # the PCM of a multi-rank run lives in a torch tensor so that the gather leg can hand it to RCCL
+        d_idx = dev.malloc(batch.idx.nbytes)
+        d_hdr = dev.malloc(batch.hdr.nbytes)
+        pcm_t = torch.empty(batch.pcm_words, dtype=torch.int16, device="cuda:%d" % local)
+        torch.cuda.synchronize()
+        flat = batch.idx.view(np.uint8)
+        for o in range(0, flat.size, 1 << 28):
+            dev.upload(d_idx + o, flat[o:o + (1 << 28)])
+        dev.upload(d_hdr, batch.hdr)
+        bufs = (d_idx, d_hdr, pcm_t.data_ptr())
+    else:
+        pcm_t = None
+        bufs = batch.upload(dev)
     plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
     stats = plan.stats()
 
-    # setup-time self check (untimed, before the warm-up): the first streams must match the oracle bit for bit,
-    # and repeated launches over the same resident input must keep producing exactly that (idempotence: the hot
-    # path carries no state between launches; also catches races)
-    verified = None
+    # setup-time check (untimed): every stream of the workload against the CPU oracle, CRC-32 of its PCM
+    verified, n_verified, want = None, 0, None
     if batch.files and not args.no_verify:
-        try:
-            import oracle_api as O
-            nchk = min(4, len(batch.files))
-            want = [O.Oracle.decode_all(batch.files[k].tobytes())[0].view(np.uint16) for k in range(nchk)]
-            verified = True
-            for rep in range(8):
-                plan.launch(*bufs)
-                dev.sync()
-                for k in range(nchk):
-                    d = batch.descs[k]
-                    got = np.zeros(d.n_emit, dtype=np.uint16)
-                    dev.download(got, bufs[2] + 2 * d.pcm_off)
-                    verified = verified and bool(np.array_equal(got, want[k][:d.n_emit]))
-        except Exception as e:
-            verified = "error: %s" % str(e)[:120]
-        if verified is False:
-            raise SystemExit("bench.py: HIP output differs from the oracle - refusing to report a number")
+        want = oracle_crcs(batch, stage_threads)
+        plan.launch(*bufs)
+        dev.sync()
+        got = device_crcs(dev, batch, bufs[2], stage_threads)
+        bad = [k for k in range(len(want)) if want[k] != got[k]]
+        if bad:
+            raise SystemExit("bench.py: HIP output differs from the oracle on %d of %d streams (first: %d) - "
+                             "refusing to report a number" % (len(bad), len(want), bad[0]))
+        verified, n_verified = True, len(want)
 
+    pre = precondition(dev, plan, bufs, PRECONDITION_S)
     wall, ev_ms = time_plan(dev, plan, bufs, args.steps, args.warmup, barrier)
+    sustained = None
+    if args.steps < SUSTAINED_STEPS:
+        # the contract's K is short (tens of ms): the same loop again, long, right behind it
+        swall, sev = time_plan(dev, plan, bufs, SUSTAINED_STEPS, 0, barrier)
+        sustained = {"steps": SUSTAINED_STEPS, "ms_per_step": round(swall / SUSTAINED_STEPS * 1e3, 4),
+                     "launch_ms": round(sev / SUSTAINED_STEPS, 4),
+                     "msamples_s_per_gpu": round(batch.samples * SUSTAINED_STEPS / swall / 1e6, 1),
+                     "frac": round(batch.samples * ALGO_BYTES_PER_SAMPLE / (sev / SUSTAINED_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the timed launches must have left exactly the verified PCM behind (the hot path carries no state between launches)
+    if want is not None:
+        got = device_crcs(dev, batch, bufs[2], stage_threads)
+        if got != want:
+            raise SystemExit("bench.py: PCM after the timed region differs from the oracle - refusing to report a number")
 
     # max over ranks of the bracketed wall time
     if dist is not None:
         t = torch.tensor([wall], device="cuda:%d" % local, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t.item())
-        s = torch.tensor([float(batch.samples)], device="cuda:%d" % local, dtype=torch.float64)
+        s = torch.tensor([float(batch.samples), float(n_verified)], device="cuda:%d" % local, dtype=torch.float64)
         dist.all_reduce(s)
-        total_samples = float(s.item())
+        total_samples, n_verified = float(s[0].item()), int(s[1].item())
     else:
         wall_max, total_samples = wall, float(batch.samples)
+
+    # ---- C2 (N > 1): gather of every rank's PCM into rank 0's HBM over RCCL/xGMI, reported beside the headline
+    gather = None
+    if dist is not None and world > 1 and not args.no_gather:
+        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda:%d" % local) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([batch.pcm_words], dtype=torch.int64, device="cuda:%d" % local))
+        sizes = [int(x.item()) for x in sizes]
+        wire = pcm_t.view(torch.uint8)
+        recv = [torch.empty(2 * sizes[r], dtype=torch.uint8, device="cuda:%d" % local) for r in range(1, world)] if rank == 0 else []
+        gt = []
+        for rep in range(3):
+            barrier()
+            g0 = time.perf_counter()
+            if rank == 0:
+                reqs = [dist.irecv(recv[r - 1], src=r) for r in range(1, world)]
+            else:
+                reqs = [dist.isend(wire, dst=0)]
+            for q in reqs:
+                q.wait()
+            torch.cuda.synchronize()
+            barrier()
+            gt.append(time.perf_counter() - g0)
+        g = min(gt[1:])
+        moved = 2 * sum(sizes[1:])
+        gather = {"seconds": round(g, 4), "bytes_into_rank0": moved, "gbs": round(moved / g / 1e9, 1),
+                  "msamples_s_with_gather": round(total_samples / (wall_max / args.steps + g) / 1e6, 1)}
+        del recv
 
     value = total_samples * args.steps / wall_max / 1e6
     ms_per_step = wall_max / args.steps * 1e3
     launch_ms = ev_ms / args.steps                         # average duration of one launch (rank 0's own events)
     achieved = batch.samples * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
 
-    # HBM traffic per launch from the committed PMC run of this same command (profiles/run_profile.sh):
-    # bench.py cannot collect counters on itself, so this is the profile's number, not a live one
-    traffic = None
+    # HBM traffic per launch from the committed PMC run of this same command (profiles/run_profile.sh): bench.py cannot
+    # collect counters on itself.  The file records the kernel source it was measured on; another source -> null.
+    traffic, traffic_src = None, None
     try:
-        key = {(7, 16, 1000, 1024): "level7_1024x1000blocks_rows16", (9, 16, 250, 1024): "level9_1024x250blocks_rows16"}.get(
-            (args.level, args.rows, args.blocks, args.streams)) if args.workload == "uniform" else None
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            traffic = json.load(f)[key]["hbm_bytes_per_launch"] if key else None
+        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
+            tj = json.load(f)
+        key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
+        if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
+            traffic = tj[key]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r2_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
     except Exception:
         traffic = None
 
+    lv_txt = "7-9" if args.workload == "corpus" else args.level
+    shape = (args.streams, args.level, args.rows, args.blocks, args.channels)
     out = {
         "metric": "decoded PCM Msamples/sec over a batch of ACM streams (hot path on HBM-resident staged input)",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if args.workload == "corpus" else "weak", "vs_baseline": None, "verified_vs_oracle": verified, "dtype": "int32", "data": "synthetic",
+        "scaling": "strong" if args.workload == "corpus" else "weak", "vs_baseline": None,
+        "verified_vs_oracle": verified if not args.no_verify else "skipped (--no-verify)",
+        "verified_streams": n_verified, "dtype": "int32", "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[2]: %d-file corpus, mixed mono/stereo, acm_level 7-9, 1-60 s at 22050 Hz, "
                                 "sharded by file" % args.files) if args.workload == "corpus" else
-                               "%s%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each" % (
-                       "BASELINE.json configs[1]: " if (args.streams, args.level, args.rows, args.blocks, args.channels)
-                       == (1024, 7, 16, 1000, 1) else "", args.streams, "mono" if args.channels == 1 else "stereo",
-                       args.level, args.rows, args.blocks),
-                   "streams_per_gpu": len(batch.descs), "acm_level": "7-9" if args.workload == "corpus" else args.level,
+                               "%d synthetic %s streams per GPU, acm_level %d, acm_rows %d, %d blocks each%s" % (
+                                   args.streams, "mono" if args.channels == 1 else "stereo", args.level, args.rows, args.blocks,
+                                   " (north_star target configuration)" if shape == (1024, 9, 16, 250, 1) else
+                                   " (BASELINE.json configs[1])" if shape == (1024, 7, 16, 1000, 1) else ""),
+                   "streams_per_gpu": len(batch.descs), "acm_level": lv_txt,
                    "acm_rows": args.rows, "blocks_per_stream": "ragged" if args.workload == "corpus" else args.blocks,
                    "channels": "1|2" if args.workload == "corpus" else args.channels,
                    "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
-                   "kernel": "stagewise" if args.stagewise else "fused_tile", "tiles": int(stats.tiles),
-                   "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2)},
+                   "kernel": "stagewise" if args.stagewise else "acm_tile2 + acm_fused_tile", "tiles": int(stats.tiles),
+                   "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2),
+                   "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": "acm_fused_tile<TileCfg<%s,...>>" % ("7|8|9" if args.workload == "corpus" else args.level), "launch_ms": round(launch_ms, 4),
-                     "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
+                     "kernel": "acm_tile2<TileCfg<%s,256,8192>> (+ acm_fused_tile on ragged tails)" % lv_txt,
+                     "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
+    if sustained:
+        out["sustained"] = sustained
+    if gather:
+        out["gather_c2"] = gather
 
     if rank == 0 and world == 1:
         if not args.no_extra:
@@ -309,17 +490,19 @@ def main():
                 out["roofline"]["d2d_copy_gbs"] = round(copy_gbs, 1)
                 out["roofline"]["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
                 del x, y
-            except Exception as e:
+            except Exception:
                 out["roofline"]["d2d_copy_gbs"] = None
         if not args.no_extra and not args.stagewise:
             extra = []
-            for (lv, rw, bl, ns) in ((9, 16, 250, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch
+            for (lv, rw, bl, ns) in ((7, 16, 1000, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch
+                if (lv, rw, bl, ns) == (args.level, args.rows, args.blocks, args.streams):
+                    continue
                 try:
-                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(3, args.steps // 2)))
+                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(20, args.steps // 3)))
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
-        if not args.no_cpu and len(batch.files) > 4:
+        if not args.no_extra and not args.no_cpu and len(batch.files) > 4:
             # informational: file bytes -> PCM in host memory through acm_batch_decode (bit parsing on the host pool
             # or on device lanes, PCIe both ways, pipelined); by contract this is NOT `value`
             try:
@@ -344,8 +527,12 @@ def main():
         print(json.dumps(out), flush=True)
 
     plan.destroy()
-    for p in bufs:
-        dev.free(p)
+    if dist is not None:
+        dev.free(bufs[0])
+        dev.free(bufs[1])
+    else:
+        for p in bufs:
+            dev.free(p)
     dev.close()
     if dist is not None:
         dist.barrier()

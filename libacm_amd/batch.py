@@ -3,16 +3,18 @@
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests).
 ACM streams share no state, so the data path has NO collective:
 
-    rank 0:  read headers -> weights (total_values) -> greedy longest-first shards
-    C1    :  scatter of the shard table (a few KB of metadata)            [collective, control]
-    rank r:  parse its files on the host, synthesise them on its GPU       [no communication]
-    C2    :  gather of PCM (2 B/sample) + per-stream status to rank 0      [collective, results]
+    rank 0:  read the 14-byte headers -> weights (total_values) -> greedy longest-first shards
+    C1    :  scatter of the shard TABLE - file ids and paths, a few KB; never file contents   [collective, control]
+    rank r:  read its own files, parse them on the host, synthesise them on its GPU           [no communication]
+    C2    :  PCM (2 B/sample) + per-stream status to rank 0: each rank cuts its shard into a few chunks and sends
+             chunk k (point-to-point, exact size, from HBM) while chunk k+1 is being decoded   [results]
 
 The decode itself is injected (`decoder`): the product decoder is GpuDecoder below (HIP kernels through
-libacm_hip.so, device memory and stream owned by torch); tests on CPU-only machines inject a stand-in so that
+libacm_hip.so, device memory owned by torch); tests on CPU-only machines inject a stand-in so that
 sharding, scatter and gather are exercised with world_size > 1.
 """
 import heapq
+import os
 
 import numpy as np
 
@@ -37,6 +39,25 @@ def file_weight(data):
     return int(info.total_values) if rc == 0 else 0
 
 
+def _is_path(f):
+    return isinstance(f, (str, os.PathLike))
+
+
+def _head(f, n=64):
+    """the first bytes of a file (path) or file image (bytes): enough for the ACM / WAVC header"""
+    if _is_path(f):
+        with open(f, "rb") as fh:
+            return fh.read(n)
+    return bytes(f[:n])
+
+
+def _load(f):
+    if _is_path(f):
+        with open(f, "rb") as fh:
+            return fh.read()
+    return f
+
+
 class GpuDecoder:
     """Decode a list of file images on this rank's GPU; PCM stays in HBM as one torch int16 tensor.
 
@@ -53,22 +74,29 @@ class GpuDecoder:
         self.parse = parse
         self.timing = None
         torch.cuda.set_device(ordinal)
-        self.dev = capi.Device(ordinal, torch.cuda.current_stream().cuda_stream)
+        # the library runs on a stream of its own (torch's current stream is usually the null stream, which
+        # acmhip_device_open does not adopt); __call__ orders the two around the torch-owned PCM tensor
+        self.dev = capi.Device(ordinal)
 
     def __call__(self, files):
         """-> (pcm int16 tensor in HBM, per-file word offsets into it, per-file word counts, per-file statuses)"""
         torch = self.torch
         cap = capi.batch_pcm_words(files)
         d_pcm = torch.empty(max(cap, 1), dtype=torch.int16, device="cuda")
+        # a block the caching allocator hands out may still be in use by torch work queued on torch's stream
+        torch.cuda.current_stream().synchronize()
         # one call: threaded (or device-side) bit parsing, pipelined H2D, synthesis; the PCM stays in d_pcm
         statuses, words, offsets, self.timing = capi.batch_decode_device(
             self.dev, files, d_pcm.data_ptr(), cap, fmt=self.fmt, parse=self.parse)
+        # acm_batch_decode returns with its stream drained: d_pcm is complete and visible to torch's streams
         return d_pcm, offsets, words, statuses
 
 
-def decode_sharded(files, decoder, dist=None, root=0, device=None):
-    """Decode `files` (list of bytes; only rank `root` needs to hold them) across all ranks of `dist`.
+def decode_sharded(files, decoder, dist=None, root=0, device=None, chunks=2):
+    """Decode `files` across all ranks of `dist`.
 
+    `files`: list of paths (str / PathLike: every rank can open them; only `root` needs the list) and/or file images
+    (bytes: every rank must pass the same list - contents are never sent, only ids).
     Returns on root: list of (status, np.uint16 array) in input order; on other ranks: None.
     With dist=None runs single-process.  `decoder(list_of_bytes)` -> (pcm 1-D int16 tensor, offsets, words, statuses).
     """
@@ -76,54 +104,76 @@ def decode_sharded(files, decoder, dist=None, root=0, device=None):
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
 
-    # ---- C1: shard table scatter (control)
+    # ---- C1: shard table scatter (control): ids + paths, never contents
     if rank == root:
-        weights = [file_weight(f) for f in files]
+        weights = [file_weight(_head(f)) for f in files]
         shards = shard_longest_first(weights, world)
-        payload = [[(i, files[i]) for i in shard] for shard in shards]
+        table = [[(i, os.fspath(files[i]) if _is_path(files[i]) else None) for i in shard] for shard in shards]
     else:
-        payload = None
+        table = None
     if dist is not None:
         mine = [None]
-        dist.scatter_object_list(mine, payload if rank == root else None, src=root)
+        dist.scatter_object_list(mine, table if rank == root else None, src=root)
         mine = mine[0]
     else:
-        mine = payload[0]
+        mine = table[0]
+    for i, path in mine:
+        if path is None and (files is None or i >= len(files)):
+            raise ValueError("decode_sharded: file %d was passed as bytes on the root only; pass paths, or the same list on every rank" % i)
 
-    # ---- local decode (no communication)
-    ids = [i for i, _ in mine]
-    pcm, offsets, words, statuses = decoder([f for _, f in mine])
-    if device is None:
-        device = pcm.device
-    # compact this rank's PCM into one contiguous run (drop the alignment padding between streams)
-    parts = [pcm[o:o + w] for o, w in zip(offsets, words) if w]
-    flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int16, device=device)
+    # ---- local decode in a few chunks; chunk k travels to root while chunk k+1 is decoded (no communication otherwise)
+    nch = max(1, min(chunks if (dist is not None and world > 1) else 1, len(mine)))
+    cuts = [len(mine) * k // nch for k in range(nch + 1)]
+    pieces, pending, keep_alive = [], [], []
+    for k in range(nch):
+        part = mine[cuts[k]:cuts[k + 1]]
+        ids = [i for i, _ in part]
+        pcm, offsets, words, statuses = decoder([_load(path if path is not None else files[i]) for i, path in part])
+        if device is None:
+            device = pcm.device
+        # compact the chunk's PCM into one contiguous run (drop the alignment padding between streams)
+        parts = [pcm[o:o + w] for o, w in zip(offsets, words) if w]
+        flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int16, device=device)
+        pieces.append(((ids, list(words), list(statuses)), flat))
+        if dist is not None and rank != root and flat.numel():
+            wire = flat.view(torch.uint8)                # neither RCCL nor gloo moves int16; bytes are bytes
+            keep_alive.append(wire)
+            pending.append(dist.isend(wire, dst=root))   # exact size, straight from HBM
 
-    # ---- C2: gather (results)
-    meta = (ids, words, statuses)
+    # ---- C2: results to root
     if dist is None:
-        metas, flats = [meta], [flat]
+        metas = [[m for m, _ in pieces]]
+        flats = [[f for _, f in pieces]]
     else:
         metas = [None] * world if rank == root else None
-        dist.gather_object(meta, metas, dst=root)
-        n = torch.tensor([flat.numel()], dtype=torch.int64, device=device)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n)
-        cap = int(max(int(s.item()) for s in sizes))
-        padded = torch.zeros(max(cap, 1), dtype=torch.int16, device=device)
-        padded[:flat.numel()] = flat
-        wire = padded.view(torch.uint8)              # neither RCCL nor gloo moves int16; bytes are bytes
-        bufs = [torch.empty_like(wire) for _ in range(world)] if rank == root else None
-        dist.gather(wire, bufs, dst=root)
-        flats = [b.view(torch.int16)[:int(s.item())] for b, s in zip(bufs, sizes)] if rank == root else None
+        dist.gather_object([m for m, _ in pieces], metas, dst=root)
+        if rank == root:
+            flats = [None] * world
+            flats[root] = [f for _, f in pieces]
+            recvs = []
+            for r in range(world):
+                if r == root:
+                    continue
+                flats[r] = []
+                for (_, words_r, _) in metas[r]:
+                    n = int(sum(words_r))
+                    buf = torch.empty(2 * n, dtype=torch.uint8, device=device)
+                    if n:
+                        recvs.append(dist.irecv(buf, src=r))
+                    flats[r].append(buf.view(torch.int16))
+            for q in recvs:
+                q.wait()
+        for q in pending:
+            q.wait()
     if rank != root:
         return None
 
     out = [None] * len(files)
-    for (ids_r, words_r, st_r), flat_r in zip(metas, flats):
-        host = flat_r.cpu().numpy().view(np.uint16)
-        pos = 0
-        for i, w, st in zip(ids_r, words_r, st_r):
-            out[i] = (st, host[pos:pos + w].copy())
-            pos += w
+    for metas_r, flats_r in zip(metas, flats):
+        for (ids_r, words_r, st_r), flat_r in zip(metas_r, flats_r):
+            host = flat_r.cpu().numpy().view(np.uint16)
+            pos = 0
+            for i, w, st in zip(ids_r, words_r, st_r):
+                out[i] = (st, host[pos:pos + w].copy())
+                pos += w
     return out

@@ -70,17 +70,22 @@ def test_single_process_front_end():
     check(batch.decode_sharded(files, oracle_decoder), files)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, paths=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        files = corpus() if rank == 0 else None
+        if paths is not None:
+            # the file LIST lives on rank 0 only; the other rank learns its paths from the shard table (C1)
+            files = paths if rank == 0 else None
+        else:
+            # file images: every rank holds the same list, only ids are scattered
+            files = corpus()
         out = batch.decode_sharded(files, oracle_decoder, dist=dist, root=0, device=torch.device("cpu"))
         if rank == 0:
-            check(out, files)
+            check(out, corpus())
             q.put("ok")
         else:
             assert out is None
@@ -90,15 +95,23 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_gloo():
+@pytest.mark.parametrize("by_path", [False, True])
+def test_two_ranks_gloo(by_path, tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    paths = None
+    if by_path:
+        paths = []
+        for k, f in enumerate(corpus()):
+            p = tmp_path / ("f%02d.acm" % k)
+            p.write_bytes(bytes(f))
+            paths.append(str(p))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, paths)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -107,7 +120,59 @@ def test_two_ranks_gloo():
     assert q.get(timeout=5) == "ok"
 
 
+def test_bytes_on_root_only_is_refused():
+    """file contents are never scattered: images passed on the root alone cannot reach the other ranks"""
+    class FakeDist:
+        def get_world_size(self): return 2
+        def get_rank(self): return 1
+        def scatter_object_list(self, out, src_list, src=0): out[0] = [(0, None)]
+    with pytest.raises(ValueError):
+        batch.decode_sharded(None, oracle_decoder, dist=FakeDist(), root=0, device=torch.device("cpu"))
+
+
 @pytest.mark.gpu
 def test_front_end_with_gpu_decoder(dev):
     files = corpus()
     check(batch.decode_sharded(files, batch.GpuDecoder(0)), files)
+
+
+def _nccl_worker(rank, world, port, q, paths):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        out = batch.decode_sharded(paths if rank == 0 else None, batch.GpuDecoder(0), dist=dist, root=0)
+        if rank == 0:
+            check(out, corpus())
+            q.put("ok")
+    except Exception as e:
+        q.put("rank %d: %r" % (rank, e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_front_end_on_rccl(dev, tmp_path):
+    """the N > 1 code path on RCCL with the real GPU decoder: backend nccl, world size 1 on a one-GPU box (scatter of the
+    shard table, gather of the metadata; the PCM of rank 0 stays where it is), in a fresh process"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    paths = []
+    for k, f in enumerate(corpus()):
+        p = tmp_path / ("f%02d.acm" % k)
+        p.write_bytes(bytes(f))
+        paths.append(str(p))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(0, 1, port, q, paths))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
