@@ -318,9 +318,13 @@ class Arena:
         self.patches = (Patch * len(self.patch_list))(*self.patch_list) if self.patch_list else None
 
 
-def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False):
-    """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream."""
+def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None):
+    """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream.
+    patch_subset (tests): keep only these entries of the batch's H1 patch list."""
     ar = Arena(staged_list, windows)
+    if patch_subset is not None and ar.patch_list:
+        ar.patch_list = [ar.patch_list[k] for k in patch_subset]
+        ar.patches = (Patch * len(ar.patch_list))(*ar.patch_list) if ar.patch_list else None
     d_idx = dev.malloc(ar.idx.nbytes)
     d_hdr = dev.malloc(ar.hdr.nbytes)
     d_pcm = dev.malloc(ar.pcm_words * 2)

@@ -59,6 +59,8 @@ struct LevelGroup {
 	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
 	AcmTile2 *d_tiles2 = nullptr;   /* whole tiles of streams decoded from row 0: the lean kernel (acm_tile2) */
 	uint32_t ntiles2 = 0;
+	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
+	uint32_t ntiles_extra = 0;
 	uint32_t *d_list = nullptr;
 	uint32_t nlist = 0;
 	uint64_t max_elems = 0;     /* stage-wise: longest plane run in the group */
@@ -333,6 +335,7 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	for (auto &g : plan->fused) {
 		(void)hipFree(g.d_tiles);
 		(void)hipFree(g.d_tiles2);
+		(void)hipFree(g.d_tiles_extra);
 	}
 	for (auto &g : plan->stagewise)
 		(void)hipFree(g.d_list);
@@ -363,7 +366,16 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		has_patch[patches[p].stream] = 1;
 	}
 
-	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16), tiles_rest(16);
+	std::vector<std::vector<AcmTile>> tiles(16), tiles_carry(16), tiles_rest(16), tiles_extra(16);
+	/* H1 patches (stale amplitude table): only the tiles that can see a patched sample leave the tile kernel - each of them
+	 * becomes a window of its stream for the stage-wise kernels (a pseudo stream behind the n real ones) */
+	struct PatchWindow { uint32_t stream; uint64_t lo_row, hi_row, scratch_off; };
+	std::vector<PatchWindow> windows;
+	std::vector<std::vector<uint64_t>> patch_rows(npatches ? n : 0);
+	for (size_t p = 0; p < npatches; p++)
+		patch_rows[patches[p].stream].push_back(patches[p].sample >> streams[patches[p].stream].level);
+	for (auto &v : patch_rows)
+		std::sort(v.begin(), v.end());
 	std::vector<std::vector<AcmTile2>> tiles2(16);
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1);
@@ -383,7 +395,8 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 				(unsigned long long)s.idx_off, (unsigned long long)s.pcm_off);
 			return ACMHIP_ERR_ARG;
 		}
-		AcmDevStream &d = ds[i];
+		ds[i] = AcmDevStream{};
+		AcmDevStream d{};               /* filled here, stored below: ds grows while windows are cut */
 		d.idx_off = s.idx_off;
 		d.hdr_off = s.hdr_off;
 		d.pcm_off = s.pcm_off;
@@ -396,11 +409,44 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		d.scratch_off = 0;
 		d.pad = 0;
 		st.samples += s.n_emit;
+		ds[i] = d;
 		if (s.n_emit == 0)
 			continue;
 
-		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s, variant) && !has_patch[i];
-		if (fused) {
+		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s, variant);
+		if (fused && has_patch[i]) {
+			const uint32_t T = (uint32_t)acmk_fused_tile_rows(s.level, variant) - 2;
+			const uint64_t cols = 1ull << s.level;
+			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
+			const std::vector<uint64_t> &pr = patch_rows[i];
+			for (uint64_t r = 0; r < emit_rows; r += T) {
+				const uint64_t row0 = s.row_begin + r;
+				const uint64_t lo = row0 >= 2 ? row0 - 2 : 0, hi = std::min<uint64_t>(row0 + T, s.nrows);
+				auto it = std::lower_bound(pr.begin(), pr.end(), lo);
+				if (it == pr.end() || *it >= hi) {
+					tiles_extra[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)row0, 0u, 0u });   /* clean tile: halo flavour */
+					continue;
+				}
+				AcmDevStream w = d;
+				w.pcm_off = s.pcm_off + (r << s.level);
+				w.n_emit = std::min<uint64_t>((uint64_t)T << s.level, s.n_emit - (r << s.level));
+				w.row_begin = (uint32_t)row0;
+				w.halo_row = (uint32_t)lo;
+				w.nrows = (uint32_t)hi;
+				const uint64_t elems = (hi - lo) << s.level;
+				w.scratch_off = plane;
+				plane += (elems + 63) & ~63ull;
+				windows.push_back(PatchWindow{ (uint32_t)i, lo, hi, w.scratch_off });
+				const uint32_t id = (uint32_t)ds.size();
+				ds.push_back(w);
+				lists[s.level].push_back(id);
+				sw_all.push_back(id);
+				grp_max_elems[s.level] = std::max(grp_max_elems[s.level], elems);
+				grp_max_emit[s.level] = std::max(grp_max_emit[s.level], (uint64_t)w.n_emit);
+				sw_max = std::max(sw_max, elems);
+			}
+			st.fused_streams++;
+		} else if (fused) {
 			const uint32_t T = (uint32_t)acmk_fused_tile_rows(s.level, variant) - 2;
 			const uint64_t cols = 1ull << s.level;
 			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
@@ -442,6 +488,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		} else {
 			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
 			d.scratch_off = plane;
+			ds[i].scratch_off = plane;
 			plane += (elems + 63) & ~63ull;
 			lists[s.level].push_back((uint32_t)i);
 			sw_all.push_back((uint32_t)i);
@@ -454,8 +501,22 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 
 	/* H1 patches -> plane coordinates */
 	std::vector<AcmDevPatch> dp;
+	std::vector<std::vector<size_t>> win_of(windows.empty() ? 0 : n);
+	for (size_t w = 0; w < windows.size(); w++)
+		win_of[windows[w].stream].push_back(w);
 	for (size_t p = 0; p < npatches; p++) {
 		const AcmDevStream &d = ds[patches[p].stream];
+		if (!win_of.empty() && !win_of[patches[p].stream].empty()) {
+			/* a tile-kernel stream: the patch lands in every window that can see it (its own tile, and the next one
+			 * when it sits in that tile's two halo rows) */
+			const uint64_t row = patches[p].sample >> d.level;
+			for (size_t w : win_of[patches[p].stream]) {
+				const PatchWindow &pw = windows[w];
+				if (row >= pw.lo_row && row < pw.hi_row)
+					dp.push_back(AcmDevPatch{ pw.scratch_off + (patches[p].sample - (pw.lo_row << d.level)), patches[p].value, 0 });
+			}
+			continue;
+		}
 		const uint64_t first = (uint64_t)d.halo_row << d.level;
 		const uint64_t end = (uint64_t)d.nrows << d.level;
 		if (d.n_emit == 0 || patches[p].sample < first || patches[p].sample >= end)
@@ -470,9 +531,17 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	pl->variant = variant;
 	int rc = to_device(dev, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
-		if (!tiles[lv].empty()) {
+		if (!tiles[lv].empty() || !tiles_extra[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
+			if (!tiles_extra[lv].empty()) {
+				g.ntiles_extra = (uint32_t)tiles_extra[lv].size();
+				rc = to_device(dev, tiles_extra[lv], &g.d_tiles_extra);
+				st.tiles += g.ntiles_extra;
+				st.launches += 1;
+				if (tiles[lv].empty())
+					st.launches -= 1;               /* the launch counted below does not happen */
+			}
 			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
@@ -561,6 +630,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->fused) {
 		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, fmt, st));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, st));
 	}
 
 	for (const LevelGroup &g : pl->small)

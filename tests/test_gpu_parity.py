@@ -123,6 +123,24 @@ def test_h1_stale_table_patches(dev):
         check_streams(dev, [f])
 
 
+def test_h1_patches_demote_tiles_not_streams(dev):
+    """a few out-of-range indices in a long tile-kernel stream: only the tiles that can see a patched sample (their own
+    rows and the two halo rows in front) go through the stage-wise kernels, as windows; the stream stays fused"""
+    for lv, rows, nb in ((7, 16, 120), (9, 16, 40), (11, 8, 30)):
+        clean = make_stream(950 + lv, lv, rows, nb, cut=11)
+        dirty = make_stream(960 + lv, lv, rows, nb, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6, cut=3)
+        sd = capi.stage_file(dirty)
+        assert sd.info.npatches > 0
+        st = check_streams(dev, [clean, dirty, clean])
+        assert st.fused_streams == 3 and st.stagewise_streams == 0
+        # sparse patches: keep the first, one in the middle and the last -> most tiles stay on the tile kernel; the
+        # all-stage-wise plan over the same inputs is the (independent) second implementation to compare with
+        keep = [0, sd.info.npatches // 2, sd.info.npatches - 1]
+        got, st2 = capi.synth(dev, [sd], return_stats=True, patch_subset=keep)
+        ref = capi.synth(dev, [sd], flags=capi.PLAN_STAGEWISE, patch_subset=keep)
+        assert st2.fused_streams == 1 and st2.tiles > 0 and np.array_equal(got[0], ref[0])
+
+
 def test_window_with_halo(dev):
     """a window starting at row_begin > 0 needs only the two staged rows in front of it"""
     for lv, rows in ((7, 16), (9, 16), (5, 3), (11, 4), (2, 5)):
