@@ -84,7 +84,7 @@ def build_tools(force=False):
     lib = build_hip(force)
     if os.path.exists(src[0]) and (force or _stale(out, src + [lib] + _headers())):
         _run(["gcc", "-O2", "-g", "-Wall", "-Wextra", "-I", INC, "-o", out] + src +
-             ["-L", LIB, "-lacm_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + LIB])
+             ["-L", LIB, "-lacm_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + LIB])
     return out
 
 

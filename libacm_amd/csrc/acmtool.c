@@ -10,6 +10,7 @@
  * batch on the GPU (acm_batch_decode) instead of one after the other.
  */
 #include <getopt.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -184,24 +185,25 @@ static void patch_channels(const char *name, int chans)
 	}
 	if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr)) {
 		fprintf(stderr, "%s: cannot read header\n", name);
-		return;
+		goto done;
 	}
 	if (memcmp(hdr, magic, sizeof(magic)) != 0) {
 		fprintf(stderr, "%s: not an ACM file\n", name);
-		return;
+		goto done;
 	}
 	old = hdr[8] | (hdr[9] << 8);
 	if (old != 1 && old != 2) {
 		fprintf(stderr, "%s: suspicios number of channels: %d\n", name, old);
-		return;
+		goto done;
 	}
 	if (fseek(f, 0, SEEK_SET)) {
 		perror(name);
-		return;
+		goto done;
 	}
 	hdr[8] = (unsigned char)chans;
 	if (fwrite(hdr, 1, sizeof(hdr), f) != sizeof(hdr))
 		perror(name);
+done:
 	fclose(f);
 }
 
@@ -233,90 +235,301 @@ static int slurp(const char *name, unsigned char **data, size_t *len)
 	return 0;
 }
 
+/*
+ * -B: batch mode (no reference counterpart; the files it leaves behind are the ones acmtool.c:231-316 writes one by one).
+ * Three stages run beside each other on groups of files that fit a memory budget:
+ *   reader   slurps the files of group g+1, reads their headers and carves one pinned PCM arena per group
+ *   decoder  (this thread) runs acm_batch_decode on group g
+ *   writers  write the WAV / raw files of group g-1 from a small thread pool, then release the group
+ * At most three groups exist at a time, whatever the length of the file list.
+ */
+typedef struct bgroup {
+	int first, n;                   /* names[first .. first + n) */
+	acm_batch_item *items;
+	void *arena;                    /* PCM of the whole group: pinned when the device hands it out, else malloc */
+	int arena_pinned;
+	acm_batch_timing tm;
+	int rc;
+	struct bgroup *next;
+} bgroup;
+
+typedef struct bqueue {                 /* unbounded FIFO; the group budget below bounds what is in flight */
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	bgroup *head, *tail;
+	int closed;
+} bqueue;
+
+static void bq_init(bqueue *q)
+{
+	pthread_mutex_init(&q->mu, NULL);
+	pthread_cond_init(&q->cv, NULL);
+	q->head = q->tail = NULL;
+	q->closed = 0;
+}
+
+static void bq_push(bqueue *q, bgroup *g)       /* g == NULL closes the queue */
+{
+	pthread_mutex_lock(&q->mu);
+	if (!g) {
+		q->closed = 1;
+	} else {
+		g->next = NULL;
+		if (q->tail)
+			q->tail->next = g;
+		else
+			q->head = g;
+		q->tail = g;
+	}
+	pthread_cond_broadcast(&q->cv);
+	pthread_mutex_unlock(&q->mu);
+}
+
+static bgroup *bq_pop(bqueue *q)
+{
+	bgroup *g;
+	pthread_mutex_lock(&q->mu);
+	while (!q->head && !q->closed)
+		pthread_cond_wait(&q->cv, &q->mu);
+	g = q->head;
+	if (g) {
+		q->head = g->next;
+		if (!q->head)
+			q->tail = NULL;
+	}
+	pthread_mutex_unlock(&q->mu);
+	return g;
+}
+
+static struct {
+	int nfiles;
+	char **names;
+	size_t budget;                  /* bytes of file images + PCM per group */
+	bqueue to_decode, to_write;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	int groups_alive;               /* read but not yet written out and freed */
+	acm_batch_timing total;
+} bt;
+
+#define BATCH_GROUPS_IN_FLIGHT 3
+#define BATCH_WRITERS 4
+
+static void *batch_reader(void *unused)
+{
+	int i = 0;
+	(void)unused;
+	while (i < bt.nfiles) {
+		bgroup *g = calloc(1, sizeof(*g));
+		size_t bytes = 0, pcm_words = 0, at = 0;
+		int k;
+		pthread_mutex_lock(&bt.mu);
+		while (bt.groups_alive >= BATCH_GROUPS_IN_FLIGHT)
+			pthread_cond_wait(&bt.cv, &bt.mu);
+		bt.groups_alive++;
+		pthread_mutex_unlock(&bt.mu);
+		g->first = i;
+		g->items = calloc((size_t)(bt.nfiles - i), sizeof(*g->items));
+		while (i < bt.nfiles && (g->n == 0 || bytes < bt.budget)) {
+			acm_batch_item *it = &g->items[g->n];
+			unsigned char *data = NULL;
+			acm_stage_info si;
+			if (slurp(bt.names[i], &data, &it->len) == 0) {
+				it->data = data;
+				if (acm_stage_probe(data, it->len, cfg.force_chans, &si) == ACM_OK)
+					it->pcm_cap = si.total_values;
+				bytes += it->len + 2 * it->pcm_cap;
+				pcm_words += (it->pcm_cap + 63) & ~(size_t)63;
+			}
+			g->n++;
+			i++;
+		}
+		/* one arena per group, every file's PCM on a 128-byte boundary inside it; pinned memory lets the
+		 * read-back copy engine write it without a bounce buffer */
+		if (pcm_words) {
+			if (acmhip_host_alloc(pcm_words * 2, &g->arena) == ACMHIP_OK)
+				g->arena_pinned = 1;
+			else
+				g->arena = malloc(pcm_words * 2);
+		}
+		for (k = 0; k < g->n; k++) {
+			if (g->items[k].pcm_cap && g->arena) {
+				g->items[k].pcm = (int16_t *)g->arena + at;
+				at += (g->items[k].pcm_cap + 63) & ~(size_t)63;
+			}
+		}
+		bq_push(&bt.to_decode, g);
+	}
+	bq_push(&bt.to_decode, NULL);
+	return NULL;
+}
+
+typedef struct bwrite_job {
+	bgroup *g;
+	int next;                       /* next file of the group to write (under bt.mu) */
+} bwrite_job;
+
+static void write_one(const char *name, const acm_batch_item *it)
+{
+	char *dst = swap_extension(name, cfg.raw ? ".raw" : ".wav");
+	FILE *out = fopen(dst, "wb");
+	if (!out) {
+		perror(dst);
+	} else {
+		unsigned chans = it->channels ? it->channels : 1;
+		unsigned whole = it->total_values / chans * chans;      /* acm_pcm_total * channels */
+		if (!cfg.raw) {
+			unsigned char h[44], *p = h;                    /* acmtool.c:193-229 */
+			p = tag(p, "RIFF");
+			p = le32(p, 4 + 8 + 16 + 8 + whole * ACM_WORD);
+			p = tag(p, "WAVEfmt ");
+			p = le32(p, 16);
+			p = le16(p, 1);
+			p = le16(p, chans);
+			p = le32(p, it->rate);
+			p = le32(p, it->rate * chans * ACM_WORD);
+			p = le16(p, ACM_WORD * 8 * chans / 8);
+			p = le16(p, ACM_WORD * 8);
+			p = tag(p, "data");
+			p = le32(p, whole * ACM_WORD);
+			fwrite(h, 1, sizeof(h), out);
+		}
+		fwrite(it->pcm, 2, whole, out);
+		fclose(out);
+	}
+	free(dst);
+}
+
+static void *batch_write_worker(void *arg)
+{
+	bwrite_job *job = arg;
+	for (;;) {
+		int k;
+		pthread_mutex_lock(&bt.mu);
+		k = job->next++;
+		pthread_mutex_unlock(&bt.mu);
+		if (k >= job->g->n)
+			return NULL;
+		if (job->g->items[k].data && job->g->items[k].pcm && !cfg.no_output)
+			write_one(bt.names[job->g->first + k], &job->g->items[k]);
+	}
+}
+
+static void *batch_writer(void *unused)
+{
+	bgroup *g;
+	(void)unused;
+	while ((g = bq_pop(&bt.to_write)) != NULL) {
+		pthread_t th[BATCH_WRITERS];
+		bwrite_job job;
+		int k, nth;
+		/* messages in file order, exactly what a one-by-one run prints; then the files themselves in parallel */
+		for (k = 0; k < g->n && g->rc == ACMHIP_OK; k++) {
+			acm_batch_item *it = &g->items[k];
+			const char *name = bt.names[g->first + k];
+			unsigned chans, whole;
+			if (!it->data) {
+				fprintf(stderr, "%s: %s\n", name, acm_strerror(ACM_ERR_OPEN));
+				continue;
+			}
+			if (!it->pcm) {
+				fprintf(stderr, "%s: %s\n", name, acm_strerror(it->status));
+				continue;
+			}
+			if (it->status < 0 && it->words == 0)
+				fprintf(stderr, "%s: %s\n", name, acm_strerror(it->status));
+			if (!cfg.quiet)
+				printf("%s: Chans:%u Freq:%u A:%u/%u words:%llu/%u\n", name, it->channels, it->rate,
+				       it->level, it->rows, (unsigned long long)it->words, it->total_values);
+			if (cfg.no_output)
+				continue;
+			chans = it->channels ? it->channels : 1;
+			whole = it->total_values / chans * chans;
+			if (it->words < whole) {
+				/* silence for what the stream did not deliver (acmtool.c:293-310) */
+				fprintf(stderr, "%s: adding filler_samples: %d\n", name, (int)((whole - it->words) * ACM_WORD));
+				memset(it->pcm + it->words, 0, (size_t)(whole - it->words) * 2);
+			}
+		}
+		job.g = g;
+		job.next = 0;
+		nth = g->rc == ACMHIP_OK ? (g->n < BATCH_WRITERS ? g->n : BATCH_WRITERS) : 0;
+		for (k = 0; k < nth; k++)
+			pthread_create(&th[k], NULL, batch_write_worker, &job);
+		for (k = 0; k < nth; k++)
+			pthread_join(th[k], NULL);
+		for (k = 0; k < g->n; k++)
+			free((void *)g->items[k].data);
+		if (g->arena_pinned)
+			acmhip_host_free(g->arena);
+		else
+			free(g->arena);
+		free(g->items);
+		free(g);
+		pthread_mutex_lock(&bt.mu);
+		bt.groups_alive--;
+		pthread_cond_broadcast(&bt.cv);
+		pthread_mutex_unlock(&bt.mu);
+	}
+	return NULL;
+}
+
 static int decode_batch(int nfiles, char **names)
 {
-	acm_batch_item *items = calloc((size_t)nfiles, sizeof(*items));
 	acm_batch_opts opts;
-	acm_batch_timing tm;
 	acmhip_device *dev = NULL;
-	int i, rc;
+	pthread_t reader, writer;
+	bgroup *g;
+	int rc, failed = 0;
+	const char *mb = getenv("ACMTOOL_BATCH_MB"), *bb = getenv("ACMTOOL_BATCH_BYTES");
 
 	memset(&opts, 0, sizeof(opts));
 	opts.force_chans = cfg.force_chans;
 	opts.parse = ACM_BATCH_PARSE_AUTO;
-	for (i = 0; i < nfiles; i++) {
-		unsigned char *data = NULL;
-		acm_stage_info si;
-		if (slurp(names[i], &data, &items[i].len) < 0) {
-			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(ACM_ERR_OPEN));
-			continue;
-		}
-		items[i].data = data;
-		if (acm_stage_probe(data, items[i].len, cfg.force_chans, &si) == ACM_OK) {
-			items[i].pcm_cap = si.total_values;
-			items[i].pcm = calloc(si.total_values, sizeof(int16_t));   /* zeros = the padding of :293-310 */
-		}
-	}
+	memset(&bt, 0, sizeof(bt));
+	bt.nfiles = nfiles;
+	bt.names = names;
+	bt.budget = (size_t)(mb && atoi(mb) > 0 ? atoi(mb) : 1024) << 20;      /* file images + PCM per group */
+	if (bb && atol(bb) > 0)
+		bt.budget = (size_t)atol(bb);
+	bq_init(&bt.to_decode);
+	bq_init(&bt.to_write);
+	pthread_mutex_init(&bt.mu, NULL);
+	pthread_cond_init(&bt.cv, NULL);
+
 	rc = acmhip_device_open(0, NULL, &dev);
-	if (rc == ACMHIP_OK)
-		rc = acm_batch_decode(dev, items, (size_t)nfiles, &opts, &tm);
 	if (rc != ACMHIP_OK) {
 		fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
 		return 1;
 	}
-	for (i = 0; i < nfiles; i++) {
-		acm_batch_item *it = &items[i];
-		char *dst;
-		FILE *out;
-		if (!it->data)
-			continue;
-		if (!it->pcm) {
-			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(it->status));
-			continue;
+	pthread_create(&reader, NULL, batch_reader, NULL);
+	pthread_create(&writer, NULL, batch_writer, NULL);
+	while ((g = bq_pop(&bt.to_decode)) != NULL) {
+		g->rc = failed ? ACMHIP_ERR_ARG : acm_batch_decode(dev, g->items, (size_t)g->n, &opts, &g->tm);
+		if (g->rc != ACMHIP_OK && !failed) {
+			fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
+			failed = 1;
 		}
-		if (it->status < 0 && it->words == 0)
-			fprintf(stderr, "%s: %s\n", names[i], acm_strerror(it->status));
-		if (!cfg.quiet)
-			printf("%s: Chans:%u Freq:%u A:%u/%u words:%llu/%u\n", names[i], it->channels, it->rate,
-			       it->level, it->rows, (unsigned long long)it->words, it->total_values);
-		if (cfg.no_output)
-			continue;
-		/* same files a one-by-one run would leave behind: WAV unless -r, silence-padded to the header's length */
-		dst = swap_extension(names[i], cfg.raw ? ".raw" : ".wav");
-		out = fopen(dst, "wb");
-		if (!out) {
-			perror(dst);
-		} else {
-			unsigned chans = it->channels ? it->channels : 1;
-			unsigned whole = it->total_values / chans * chans;      /* acm_pcm_total * channels */
-			if (!cfg.raw) {
-				unsigned char h[44], *p = h;
-				p = tag(p, "RIFF");
-				p = le32(p, 4 + 8 + 16 + 8 + whole * ACM_WORD);
-				p = tag(p, "WAVEfmt ");
-				p = le32(p, 16);
-				p = le16(p, 1);
-				p = le16(p, chans);
-				p = le32(p, it->rate);
-				p = le32(p, it->rate * chans * ACM_WORD);
-				p = le16(p, ACM_WORD * 8 * chans / 8);
-				p = le16(p, ACM_WORD * 8);
-				p = tag(p, "data");
-				p = le32(p, whole * ACM_WORD);
-				fwrite(h, 1, sizeof(h), out);
-			}
-			if (it->words < whole)
-				fprintf(stderr, "%s: adding filler_samples: %d\n", names[i], (int)((whole - it->words) * ACM_WORD));
-			fwrite(it->pcm, 2, whole, out);
-			fclose(out);
+		if (g->rc == ACMHIP_OK) {
+			bt.total.samples += g->tm.samples;
+			bt.total.alloc_s += g->tm.alloc_s;
+			bt.total.stage_s += g->tm.stage_s;
+			bt.total.h2d_s += g->tm.h2d_s;
+			bt.total.kernel_s += g->tm.kernel_s;
+			bt.total.d2h_s += g->tm.d2h_s;
+			bt.total.total_s += g->tm.total_s;
 		}
-		free(dst);
+		bq_push(&bt.to_write, g);
 	}
-	if (!cfg.quiet)
+	bq_push(&bt.to_write, NULL);
+	pthread_join(reader, NULL);
+	pthread_join(writer, NULL);
+	if (!cfg.quiet && !failed)
 		printf("batch: %llu samples, alloc %.3fs parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
-		       (unsigned long long)tm.samples, tm.alloc_s, tm.stage_s, tm.h2d_s, tm.kernel_s, tm.d2h_s, tm.total_s);
+		       (unsigned long long)bt.total.samples, bt.total.alloc_s, bt.total.stage_s, bt.total.h2d_s,
+		       bt.total.kernel_s, bt.total.d2h_s, bt.total.total_s);
 	acmhip_device_close(dev);
-	return 0;
+	return failed;
 }
 
 static void usage(int code)

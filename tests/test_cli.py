@@ -71,28 +71,36 @@ def test_cli_decoding(dev, rec):
 
 
 @pytest.mark.gpu
-def test_cli_batch_mode(dev):
-    """-B: all files through one acm_batch_decode; raw output equals the per-file decode"""
+@pytest.mark.parametrize("budget", [None, "20000"], ids=["one_group", "many_groups"])
+def test_cli_batch_mode(dev, budget):
+    """-B: groups of files through acm_batch_decode with reading / decoding / writing overlapped.  The files it leaves
+    behind and its stderr are the REFERENCE tool's from a one-by-one decode of the same files (tests/golden/f8_batch.json,
+    recorded from oracle/_ref/acmtool_ref by tests/golden/make_golden_batch.py), whatever the group size."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f8_batch.json")))
+    env = dict(os.environ)
+    if budget:
+        env["ACMTOOL_BATCH_BYTES"] = budget         # a handful of files per group: several groups in flight
     with tempfile.TemporaryDirectory() as td:
         names = []
-        for k, src in enumerate(("f5_plain", "f7_src", "f1_l7_r16_c1", "f1_l9_r3_c2", "f1_l0_r3_c1")):
-            p = os.path.join(td, "b%d.acm" % k)
-            open(p, "wb").write(golden_file(src))
-            names.append(p)
-        trunc = os.path.join(td, "b_trunc.acm")
-        open(trunc, "wb").write(golden_file("f7_src")[:400])
-        names.append(trunc)
-        for flags, ext in ((["-r"], ".raw"), ([], ".wav")):
-            r = subprocess.run([tool(), "-d", "-B", "-q"] + flags + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            assert r.returncode == 0, r.stderr
-            batch = [open(p[:-4] + ext, "rb").read() for p in names]
-            berr = r.stderr
-            for p in names:
-                os.remove(p[:-4] + ext)
-            r = subprocess.run([tool(), "-d", "-q"] + flags + names, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            single = [open(p[:-4] + ext, "rb").read() for p in names]
-            assert batch == single
-            assert b"adding filler_samples" in berr and berr == r.stderr
+        for name, src, cut in g["inputs"]:
+            data = b"this is not an acm file at all" if src is None else golden_file(src)
+            with open(os.path.join(td, name), "wb") as f:
+                f.write(data if cut is None else data[:cut])
+            names.append(name)
+        for run in g["runs"]:
+            for out in run["files"]:
+                if os.path.exists(os.path.join(td, out)):
+                    os.remove(os.path.join(td, out))
+            r = subprocess.run([tool(), "-d", "-B", "-q"] + run["flags"] + names, cwd=td, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == run["rc"], r.stderr
+            assert r.stderr.decode("latin1") == run["stderr"], run["flags"]
+            assert r.stdout.decode("latin1") == run["stdout"]
+            for out, digest in run["files"].items():
+                p = os.path.join(td, out)
+                got = sha(open(p, "rb").read()) if os.path.exists(p) else None
+                assert got == digest, (run["flags"], out)
 
 
 @pytest.mark.gpu
