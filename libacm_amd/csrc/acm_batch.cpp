@@ -160,6 +160,17 @@ struct Slot {
 	bool host_staged = false;       /* staged by the host reader (its arena slice has to go H2D) */
 };
 
+/* Blocks a file can possibly hold: the header promises total_values, but arenas are sized by this - a block costs at
+ * least its 20-bit header and a 5-bit filler code per column (decode.c:491-502, 586-589), and the reader appends one
+ * virtual zero byte (decode.c:57-61).  A 19-byte file that claims 2^32-1 samples gets one block, not 8 GB. */
+inline uint64_t blocks_possible(const acm_stage_info &info, size_t len)
+{
+	const uint64_t bl = (uint64_t)info.rows * info.cols;
+	const uint64_t promised = ((uint64_t)info.total_values + bl - 1) / bl;
+	const uint64_t bits = (len > info.header_bytes ? (uint64_t)(len - info.header_bytes) * 8 : 0) + 8;
+	return std::min<uint64_t>(promised, bits / (20 + 5 * (uint64_t)info.cols) + 1);
+}
+
 /* a run of whole streams that travels through the device as one unit */
 struct Chunk {
 	size_t first = 0, last = 0;             /* stream index range [first, last) */
@@ -181,7 +192,7 @@ extern "C" uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, i
 		if (acm_stage_probe(items[i].data, items[i].len, force_chans, &info) != ACM_OK)
 			continue;
 		const uint64_t bl = (uint64_t)info.rows * info.cols;
-		total += round_up(((uint64_t)info.total_values + bl - 1) / bl * bl, 64);
+		total += round_up(blocks_possible(info, items[i].len) * bl, 64);
 	}
 	return total;
 }
@@ -218,7 +229,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		s.ok = (it.status == ACM_OK);
 		if (s.ok) {
 			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
-			s.need_blocks = ((uint64_t)s.info.total_values + bl - 1) / bl;
+			s.need_blocks = blocks_possible(s.info, it.len);
 			s.idx_len = round_up(s.need_blocks * bl, 64);
 		}
 	});

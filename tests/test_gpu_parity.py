@@ -253,6 +253,26 @@ def test_batch_decode_c_api(dev, parse):
         assert tm.samples == total
 
 
+def test_batch_arena_is_bounded_by_the_file_not_by_its_header(dev):
+    """a header may promise 2^32-1 samples; the arenas are sized by what the bytes of the file can hold, the
+    item ends with its own status and the rest of the batch is untouched"""
+    good = make_stream(3300, 7, 16, 6)
+    want, _ = oracle_pcm(good)
+    lying = bytearray(good)
+    lying[4:8] = (500_000_000).to_bytes(4, "little")          # total_values (decode.c:734-738)
+    lying = bytes(lying)
+    tiny = lying[:19]
+    assert capi.batch_pcm_words([tiny]) <= 2 * 16 * 128 + 64
+    assert capi.batch_pcm_words([lying]) <= (len(lying) * 8 // (20 + 5 * 128) + 2) * 16 * 128
+    for parse in (capi.PARSE_HOST, capi.PARSE_DEVICE):
+        res, tm = capi.batch_decode(dev, [good, lying, tiny, good], parse=parse)
+        assert res[0][0] == 0 and np.array_equal(res[0][1], want)
+        assert res[3][0] == 0 and np.array_equal(res[3][1], want)
+        # every block the file holds, then a clean end of stream at the block boundary (decode.c:588-589)
+        assert res[1][0] == 0 and np.array_equal(res[1][1], want)
+        assert res[2][1].size == 0
+
+
 def test_device_parser_every_filler(dev):
     """ACM_BATCH_PARSE_DEVICE stages exactly what the host reader stages: every filler code, WAVC prefix, ragged
     rows, hazard-H1 streams (flagged -> host), and many streams at once (more lanes than one wavefront)"""
