@@ -34,6 +34,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "acm_device.h"
 
 namespace {
@@ -1218,9 +1220,9 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
  * waves per SIMD), so the tile loop is written for instruction count: 32 KB tiles at four workgroups per CU, all
  * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
  */
-template <class C, int G, int W>
-struct FirstPass2 : FirstPass<C, G, W, 0> {
-	using FP = FirstPass<C, G, W, 0>;
+template <class C, int G, int W, int ABL = 0>
+struct FirstPass2 : FirstPass<C, G, W, ABL> {
+	using FP = FirstPass<C, G, W, ABL>;
 	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
 	static constexpr bool WARM = FP::WARM;
 	static_assert(FP::WARM, "K2 geometry: every segment re-runs the two rows in front of it");
@@ -1231,36 +1233,58 @@ struct FirstPass2 : FirstPass<C, G, W, 0> {
 		return (uint32_t)((seg * FP::RPS * COLS + i0) * 2);
 	}
 	/* base = staged index of (tile row -2, column 0); voff_warm = voff except for segment 0 of a stream's first tile,
-	 * whose two rows in front do not exist (they are read from rows 0..1 instead and weigh 0) */
+	 * whose two rows in front do not exist (they are read from rows 0..1 instead and weigh 0).
+	 * The loads are issued by hand (see k2_wait): one SGPR base, one VGPR offset, compile-time immediates. */
+	template <int K>
+	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	{
+		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
+		constexpr int imm = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
+		static_assert(imm >= 0 && imm < 4096, "13-bit signed instruction offset");
+		if (ABL & 1)                            /* timing-only build: no HBM loads */
+			raw[K] = voff + imm;
+		else
+			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base), "n"(imm) : "memory");
+	}
+	template <int... Ks>
+	static __device__ __forceinline__ void load_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
+							std::integer_sequence<int, Ks...>)
+	{
+		(load_one<Ks>(raw, base, voff, voff_warm), ...);
+	}
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
-#pragma unroll
-		for (int b = ACM_WARM_FROM; b < NB; b++)
-#pragma unroll
-			for (int half = 0; half < 2; half++)
-#pragma unroll
-				for (int q = 0; q < U; q++) {
-					const uint32_t imm = (uint32_t)((((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2);
-					const uint8_t *p = base + (size_t)((b < 0 ? voff_warm : voff) + imm);
-#ifdef ACM_K2_NT_LOADS
-					raw[(b + 1) * BODY + half * U + q] = (W == 1) ? (uint32_t)*reinterpret_cast<const uint16_t *>(p)
-										       : __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
-#else
-					raw[(b + 1) * BODY + half * U + q] = (W == 1) ? (uint32_t)*reinterpret_cast<const uint16_t *>(p)
-										       : *reinterpret_cast<const uint32_t *>(p);
-#endif
-				}
+		static_assert(W == 2, "two adjacent columns per lane");
+		load_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
 	}
 };
 
-template <class C, int G0, int... Gs>
+/*
+ * Vector memory in acm_tile2 is issued and waited for by hand.  Left to the compiler, the first use of a prefetched
+ * index waits with vmcnt(0) - for the PCM stores of the previous tile as well (it cannot prove how many stores are
+ * behind the loads once a lead-in tile may have skipped them), and the row-value fetch is waited for right where it
+ * is issued: one full memory latency per tile with every other wave parked at the next barrier.  Here the loads are
+ * inline asm, so the compiler's counter bookkeeping never sees them, and ONE wait at the end of the iteration that
+ * issued them names exactly the number of younger operations (that tile's PCM stores) it may leave in flight.
+ * The loaded registers are first read in the NEXT iteration, behind that wait and a barrier.  What the compiler must
+ * not do is copy or spill such a register between its load and the wait (it would copy the old content);
+ * tests/test_isa_invariants.py checks the generated code for that.
+ */
+template <int YOUNGER>
+__device__ __forceinline__ void k2_wait()
+{
+	static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit field");
+	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
+}
+
+template <class C, int ABL, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, 4)
 acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
-	using FP = FirstPass2<C, G0, 2>;
+	using FP = FirstPass2<C, G0, 2, ABL>;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 
 	__shared__ uint32_t tile_mem[8 + NELEM + (NELEM >> C::PS)];     /* no guard zone: segment 0 always reads the carry */
@@ -1278,7 +1302,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		return;
 	/* a run that starts inside a stream first replays the tile in front of it without storing PCM */
 	bool discard = false;
-	if (!(tiles[t].flags & ACM_TILE_FRESH)) {
+	if (!(tiles[__builtin_amdgcn_readfirstlane(t)].flags & ACM_TILE_FRESH)) {
 		discard = true;
 		t--;
 	}
@@ -1287,33 +1311,47 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
 	constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
 
-	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589) */
-	auto fetch_val = [&](const AcmTile2 &r) -> int32_t {
-		int32_t v = 0;
+	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589).  Every lane of every
+	 * wave issues the load (lanes beyond the tile repeat its last row) so that all waves count the same vector-memory
+	 * operations; what is loaded is only looked at in finish_val, a whole tile later */
+	const uint32_t lr_fetch = (uint32_t)(tid < TR + 2 ? tid : TR + 1);
+	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
 		const bool fr = (r.flags & ACM_TILE_FRESH) != 0;                 /* no rows in front of the stream: they weigh 0 */
-		if (tid < TR + 2 && !(fr && tid < 2)) {
-			const uint32_t q = r.rowpos + (uint32_t)tid - (fr ? 2u : 0u);     /* rows counted from the record's reference row */
-			const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;     /* q / acm_rows (magic = ceil(2^32 / rows), 0 for rows == 1) */
-			v = (int32_t)hdr[r.hdr_blk + b].val;
-			v = (int32_t)((uint32_t)v << OutScale<L>::SHIFT);
-			if (NEG_ODD_ROWS && (tid & 1))
-				v = -v;
-		}
+		const uint32_t q = r.rowpos + (fr ? (lr_fetch < 2 ? 0u : lr_fetch - 2) : lr_fetch);     /* rows counted from the record's reference row */
+		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;     /* q / acm_rows (magic = ceil(2^32 / rows), 0 for rows == 1) */
+		const uint32_t *p = &hdr[r.hdr_blk + b].val;
+		uint32_t v;
+		if (ABL & 1)
+			v = b;
+		else
+			asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 		return v;
 	};
+	auto finish_val = [&](uint32_t v, const AcmTile2 &r) -> int32_t {
+		if ((r.flags & ACM_TILE_FRESH) && tid < 2)
+			v = 0;
+		v <<= OutScale<L>::SHIFT;
+		return (NEG_ODD_ROWS && (tid & 1)) ? -(int32_t)v : (int32_t)v;
+	};
 	auto idx_base = [&](const AcmTile2 &r) -> const uint8_t * {
-		return reinterpret_cast<const uint8_t *>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
+		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
+		const uint64_t a = reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
 	};
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
 
-	AcmTile2 cur = tiles[t];
+	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;      /* 16-byte PCM stores per thread and tile */
+	static_assert(NVEC % NT == 0, "whole rounds");
+	/* tile records through the scalar cache (the index is wave-uniform; readfirstlane says so to the compiler):
+	 * a vector load here would be tracked by the compiler's vmcnt bookkeeping, which knows nothing of the asm loads */
+	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
 	uint32_t raw[FP::NRAW];
-	int32_t hv = fetch_val(cur);
+	uint32_t hv = fetch_val(cur);
 	FP::load(raw, idx_base(cur), voff, warm_off(cur));
-	if (tid < TR + 2)
-		rowval[0][tid] = hv;
+	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
 
@@ -1321,6 +1359,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		if (fresh)
 			for (int k = tid; k < NCARRY * CW; k += NT)
 				(&carry_mem[0][0])[k] = 0u;
+		if (tid < TR + 2)
+			rowval[buf][tid] = finish_val(hv, cur);  /* fetched (and waited for) while the previous tile was in the LDS passes */
 		__syncthreads();
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
@@ -1329,17 +1369,16 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		const bool more = tn < t_end;
 		AcmTile2 nxt = cur;
 		if (more) {
-			nxt = tiles[tn];
+			nxt = tiles[__builtin_amdgcn_readfirstlane(tn)];
 			hv = fetch_val(nxt);
 			FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
 		}
 
-		run_lds_passes<C, 0, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+		if (!(ABL & 8))
+			run_lds_passes<C, ABL, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
 		__syncthreads();
 
 		if (!discard) {
-			constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8;
-			static_assert(NVEC % NT == 0, "whole rounds");
 			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 			v4u *out = reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
 #pragma unroll
@@ -1347,6 +1386,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 				const int vec = tid + k * NT;
 				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
 				const v4u o = { q[0], q[1], q[2], q[3] };
+				if ((ABL & 16) && o.x != 0x12345u)              /* timing-only build: no stores */
+					continue;
 #ifdef ACM_K2_PLAIN_STORES
 				out[vec] = o;
 #else
@@ -1356,8 +1397,13 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		}
 		if (!more)
 			break;
-		if (tid < TR + 2)
-			rowval[buf ^ 1][tid] = hv;
+		/* the next tile's staged indices were requested before the LDS passes; behind them only this tile's PCM stores
+		 * may still be on their way.  (Waiting here, inside the iteration that issued the loads, keeps the loaded
+		 * registers out of any copy the compiler places on the loop's back edge.) */
+		if (discard)
+			k2_wait<0>();
+		else
+			k2_wait<NSTORE>();
 		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
 		discard = false;
 		cur = nxt;
@@ -1371,7 +1417,16 @@ struct Tile2Entry {
 	int threads, tile_rows, wg_per_cu;
 };
 template <class C, int... Gs>
-constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 0, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+#ifdef ACM_ABLATION
+/* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
+template <int ABL>
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, ABL, 3, 3, 3>, 256, 16, 4 }; }
+const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
+	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
+	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() },
+};
+#endif
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
 	entry_k2<TileCfg<7, 256, 8192>, 2, 2, 3>(),
@@ -1536,7 +1591,13 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 		return 0;
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return -1;
-	const Tile2Entry &e = g_tile2[level - ACM_K2_MIN_LEVEL];
+	Tile2Entry e = g_tile2[level - ACM_K2_MIN_LEVEL];
+#ifdef ACM_ABLATION
+	if (const char *a = getenv("ACM_K2_ABL"))
+		for (const auto &x : g_tile2_abl)
+			if (level == 9 && x.mask == atoi(a))
+				e = x.e;
+#endif
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;

@@ -1,0 +1,95 @@
+"""Generated-code invariants of the lean tile kernel (libacm_amd/csrc/acm_kernels.hip: acm_tile2).
+
+acm_tile2 issues its global loads from inline asm and waits for them by hand (one `s_waitcnt vmcnt(N)` at the end
+of the iteration that issued them), so the compiler does not know that the destination registers of those loads are
+not valid until that wait.  It must therefore not READ such a register (copy it, spill it, use it) between the load
+and the next `s_waitcnt vmcnt`.  This test compiles the kernels to gfx950 assembly (hipcc cross-compiles without a
+GPU) and checks exactly that, plus that no compiler-tracked vector load crept into the kernel (its automatic waits
+would be computed without the asm loads)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from libacm_amd import _build
+
+
+def regs_of(tok):
+    """'v12' -> {12}; 'v[4:7]' -> {4,5,6,7}; anything else -> empty"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def operands(line):
+    body = line.split(";")[0].strip()
+    if not body or body.endswith(":") or body.startswith("."):
+        return None, []
+    parts = body.split(None, 1)
+    ops = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", parts[1])] if len(parts) > 1 else []
+    ops = [re.sub(r"^(sext|neg|abs)\((.*)\)$", r"\2", o.split(" ")[0]) for o in ops]
+    return parts[0], ops
+
+
+@pytest.fixture(scope="module")
+def kernel_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "acm_kernels.s"
+    cmd = [_build.HIPCC, "-O3", "-std=c++17", "--offload-arch=" + _build.GFX, "-I", _build.INC, "-I", _build.CSRC,
+           "--cuda-device-only", "-S", "-o", str(out), os.path.join(_build.CSRC, "acm_kernels.hip")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    return out.read_text()
+
+
+def tile2_bodies(asm):
+    for m in re.finditer(r"^(_ZN\S*acm_tile2\S*):", asm, re.M):
+        end = asm.index(".Lfunc_end", m.end())
+        yield m.group(1), asm[m.end():end].split("\n")
+
+
+def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
+    n_kernels = 0
+    for name, lines in tile2_bodies(kernel_asm):
+        n_kernels += 1
+        pending = set()              # registers with a hand-issued load in flight
+        n_loads = 0
+        for ln, line in enumerate(lines):
+            op, ops = operands(line)
+            if op is None:
+                continue
+            if op == "s_waitcnt" and "vmcnt" in line:
+                pending.clear()
+                continue
+            srcs = ops[1:] if not op.startswith(("global_store", "ds_write", "s_")) else ops
+            if op.startswith("global_store"):
+                srcs = ops
+            read = set()
+            for o in srcs:
+                read |= regs_of(o)
+            # SDWA with UNUSED_PRESERVE and v_mad-style ops also read their destination; be conservative for VALU
+            if op.startswith("v_") and ops and "UNUSED_PRESERVE" in line:
+                read |= regs_of(ops[0])
+            bad = read & pending
+            assert not bad, "%s line %d reads v%s while its load is in flight: %s" % (name[:60], ln, sorted(bad), line.strip())
+            if op.startswith("global_load"):
+                dst = regs_of(ops[0])
+                # a load that overwrites its own address register is fine (the address is read at issue)
+                pending |= dst
+                n_loads += 1
+        assert n_loads >= 2 * 25, (name, n_loads)          # prologue + in-loop sets of staged-index loads
+    assert n_kernels >= 4
+
+
+def test_every_wait_is_written_by_hand(kernel_asm):
+    """exactly three vmcnt waits per kernel: after the prologue loads (0), and at the end of an iteration behind the PCM
+    stores (4) or behind a lead-in tile that stored nothing (0)"""
+    for name, lines in tile2_bodies(kernel_asm):
+        waits = [l.strip() for l in lines if "vmcnt" in l]
+        assert sorted(waits) == ["s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(4)"], (name[:60], waits)
+        stores = [l for l in lines if l.strip().startswith("global_store")]
+        assert len(stores) == 4, (name[:60], len(stores))
