@@ -1239,12 +1239,12 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
 	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
-		constexpr int imm = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
-		static_assert(imm >= 0 && imm < 4096, "13-bit signed instruction offset");
+		constexpr int off = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
+		constexpr int imm = off % 4096, far = off - imm;        /* 12 bits in the instruction, the rest on the scalar base */
 		if (ABL & 1)                            /* timing-only build: no HBM loads */
-			raw[K] = voff + imm;
+			raw[K] = voff + off;
 		else
-			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base), "n"(imm) : "memory");
+			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
 	template <int... Ks>
 	static __device__ __forceinline__ void load_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
@@ -1277,8 +1277,8 @@ __device__ __forceinline__ void k2_wait()
 	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
 }
 
-template <class C, int ABL, int G0, int... Gs>
-__global__ void __launch_bounds__(C::NT, 4)
+template <class C, int WPS, int ABL, int G0, int... Gs>
+__global__ void __launch_bounds__(C::NT, WPS)
 acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, const unsigned fmt)
 {
@@ -1417,22 +1417,35 @@ struct Tile2Entry {
 	int threads, tile_rows, wg_per_cu;
 };
 template <class C, int... Gs>
-constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 0, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+/* bigger tiles: WPC workgroups per CU */
+template <class C, int WPC, int... Gs>
+constexpr Tile2Entry entry_k2w() { return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC }; }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, ABL, 3, 3, 3>, 256, 16, 4 }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() },
 };
 #endif
+/* per level the fastest measured geometry and stage grouping (profiles/r2_sweep_levels.txt): 32 KB tiles at four workgroups
+ * per CU up to level 10, 64 KB tiles of 512 threads (two workgroups, still four waves per SIMD) above; passes of at most
+ * three stages, because with 32-element walks the warm-up of a four-stage pass costs as much as a pass */
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
 	entry_k2<TileCfg<7, 256, 8192>, 2, 2, 3>(),
 	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
 	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
+	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
+	entry_k2w<TileCfg<11, 512, 16384>, 2, 2, 3, 3, 3>(),
+	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),
 };
+inline const Tile2Entry &tile2_entry(uint32_t level)
+{
+	return g_tile2[level - ACM_K2_MIN_LEVEL];
+}
 
 inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 {
@@ -1574,14 +1587,14 @@ extern "C" int acmk_tile2_rows(uint32_t level)
 {
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return 0;
-	return g_tile2[level - ACM_K2_MIN_LEVEL].tile_rows;
+	return tile2_entry(level).tile_rows;
 }
 
 extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 {
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return 0;
-	return (cus > 0 ? cus : 256) * g_tile2[level - ACM_K2_MIN_LEVEL].wg_per_cu;
+	return (cus > 0 ? cus : 256) * tile2_entry(level).wg_per_cu;
 }
 
 extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
@@ -1591,7 +1604,7 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 		return 0;
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return -1;
-	Tile2Entry e = g_tile2[level - ACM_K2_MIN_LEVEL];
+	Tile2Entry e = tile2_entry(level);
 #ifdef ACM_ABLATION
 	if (const char *a = getenv("ACM_K2_ABL"))
 		for (const auto &x : g_tile2_abl)

@@ -46,12 +46,12 @@ def force_k2(monkeypatch):
     monkeypatch.setenv("ACM_K2", "1")
 
 
-@pytest.mark.parametrize("level", [6, 7, 8, 9])
+@pytest.mark.parametrize("level", [6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("rows", [1, 3, 16, 17, 64, 700])
 def test_lean_tile_kernel_matrix(dev, force_k2, level, rows):
     """acm_tile2 (whole tiles of streams decoded from row 0) + the general kernel on the ragged tail, against the oracle:
     awkward block heights (row values cross block boundaries inside a tile and inside the two rows in front of it)"""
-    tr = 8192 >> level
+    tr = (16384 if level >= 11 else 8192) >> level
     nblocks = max(2, (5 * tr + rows - 1) // rows + 1)
     f = make_stream(4000 + level * 100 + rows, level, rows, nblocks, cut=5)
     st = check_streams(dev, [f])
@@ -63,9 +63,9 @@ def test_lean_tile_kernel_batch(dev, force_k2, fmt):
     """many streams in one plan: workgroups start inside streams (lead-in tiles) and cross stream boundaries"""
     files = []
     for i in range(37):
-        lv = 6 + i % 4
+        lv = 6 + i % 7
         rows = [16, 5, 33, 1][i % 4]
-        files.append(make_stream(5000 + i, lv, rows, 2 + (i * 5) % 11 + ((8192 >> lv) * (1 + i % 3)) // rows,
+        files.append(make_stream(5000 + i, lv, rows, 2 + (i * 5) % 11 + ((16384 >> lv) * (1 + i % 3)) // rows,
                                  channels=1 + i % 2, cut=i % 3, val_max=65535 if i % 5 == 0 else 255, pwr_max=15 if i % 5 == 0 else 12))
     check_streams(dev, files, fmt=fmt)
 
