@@ -1440,7 +1440,7 @@ const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
 	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
 	entry_k2w<TileCfg<11, 512, 16384>, 2, 2, 3, 3, 3>(),
-	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),
+	entry_k2w<TileCfg<12, 512, 32768>, 1, 3, 3, 3, 3>(),   /* 64 KB tiles spill at 128 registers; one 128 KB tile per CU is as fast */
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {

@@ -81,7 +81,7 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                 # a load that overwrites its own address register is fine (the address is read at issue)
                 pending |= dst
                 n_loads += 1
-        assert n_loads >= 2 * 25, (name, n_loads)          # prologue + in-loop sets of staged-index loads
+        assert n_loads >= 2 * 13, (name, n_loads)          # prologue + in-loop sets of staged-index loads
     assert n_kernels >= 4
 
 
@@ -89,7 +89,8 @@ def test_every_wait_is_written_by_hand(kernel_asm):
     """exactly three vmcnt waits per kernel: after the prologue loads (0), and at the end of an iteration behind the PCM
     stores (4) or behind a lead-in tile that stored nothing (0)"""
     for name, lines in tile2_bodies(kernel_asm):
-        waits = [l.strip() for l in lines if "vmcnt" in l]
-        assert sorted(waits) == ["s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(4)"], (name[:60], waits)
+        assert not any(l.strip().startswith("scratch_") for l in lines), name[:60]     # a spill is a compiler-tracked vector access
         stores = [l for l in lines if l.strip().startswith("global_store")]
-        assert len(stores) == 4, (name[:60], len(stores))
+        assert len(stores) in (4, 8), (name[:60], len(stores))
+        waits = [l.strip() for l in lines if "vmcnt" in l]
+        assert sorted(waits) == ["s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(%d)" % len(stores)], (name[:60], waits)
