@@ -66,6 +66,8 @@ def build_hip(force=False):
                        "--offload-arch=" + GFX, "-I", INC, "-I", CSRC, "-c", s, "-o", o]
                 if os.environ.get("ACM_ABLATION"):      # timing-only kernel variants for profiling sessions
                     cmd.insert(1, "-DACM_ABLATION=1")
+                if os.environ.get("ACM_TUNING"):        # the alternative tile geometries behind ACM_K1_VARIANT
+                    cmd.insert(1, "-DACM_TUNING=1")
                 extra = os.environ.get("ACM_HIPCC_EXTRA", "").split()           # compiler-flag experiments
                 cmd[1:1] = extra
                 if s.endswith(".cpp"):

@@ -1015,10 +1015,16 @@ template <class C, int W, int ABL, int... Gs>
 constexpr FusedEntry abl() { return FusedEntry{ acm_fused_tile<C, W, ABL, 1, false, Gs...>, C::NT, C::TR, W * 256 / C::NT, nullptr }; }
 #endif
 
+/* variants 1.. are tuning aids (geometry sweeps: -DACM_TUNING; timing-only ablations: -DACM_ABLATION, which implies it) */
+#if defined(ACM_ABLATION) && !defined(ACM_TUNING)
+#define ACM_TUNING 1
+#endif
 #ifdef ACM_ABLATION
 constexpr int NVARIANTS = 20;
-#else
+#elif defined(ACM_TUNING)
 constexpr int NVARIANTS = 10;
+#else
+constexpr int NVARIANTS = 1;
 #endif
 const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 	{	/* variant 0 (default): per level the fastest measured geometry (profiles/sweep_variants.py) */
@@ -1031,6 +1037,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
 	},
+#ifdef ACM_TUNING
 	{	/* variant 1: 64 KB tiles shared by 8 waves (4 waves per SIMD, 32 elements per thread) */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
 		entry2<TileCfg<6, 512, 16384>, 4, 2, 2, 2>(),
@@ -1113,6 +1120,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
 	},
+#endif
 #ifdef ACM_ABLATION
 	{	/* timing only: default geometry without the barriers inside the LDS passes */
 		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
