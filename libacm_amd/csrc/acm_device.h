@@ -107,8 +107,9 @@ int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const Acm
 		      uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_tile2_rows(uint32_t level);                            /* rows per acm_tile2 tile, 0 if the level is not covered */
 int acmk_tile2_grid(uint32_t level, int cus);
+#define ACM_K2_SINK_BYTES 65536                               /* >= one tile of PCM: where lead-in tiles put theirs */
 int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
-		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
+		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);

@@ -71,6 +71,7 @@ struct acmhip_plan {
 	acmhip_device *dev = nullptr;
 	AcmDevStream *d_streams = nullptr;
 	std::vector<LevelGroup> fused, stagewise, small;   /* small: levels 0-4, one register-cascade launch */
+	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
 	uint64_t sw_max_elems = 0;
@@ -341,6 +342,7 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		(void)hipFree(g.d_list);
 	for (auto &g : plan->small)
 		(void)hipFree(g.d_list);
+	(void)hipFree(plan->d_sink);
 	(void)hipFree(plan->d_sw_all);
 	(void)hipFree(plan->d_patches);
 	(void)hipFree(plan->d_plane[0]);
@@ -550,6 +552,11 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
 			rc = to_device(dev, use, &g.d_tiles);
+			if (k2 && rc == ACMHIP_OK && !pl->d_sink) {
+				hipError_t e = hipMalloc((void **)&pl->d_sink, ACM_K2_SINK_BYTES);
+				if (e != hipSuccess)
+					rc = hip_fail(e, "hipMalloc(lead-in sink)");
+			}
 			if (k2 && rc == ACMHIP_OK) {
 				g.ntiles2 = (uint32_t)tiles2[lv].size();
 				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
@@ -628,7 +635,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	void *st = (void *)pl->dev->stream;
 
 	for (const LevelGroup &g : pl->fused) {
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, fmt, st));
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, st));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, st));
 	}

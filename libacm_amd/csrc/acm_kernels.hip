@@ -1288,7 +1288,7 @@ __device__ __forceinline__ void k2_wait()
 template <class C, int WPS, int ABL, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
 acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
-	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, const unsigned fmt)
+	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
@@ -1362,33 +1362,44 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
+#ifdef ACM_STAMPS
+	unsigned long long acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long last_ = stamp_now();
+#endif
 
+	/* tile records come through the scalar cache one iteration ahead (asked for behind the PCM stores, used after the
+	 * next first pass); the last tile of a run names itself as its successor */
+	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
 	for (;;) {
+		const uint32_t tn = t + 1;
+		const bool more = tn < t_end;
 		if (fresh)
 			for (int k = tid; k < NCARRY * CW; k += NT)
 				(&carry_mem[0][0])[k] = 0u;
 		if (tid < TR + 2)
 			rowval[buf][tid] = finish_val(hv, cur);  /* fetched (and waited for) while the previous tile was in the LDS passes */
 		__syncthreads();
+		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		ACM_STAMP(1);
 
-		const uint32_t tn = t + 1;
-		const bool more = tn < t_end;
-		AcmTile2 nxt = cur;
-		if (more) {
-			nxt = tiles[__builtin_amdgcn_readfirstlane(tn)];
-			hv = fetch_val(nxt);
-			FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
-		}
+		hv = fetch_val(nxt);                            /* the last tile of a run fetches its own again: no branch around the loads */
+		ACM_STAMP(2);
 
+		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
+		FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+		ACM_STAMP(3);
 		__syncthreads();
+		ACM_STAMP(4);
 
-		if (!discard) {
+		{
+			/* a lead-in tile stores too - into a sink nobody reads - so that every iteration issues the same vector
+			 * memory operations and ONE counted wait serves them all */
 			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-			v4u *out = reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
+			v4u *out = discard ? reinterpret_cast<v4u *>(sink) : reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
 #pragma unroll
 			for (int k = 0; k < NVEC / NT; k++) {
 				const int vec = tid + k * NT;
@@ -1403,25 +1414,30 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 #endif
 			}
 		}
+		ACM_STAMP(5);
+		/* the next tile's staged indices were requested from inside the LDS passes; behind them only this tile's PCM
+		 * stores may still be on their way.  (Waiting here, inside the iteration that issued the loads, keeps the loaded
+		 * registers out of any copy the compiler places on the loop's back edge.) */
+		k2_wait<NSTORE>();
+		ACM_STAMP(6);
 		if (!more)
 			break;
-		/* the next tile's staged indices were requested before the LDS passes; behind them only this tile's PCM stores
-		 * may still be on their way.  (Waiting here, inside the iteration that issued the loads, keeps the loaded
-		 * registers out of any copy the compiler places on the loop's back edge.) */
-		if (discard)
-			k2_wait<0>();
-		else
-			k2_wait<NSTORE>();
 		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
 		discard = false;
 		cur = nxt;
 		t = tn;
+		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
 		buf ^= 1;
 	}
+#ifdef ACM_STAMPS
+	if ((tid & 63) == 0 && blockIdx.x < 2048 / 4)
+		for (int k = 0; k < 8; k++)
+			g_acm_stamps[blockIdx.x * 4 + (tid >> 6) % 4][k] = acc_[k];
+#endif
 }
 
 struct Tile2Entry {
-	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned);
+	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
 	int threads, tile_rows, wg_per_cu;
 };
 template <class C, int... Gs>
@@ -1606,10 +1622,12 @@ extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 }
 
 extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
-				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream)
+				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
 		return 0;
+	if (!d_sink)
+		return -1;
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return -1;
 	Tile2Entry e = tile2_entry(level);
@@ -1622,7 +1640,7 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, fmt);
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
