@@ -1,18 +1,21 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun): kernel trace + PMC passes for bench.py's default workload.
-# usage: profiles/run_profile.sh <tag> [bench args...]
+# Profiling recipe (run on the GPU box through gpurun): kernel trace + PMC passes for one bench.py workload.
+# usage: profiles/run_profile.sh <tag> [bench args...]      (default workload = bench.py's default: level 9)
+# Counters are collected in passes of their own (never together with the trace), as MI355X_MICROARCH.md prescribes;
+# FETCH_SIZE is doubled by summarize.py / traffic_json.py (gfx950 counts 128-byte requests at 64 B).
 set -u
-TAG=${1:-r1}; shift || true
+TAG=${1:-r2}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu --no-extra $*"
+ARGS="--steps 100 --warmup 20 --no-cpu --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+python3 bench.py $ARGS > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extra $* > /dev/null 2> $OUT/pmc_$name.err
 done
 python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
