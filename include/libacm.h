@@ -10,8 +10,10 @@
  * What differs is behind the API: acm_read() serves PCM out of a read-ahead
  * window whose blocks were bit-parsed on the host and synthesised
  * (amplitude-table unpack, subband synthesis, 16-bit write-out) on the GPU.
- * There is no CPU synthesis path in this library: if no usable HIP device is
- * present acm_open_decoder()/acm_open_file() fail with ACM_ERR_OTHER.
+ * There is no CPU synthesis path in this library.  Everything that only parses
+ * (acm_open_*, the getters, acm_seek_*, acm_read() with buf == NULL) works
+ * without a device; acm_read() into a buffer needs one and returns
+ * ACM_ERR_OTHER (with a line on stderr) when no usable HIP device is present.
  */
 #ifndef __LIBACM_H
 #define __LIBACM_H

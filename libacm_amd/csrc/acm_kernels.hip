@@ -6,8 +6,8 @@
  *   synthesis `level` cascaded butterfly stages      (juggle :508-526, juggle_block :528-577)
  *   write-out (value >> level) as 16-bit             (:617-677)
  *
- * Formulation (verified against the reference by
- * tests/test_cascade_equiv.py): with m the flat sample index of a stream
+ * Formulation (verified against the reference's own juggle_block by
+ * tests/test_oracle_vs_ref.py::test_cascade_formulation_equals_reference_juggle): with m the flat sample index of a stream
  * (row*cols + col, running on across blocks) stage k, stride s = cols >> (k+1):
  *     y[m] = 2*x[m-s] + sg*(x[m-2s] + x[m]),  sg = +1 if bit log2(s) of m is 0 else -1
  *     after stage 0 only: y[m] += 1 where m % (cols/2) == 0
@@ -17,8 +17,11 @@
  * run of rows can be synthesised from its own staged rows plus the two rows
  * before it ("halo").  No state is carried between launches.
  *
- * Two kernel families:
- *   fused tile kernel (levels 5..11, no H1 patches): persistent workgroups, one tile at a time.  A tile is
+ * Kernel families:
+ *   acm_tile2 (levels 6..12, the whole tiles of streams decoded from row 0: the bulk of a batch): the lean form of the
+ *     tile kernel below - 32 KB tiles at four workgroups per CU, one record per tile, vector memory issued and
+ *     waited for by hand.  See the comment in front of it.
+ *   fused tile kernel acm_fused_tile (levels 5..12; ragged tails, windows, level 5): persistent workgroups, one tile at a time.  A tile is
  *     TR rows (2 halo + T payload) of one stream held in LDS as int32.  The stages are grouped into passes of
  *     G = 2..4: each thread owns one residue class of the pass's smallest stride and walks it with the inputs
  *     of the G stages in registers (one LDS read + one write per element per PASS, not per stage).  The
@@ -26,7 +29,8 @@
  *     the last one emits packed 16-bit samples that leave as 16 B/lane stores.  HBM traffic: 2 B read
  *     (+2/T halo, mostly L2 hits) + 2 B written per sample.  Two VALU ops per butterfly (sign folding +
  *     v_mad_i32_i24); measured limit is instruction issue, not HBM.
- *   stage-wise kernels (any level 0..15, H1 patches): unpack to an int32 plane,
+ *   acm_small_level (levels 0..4): the whole cascade in one thread's registers.
+ *   stage-wise kernels (any level 0..15; tiles that can see an H1 patch; levels 13..15): unpack to an int32 plane,
  *     one elementwise launch per stage (ping-pong planes), emit.  8*level B of
  *     HBM traffic per sample; generic fallback and cross-check.
  *
