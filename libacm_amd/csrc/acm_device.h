@@ -111,10 +111,15 @@ int acmk_tile2_grid(uint32_t level, int cus);
 int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
 		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
-		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, void *stream);
+		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);
+int acmk_launch_unpack_stage0(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
+			      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_y, uint32_t shift, void *stream);
+int acmk_plane_tile_rows(void);                                 /* tile rows (incl. 2 halo rows) of the level-12 plane kernel */
+int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+			    const int32_t *d_plane, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);
 int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
-		      uint32_t level, uint32_t k, const int32_t *d_in, int32_t *d_out, void *stream);
+		      uint32_t level, uint32_t k, const int32_t *d_in, int32_t *d_out, uint32_t shift, void *stream);
 int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file_len, uint64_t blocks);
 int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream);

@@ -65,12 +65,14 @@ struct LevelGroup {
 	uint32_t nlist = 0;
 	uint64_t max_elems = 0;     /* stage-wise: longest plane run in the group */
 	uint64_t max_emit = 0;
+	bool prefix_patched = false;    /* a stream of the group has H1 patches: unpack, patch and stage 0 stay separate launches */
+	uint32_t prefix_stages = 0; /* levels 13-15: the stage-wise kernels do level - 12 stages, the level-12 plane kernel the rest (d_tiles) */
 };
 
 struct acmhip_plan {
 	acmhip_device *dev = nullptr;
 	AcmDevStream *d_streams = nullptr;
-	std::vector<LevelGroup> fused, stagewise, small;   /* small: levels 0-4, one register-cascade launch */
+	std::vector<LevelGroup> fused, stagewise, small, prefix;   /* small: levels 0-4, one register-cascade launch; prefix: levels 13-15 */
 	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
@@ -340,6 +342,10 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	}
 	for (auto &g : plan->stagewise)
 		(void)hipFree(g.d_list);
+	for (auto &g : plan->prefix) {
+		(void)hipFree(g.d_list);
+		(void)hipFree(g.d_tiles);
+	}
 	for (auto &g : plan->small)
 		(void)hipFree(g.d_list);
 	(void)hipFree(plan->d_sink);
@@ -380,7 +386,10 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		std::sort(v.begin(), v.end());
 	std::vector<std::vector<AcmTile2>> tiles2(16);
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
-	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1);
+	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
+	std::vector<std::vector<AcmTile>> prefix_tiles(16);
+	std::vector<uint8_t> plane_shift(n, 0);                /* levels 13-15: planes carry values scaled by 2^(16 - level) */
+	const bool prefix_allowed = !(flags & ACMHIP_PLAN_STAGEWISE) && !(getenv("ACM_PREFIX") && atoi(getenv("ACM_PREFIX")) == 0);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
 	uint64_t plane = 0, sw_max = 0;
@@ -487,6 +496,34 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			small_lists[s.level].push_back((uint32_t)i);
 			grp_max_emit[s.level] = std::max(grp_max_emit[s.level], (uint64_t)s.n_emit);
 			st.fused_streams++;
+		} else if (prefix_allowed && s.level > ACM_K1_MAX_LEVEL) {
+			/* levels 13-15: level - 12 stages by the stage-wise kernels into a plane (scaled, see acmk_launch_unpack), then the
+			 * plane is a level-12 stream of 2^(level-12) times as many rows for the tile kernel: stage k of level L has the
+			 * stride of stage k - j of level L - j, and the "+1" belongs to stage 0 alone (decode.c:555-571) */
+			const uint32_t j = s.level - 12;
+			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
+			ds[i].scratch_off = plane;
+			plane_shift[i] = (uint8_t)(16 - s.level);
+			AcmDevStream w{};
+			w.idx_off = plane;                              /* int32 units into the plane */
+			w.pcm_off = s.pcm_off;
+			w.n_emit = s.n_emit;
+			w.level = 12;
+			w.rows = 1;
+			w.nrows = (s.nrows - d.halo_row) << j;
+			w.row_begin = (s.row_begin - d.halo_row) << j;
+			w.halo_row = w.row_begin >= 2 ? w.row_begin - 2 : 0;
+			plane += (elems + 63) & ~63ull;
+			const uint32_t id = (uint32_t)ds.size();
+			ds.push_back(w);
+			const uint32_t T12 = (uint32_t)acmk_plane_tile_rows() - 2;
+			const uint64_t emit_rows = (s.n_emit + 4095) >> 12;
+			for (uint64_t r = 0; r < emit_rows; r += T12)
+				prefix_tiles[s.level].push_back(AcmTile{ id, (int32_t)(w.row_begin + r), 0u, 0u });
+			prefix_lists[s.level].push_back((uint32_t)i);
+			grp_max_elems[s.level] = std::max(grp_max_elems[s.level], elems);
+			sw_max = std::max(sw_max, elems);
+			st.fused_streams++;
 		} else {
 			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
 			d.scratch_off = plane;
@@ -523,7 +560,8 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		const uint64_t end = (uint64_t)d.nrows << d.level;
 		if (d.n_emit == 0 || patches[p].sample < first || patches[p].sample >= end)
 			continue;
-		dp.push_back(AcmDevPatch{ d.scratch_off + (patches[p].sample - first), patches[p].value, 0 });
+		dp.push_back(AcmDevPatch{ d.scratch_off + (patches[p].sample - first),
+					  (int32_t)((uint32_t)patches[p].value << plane_shift[patches[p].stream]), 0 });
 	}
 
 	acmhip_plan *pl = new (std::nothrow) acmhip_plan;
@@ -578,6 +616,23 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			pl->small.push_back(g);
 			st.launches += 1;
 		}
+		if (!prefix_lists[lv].empty() && rc == ACMHIP_OK) {
+			LevelGroup g;
+			g.level = lv;
+			g.prefix_stages = lv - 12;
+			for (uint32_t id : prefix_lists[lv])
+				g.prefix_patched = g.prefix_patched || has_patch[id];
+			g.nlist = (uint32_t)prefix_lists[lv].size();
+			g.max_elems = grp_max_elems[lv];
+			rc = to_device(dev, prefix_lists[lv], &g.d_list);
+			if (rc == ACMHIP_OK) {
+				g.ntiles = (uint32_t)prefix_tiles[lv].size();
+				rc = to_device(dev, prefix_tiles[lv], &g.d_tiles);
+			}
+			pl->prefix.push_back(g);
+			st.tiles += g.ntiles;
+			st.launches += (g.prefix_patched ? 1 : 0) + g.prefix_stages + 1;     /* (unpack,) stages, tile kernel */
+		}
 		if (!lists[lv].empty() && rc == ACMHIP_OK) {
 			LevelGroup g;
 			g.level = lv;
@@ -589,12 +644,14 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			st.launches += lv + 1;          /* stages + emit */
 		}
 	}
-	if (rc == ACMHIP_OK && !sw_all.empty()) {
+	if (rc == ACMHIP_OK && plane > 0) {
 		pl->n_sw_all = (uint32_t)sw_all.size();
 		pl->sw_max_elems = sw_max;
 		pl->plane_elems = plane;
-		rc = to_device(dev, sw_all, &pl->d_sw_all);
-		st.launches += 1;                       /* unpack */
+		if (!sw_all.empty()) {
+			rc = to_device(dev, sw_all, &pl->d_sw_all);
+			st.launches += 1;                       /* unpack */
+		}
 		if (rc == ACMHIP_OK && !dp.empty()) {
 			pl->npatches = dp.size();
 			rc = to_device(dev, dp, &pl->d_patches);
@@ -643,17 +700,35 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->small)
 		LAUNCHTRY(acmk_launch_small(g.level, pl->d_streams, g.d_list, g.nlist, g.max_emit, d_idx, d_hdr, d_pcm, fmt, st));
 
-	if (pl->n_sw_all) {
-		LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,
-					     d_idx, d_hdr, pl->d_plane[0], st));
+	if (pl->n_sw_all || !pl->prefix.empty()) {
+		if (pl->n_sw_all)
+			LAUNCHTRY(acmk_launch_unpack(pl->d_streams, pl->d_sw_all, pl->n_sw_all, pl->sw_max_elems,
+						     d_idx, d_hdr, pl->d_plane[0], 0, st));
+		for (const LevelGroup &g : pl->prefix)
+			if (g.prefix_patched)
+				LAUNCHTRY(acmk_launch_unpack(pl->d_streams, g.d_list, g.nlist, g.max_elems, d_idx, d_hdr, pl->d_plane[0], 16 - g.level, st));
 		LAUNCHTRY(acmk_launch_patch(pl->d_patches, pl->npatches, pl->d_plane[0], st));
 		for (const LevelGroup &g : pl->stagewise) {
 			int cur = 0;
 			for (uint32_t k = 0; k < g.level; k++, cur ^= 1)
 				LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
-							    pl->d_plane[cur], pl->d_plane[cur ^ 1], st));
+							    pl->d_plane[cur], pl->d_plane[cur ^ 1], 0, st));
 			LAUNCHTRY(acmk_launch_emit(pl->d_streams, g.d_list, g.nlist, g.max_emit, pl->d_plane[cur],
 						   d_pcm, fmt, st));
+		}
+		for (const LevelGroup &g : pl->prefix) {
+			int cur = 0;
+			uint32_t k = 0;
+			if (!g.prefix_patched) {
+				/* unpack and stage 0 in one sweep, straight into the plane stage 1 reads */
+				LAUNCHTRY(acmk_launch_unpack_stage0(pl->d_streams, g.d_list, g.nlist, g.max_elems, d_idx, d_hdr, pl->d_plane[1], 16 - g.level, st));
+				cur = 1;
+				k = 1;
+			}
+			for (; k < g.prefix_stages; k++, cur ^= 1)
+				LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
+							    pl->d_plane[cur], pl->d_plane[cur ^ 1], 16 - g.level, st));
+			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
 		}
 	}
 	return ACMHIP_OK;

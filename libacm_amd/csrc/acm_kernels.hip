@@ -66,7 +66,7 @@ constexpr int SW_THREADS = 256;
 __global__ void __launch_bounds__(SW_THREADS)
 acm_sw_unpack(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
 	      const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
-	      int32_t *__restrict__ x)
+	      int32_t *__restrict__ x, const uint32_t shift)
 {
 	const AcmDevStream s = streams[list[blockIdx.y]];
 	const uint64_t first = (uint64_t)s.halo_row << s.level;
@@ -78,7 +78,7 @@ acm_sw_unpack(const AcmDevStream *__restrict__ streams, const uint32_t *__restri
 	     e += (uint64_t)gridDim.x * SW_THREADS) {
 		const uint32_t row = s.halo_row + (uint32_t)(e >> s.level);
 		const uint32_t val = h[row / s.rows].val;
-		dst[e] = (int32_t)((uint32_t)(int32_t)src[e] * val);    // midbuf[idx] == idx*val (:592-600)
+		dst[e] = (int32_t)((uint32_t)(int32_t)src[e] * (val << shift));    // midbuf[idx] == idx*val (:592-600); shift: see acmk_launch_unpack
 	}
 }
 
@@ -93,7 +93,7 @@ acm_sw_patch(const AcmDevPatch *__restrict__ p, uint64_t n, int32_t *__restrict_
 /* one butterfly stage, out of place; e counts from the first halo sample of the stream */
 __global__ void __launch_bounds__(SW_THREADS)
 acm_sw_stage(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
-	     uint32_t level, uint32_t k, const int32_t *__restrict__ in, int32_t *__restrict__ out)
+	     uint32_t level, uint32_t k, const int32_t *__restrict__ in, int32_t *__restrict__ out, const uint32_t one)
 {
 	const AcmDevStream s = streams[list[blockIdx.y]];
 	const uint64_t n = ((uint64_t)(s.nrows - s.halo_row)) << level;
@@ -110,8 +110,38 @@ acm_sw_stage(const AcmDevStream *__restrict__ streams, const uint32_t *__restric
 		uint32_t y = ((e >> sh) & 1) ? 2u * x1 - (x2 + x0)      // :519
 					     : 2u * x1 + (x2 + x0);     // :518
 		if (k == 0 && (e & halfmask) == 0)
-			y += 1u;                                        // :561-564
+			y += one;                                       // :561-564 (1, or the scale of a level 13-15 prefix)
 		yo[e] = y;
+	}
+}
+
+/* unpack and stage 0 in one sweep (levels 13-15 without H1 patches): 2 B in, 4 B out instead of 2+4 and 4+4.
+ * Stage 0 has stride cols/2: x[e - cols/2] sits in the same row or the one above, x[e - cols] in the row above. */
+__global__ void __launch_bounds__(SW_THREADS)
+acm_sw_unpack_stage0(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
+		     const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
+		     int32_t *__restrict__ y, const uint32_t shift)
+{
+	const AcmDevStream s = streams[list[blockIdx.y]];
+	const uint64_t first = (uint64_t)s.halo_row << s.level;
+	const uint64_t n = ((uint64_t)(s.nrows - s.halo_row)) << s.level;
+	const int16_t *src = idx + s.idx_off + first;
+	const acmhip_blkhdr *h = hdr + s.hdr_off;
+	uint32_t *dst = reinterpret_cast<uint32_t *>(y) + s.scratch_off;
+	const uint64_t half = (1ull << s.level) >> 1;
+	for (uint64_t e = (uint64_t)blockIdx.x * SW_THREADS + threadIdx.x; e < n;
+	     e += (uint64_t)gridDim.x * SW_THREADS) {
+		const uint32_t row = s.halo_row + (uint32_t)(e >> s.level);
+		const uint32_t v_here = h[row / s.rows].val << shift;
+		const uint32_t v_above = (e >> s.level) ? h[(row - 1) / s.rows].val << shift : 0u;
+		const bool second_half = (e & half) != 0;                              /* odd position of the stage-0 walk */
+		const uint32_t x0 = (uint32_t)(int32_t)src[e] * v_here;
+		const uint32_t x1 = e >= half ? (uint32_t)(int32_t)src[e - half] * (second_half ? v_here : v_above) : 0u;
+		const uint32_t x2 = e >= 2 * half ? (uint32_t)(int32_t)src[e - 2 * half] * v_above : 0u;
+		uint32_t r = second_half ? 2u * x1 - (x2 + x0) : 2u * x1 + (x2 + x0);  /* decode.c:518-519 */
+		if ((e & (half - 1)) == 0)
+			r += 1u << shift;                                               /* :561-564 */
+		dst[e] = r;
 	}
 }
 
@@ -512,6 +542,10 @@ struct TileCtx {
  * that the loads of the NEXT tile can be in flight while this tile's LDS passes
  * run: load() only issues global loads into `raw`, compute() consumes them.
  */
+/* bit of the ABL template argument that is not an ablation: the first pass reads an int32 plane (stages already applied by
+ * the stage-wise kernels: levels 13-15) instead of staged indices - no unpack multiply, no "+1" */
+constexpr int MODE_PLANE = 64;
+
 template <class C, int G, int W, int ABL = 0>
 struct FirstPass {
 	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS;
@@ -541,6 +575,8 @@ struct FirstPass {
 		/* lowest row any lane may touch: segment 0's (zero-weighted) warm-up sits two rows above the tile */
 		const int base_row = t.row_first - 2 < 0 ? 0 : (t.row_first - 2 > last_row ? last_row : t.row_first - 2);
 		const uint16_t *tbase = reinterpret_cast<const uint16_t *>(t.src) + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
+		const uint32_t *pbase = reinterpret_cast<const uint32_t *>(t.src) + ((size_t)base_row << L);   /* MODE_PLANE: t.src is an int32 plane */
+		static_assert(!(ABL & MODE_PLANE) || W == 1, "one column per lane from a plane");
 		/* interior tile (the common case): every row from row_first-2 to row_first+TR-1 exists, so the
 		 * offsets are lane-constant + compile-time constants; otherwise clamp each row into the stream */
 		const bool interior = (t.row_first >= 2) && (t.row_first + C::TR <= t.nrows);
@@ -563,6 +599,8 @@ struct FirstPass {
 					uint32_t x;
 					if (ABL & 1)
 						x = off0 + q;
+					else if (ABL & MODE_PLANE)
+						x = pbase[off0 + q * SIGMA];
 					else if (W == 1)
 						x = tbase[off0 + q * SIGMA];
 					else
@@ -599,8 +637,8 @@ struct FirstPass {
 			const int lr0 = lr_seg + 2 * b;
 			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
-			const uint32_t b0 = (i0 == 0 && lr0 >= LR_MIN && row_first + lr0 >= 0) ? ONE : 0u;
-			const uint32_t b1 = (i0 == 0 && lr0 + 1 >= LR_MIN && row_first + lr0 + 1 >= 0) ? ONE : 0u;
+			const uint32_t b0 = (!(ABL & MODE_PLANE) && i0 == 0 && lr0 >= LR_MIN && row_first + lr0 >= 0) ? ONE : 0u;
+			const uint32_t b1 = (!(ABL & MODE_PLANE) && i0 == 0 && lr0 + 1 >= LR_MIN && row_first + lr0 + 1 >= 0) ? ONE : 0u;
 			uint32_t v[W][BODY];
 			if constexpr (W == 2 && U % 4 == 0) {
 #pragma unroll
@@ -614,6 +652,12 @@ struct FirstPass {
 						v[W - 1][u + k] = hi[k];
 					}
 				}
+			} else if constexpr ((ABL & MODE_PLANE) != 0) {
+				/* rowval is a mask here: all ones for rows that exist, 0 for rows in front of / behind the stream
+				 * (they were read from a clamped address) */
+#pragma unroll
+				for (int u = 0; u < BODY; u++)
+					v[0][u] = raw[(b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
 			} else {
 #pragma unroll
 				for (int w = 0; w < W; w++)
@@ -800,6 +844,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;       // stage 0 wants odd tile rows negated
+	static_assert(!(ABL & MODE_PLANE) || !NEG_ODD_ROWS, "a plane comes with plain signs");
 	constexpr int NRV = (TR + 2 + NT - 1) / NT;             // rowval entries per thread
 	using FP = FirstPass<C, G0, W0, ABL>;
 
@@ -821,7 +866,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		const AcmTile tl = tiles[t];
 		const AcmDevStream s = streams[tl.stream];
 		TileCtx c;
-		c.src = idx + s.idx_off;
+		c.src = (ABL & MODE_PLANE) ? reinterpret_cast<const int16_t *>(reinterpret_cast<const int32_t *>(idx) + s.idx_off) : idx + s.idx_off;
 		c.hdr = hdr + s.hdr_off;
 		c.dst = reinterpret_cast<uint16_t *>(pcm) + s.pcm_off;
 		c.n_emit = s.n_emit;
@@ -841,7 +886,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 			const int rho = c.row_first + lr;
 			hv[k] = 0;
 			if (lr >= -2 + HALO && lr < TR && rho >= 0 && rho < c.nrows)
-				hv[k] = (int32_t)c.hdr[(uint32_t)rho / c.rows].val;
+				hv[k] = (ABL & MODE_PLANE) ? -1 : (int32_t)c.hdr[(uint32_t)rho / c.rows].val;
 		}
 	};
 	auto store_vals = [&](const int32_t (&hv)[NRV], int32_t *rv) {
@@ -849,7 +894,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		for (int k = 0; k < NRV; k++) {
 			const int lr = tid + k * NT - 2;
 			if (lr < TR) {
-				int32_t v = (int32_t)((uint32_t)hv[k] << OutScale<L>::SHIFT);
+				int32_t v = (ABL & MODE_PLANE) ? hv[k] : (int32_t)((uint32_t)hv[k] << OutScale<L>::SHIFT);
 				if (NEG_ODD_ROWS && (lr & 1))
 					v = -v;
 				rv[lr + 2] = v;
@@ -1475,6 +1520,10 @@ inline const Tile2Entry &tile2_entry(uint32_t level)
 	return g_tile2[level - ACM_K2_MIN_LEVEL];
 }
 
+/* levels 13-15: the stage-wise kernels apply the first level-12 stages into an int32 plane, this level-12 build of the tile
+ * kernel (halo flavour, one 128 KB tile per CU) reads the plane and does the other twelve */
+const FusedEntry g_fused_plane = { acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 1, false, 3, 3, 3, 3>, 512, 8, 1, nullptr };
+
 inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 {
 	uint64_t gx = (max_elems + (uint64_t)SW_THREADS * 4 - 1) / ((uint64_t)SW_THREADS * 4);
@@ -1540,14 +1589,16 @@ extern "C" int acmk_launch_fused(uint32_t level, int variant, int cus, int carry
 	return 0;
 }
 
+/* shift: the planes of a level 13-15 prefix carry values scaled by 2^shift (16 - level) so that the level-12 tile kernel
+ * that finishes them finds a sample in bytes 2..3, as it does for its own levels; 0 everywhere else */
 extern "C" int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
 				  uint64_t max_elems, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
-				  int32_t *d_x, void *stream)
+				  int32_t *d_x, uint32_t shift, void *stream)
 {
 	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
 		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
 		hipLaunchKernelGGL(acm_sw_unpack, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
-				   d_streams, d_list + at, d_idx, d_hdr, d_x);
+				   d_streams, d_list + at, d_idx, d_hdr, d_x, shift);
 		ACMK_CHECK_LAUNCH();
 	}
 	return 0;
@@ -1565,12 +1616,12 @@ extern "C" int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32
 
 extern "C" int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
 				 uint64_t max_elems, uint32_t level, uint32_t k, const int32_t *d_in,
-				 int32_t *d_out, void *stream)
+				 int32_t *d_out, uint32_t shift, void *stream)
 {
 	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
 		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
 		hipLaunchKernelGGL(acm_sw_stage, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
-				   d_streams, d_list + at, level, k, d_in, d_out);
+				   d_streams, d_list + at, level, k, d_in, d_out, 1u << shift);
 		ACMK_CHECK_LAUNCH();
 	}
 	return 0;
@@ -1646,5 +1697,38 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 		grid = ntiles;
 	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
+extern "C" int acmk_plane_tile_rows(void)
+{
+	return g_fused_plane.tile_rows;
+}
+
+/* d_plane stands where the staged indices stand in acmk_launch_fused; the streams' idx_off count int32 units into it */
+extern "C" int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+				       const int32_t *d_plane, int16_t *d_pcm, unsigned fmt, void *stream)
+{
+	if (ntiles == 0)
+		return 0;
+	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * g_fused_plane.wg_per_cu);
+	if (grid > ntiles)
+		grid = ntiles;
+	hipLaunchKernelGGL(g_fused_plane.fn, dim3(grid), dim3(g_fused_plane.threads), 0, (hipStream_t)stream,
+			   d_streams, d_tiles, ntiles, reinterpret_cast<const int16_t *>(d_plane), nullptr, d_pcm, fmt);
+	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
+extern "C" int acmk_launch_unpack_stage0(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
+					 uint64_t max_elems, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+					 int32_t *d_y, uint32_t shift, void *stream)
+{
+	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
+		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
+		hipLaunchKernelGGL(acm_sw_unpack_stage0, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
+				   d_streams, d_list + at, d_idx, d_hdr, d_y, shift);
+		ACMK_CHECK_LAUNCH();
+	}
 	return 0;
 }

@@ -86,6 +86,34 @@ def test_stagewise_matrix(dev, level, rows):
     assert st.stagewise_streams == 1
 
 
+@pytest.mark.parametrize("level", [13, 14, 15])
+@pytest.mark.parametrize("rows", [1, 2, 5])
+def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows):
+    """levels above the tile kernel's: level - 12 stage-wise stages into a scaled plane, then the level-12 tile kernel on
+    the plane (decode.c:566-571: the later stages of level L are the cascade of level L - j on the same sample sequence)"""
+    f = make_stream(8000 + level * 10 + rows, level, rows, 3, cut=7, val_max=65535, pwr_max=15)
+    g = make_stream(8100 + level * 10 + rows, level, rows, 2, channels=2)
+    st = check_streams(dev, [f, g])
+    assert st.fused_streams == 2 and st.stagewise_streams == 0
+    for fmt in (capi.FMT_S16BE, capi.FMT_U16LE):
+        check_streams(dev, [f], fmt=fmt)
+
+
+def test_level_13_window_and_patches(dev):
+    """the prefix path with a window that starts inside the stream, and with H1 patches (scaled like the plane)"""
+    f = make_stream(8300, 13, 2, 5)
+    s = capi.stage_file(f)
+    want, _ = oracle_pcm(f)
+    cols = 1 << 13
+    for row_begin in (1, 2, 5):
+        n_emit = (s.info.blocks * 2 - row_begin) * cols - 3
+        got = capi.synth(dev, [s], windows=[(row_begin, n_emit)])[0]
+        assert np.array_equal(got, want[row_begin * cols: row_begin * cols + n_emit]), row_begin
+    p = make_stream(8301, 13, 2, 4, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    assert capi.stage_file(p).info.npatches > 0
+    check_streams(dev, [p])
+
+
 @pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE])
 @pytest.mark.parametrize("flags", [capi.PLAN_AUTO, capi.PLAN_STAGEWISE])
 def test_output_formats(dev, fmt, flags):
@@ -111,7 +139,9 @@ def test_mixed_batch(dev):
         nb = 1 + (i * 7) % 9
         files.append(make_stream(500 + i, lv, rows, nb, channels=1 + i % 2, cut=i % 4))
     st = check_streams(dev, files)
-    assert st.fused_streams > 0 and st.stagewise_streams > 0
+    assert st.fused_streams == len(files) and st.stagewise_streams == 0      # tile kernels, register kernel, prefix + plane kernel
+    st = check_streams(dev, files, flags=capi.PLAN_STAGEWISE)
+    assert st.stagewise_streams == len(files)
 
 
 def test_h1_stale_table_patches(dev):
