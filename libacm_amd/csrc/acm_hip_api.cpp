@@ -292,9 +292,11 @@ int to_device(acmhip_device *dev, const std::vector<T> &v, T **out)
 	if (v.empty())
 		return ACMHIP_OK;
 	HIPTRY(hipMalloc((void **)out, v.size() * sizeof(T)));
-	HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->stream));
-	/* the host vector dies with the caller: finish the copy now (plan build is not the hot path) */
-	HIPTRY(hipStreamSynchronize(dev->stream));
+	/* a blocking copy on the null stream: done when it returns (the host vector dies with the caller), and - the device
+	 * stream being a non-blocking one - without waiting for the chunks of a batch that are still in flight on it
+	 * (acm_batch_decode builds the plan of chunk k+1 while chunk k runs) */
+	(void)dev;
+	HIPTRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
 	return ACMHIP_OK;
 }
 

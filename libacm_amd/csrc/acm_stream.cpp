@@ -69,7 +69,10 @@ acmhip_device *default_device()
 
 struct HipStream {
 	ACMStream pub;                          /* must stay first: ACMStream* == HipStream* */
-	acmfill::TableHistory tab;
+	acmfill::TableHistory tab;              /* stale-table history as the PARSER has seen it (it reads ahead of the caller) */
+	acmfill::TableHistory tab_served;       /* ... as the reference's table would be: blocks handed to the caller so far.
+	                                           A backward seek continues from this one (the reference never clears its
+	                                           table, decode.c:809-810, and has decoded nothing beyond the served block) */
 
 	uint32_t carry_max = 1;                 /* staged blocks kept in front of a window for its 2-row halo */
 	uint32_t carry = 0;                     /* ... how many are there now */
@@ -274,6 +277,7 @@ int next_block(HipStream *hs)
 	}
 	hs->cur = hs->win_next++;
 	hs->tell_now = hs->tell_after[hs->cur];
+	hs->tab_served.note_block(hs->h_hdr[hs->carry + hs->cur].pwr, hs->h_hdr[hs->carry + hs->cur].val);
 	a->block_ready = 1;
 	return 1;
 }
@@ -337,6 +341,7 @@ extern "C" int acm_open_decoder(ACMStream **res, void *arg, acm_io_callbacks io_
 	ACMStream *a = &hs->pub;
 	memset(a, 0, sizeof(*a));
 	hs->tab.reset();
+	hs->tab_served.reset();
 	a->io_arg = arg;
 	a->io = io_cb;
 	a->data_len = a->io.get_length_func ? (unsigned)a->io.get_length_func(a->io_arg) : 0;
@@ -560,12 +565,15 @@ extern "C" int acm_seek_pcm(ACMStream *acm, unsigned pcm_pos)
 		acm->block_ready = 0;
 		drop_window(hs);                        /* history = zeros again (util.c:241) */
 		hs->next_block_no = 0;
+		hs->tab = hs->tab_served;               /* forget what only the read-ahead had seen */
 		if (indexed) {
 			acm->buf_start_ofs = 14 + (unsigned)(at - start);
 			if (acmfill::skip_bits(acm, (unsigned)(hs->mark_bit[enter] - 8 * at)) < 0)
 				return ACM_ERR_OTHER;           /* the data source no longer holds what was indexed */
-			for (uint64_t b = 0; b < enter; b++)
+			for (uint64_t b = 0; b < enter; b++) {          /* the blocks the reference would decode again on its way */
 				hs->tab.note_block(hs->hdr_log[b].pwr, hs->hdr_log[b].val);
+				hs->tab_served.note_block(hs->hdr_log[b].pwr, hs->hdr_log[b].val);
+			}
 			acm->stream_pos = (unsigned)(enter * bl);
 			hs->next_block_no = enter;
 		}

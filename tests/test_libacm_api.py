@@ -325,3 +325,34 @@ def test_random_seek_walk_pcm(shape):
         assert [s.getter(k) for k in ("pcm_tell", "raw_tell")] == [r.getter(k) for k in ("pcm_tell", "raw_tell")]
     s.close()
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref)")
+@pytest.mark.parametrize("no_index", [False, True])
+def test_seek_walk_on_a_stale_table_stream(no_index, monkeypatch):
+    """hazard H1 plus seeks: out-of-range indices read table entries left by earlier blocks, the reference never clears its
+    table (decode.c:809-810) and has only decoded what it served - our parser reads ahead of the caller, so a backward
+    seek must continue from the table as the SERVED blocks left it.  prime_table makes block 0 write every
+    entry, so the reference's answer does not depend on heap garbage."""
+    import numpy as np
+    from libacm_amd import synth
+    if no_index:
+        monkeypatch.setenv("ACM_NO_SEEK_INDEX", "1")
+    level, rows, nb = 6, 5, 200
+    total = nb * (rows << level) - 3
+    f = synth.generate(seed=synth.BASE_SEED + 4400, level=level, rows=rows, nblocks=nb, total_values=total, mix=1,
+                       allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=7)
+    rng = np.random.default_rng(99)
+    r = O.LibacmStream(O.ref_lib(), f)
+    s = ours(f)
+    pos_list = [total // 2, 100, total // 3, 5000, total - 4000, 0, total // 4]
+    for step, pos in enumerate(pos_list):
+        # a short read first: our read-ahead window is far ahead of what has been served when the seek comes
+        n = int(rng.integers(1, 400)) * 2
+        assert s.read(n) == r.read(n), ("pre", step)
+        assert s.seek_pcm(pos) == r.seek_pcm(pos), (step, pos)
+        n = int(rng.integers(2000, 9000)) * 2
+        assert s.read(n) == r.read(n), (step, pos, n)
+    s.close()
+    r.close()
