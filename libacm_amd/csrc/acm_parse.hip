@@ -9,8 +9,9 @@
  *
  *   acm_parse_scan     one LANE per stream walks its stream and writes colpos[block][column] (the bit offset
  *                      of every column's 5-bit code) and the block headers.  Sequential per stream, light.
- *                      Up to 2048 streams: acm_parse_scan_lone, one stream per WAVEFRONT - then the walk is
- *                      wave-uniform and runs on the scalar unit (s_load + SALU), ~1.7x faster per stream.
+ *                      Up to 32 K streams: acm_parse_scan_wave, one stream per WAVEFRONT - the walk is wave-uniform
+ *                      on the scalar unit, the lanes are its register file (bitstream window, code tables, column
+ *                      offsets) and resolve a k-column together; 2.2x round 1's scalar walk on 1024 long streams.
  *   acm_parse_columns  one LANE per COLUMN decodes `rows` indices from its bit offset.  64 adjacent columns
  *                      per wavefront, all lanes produce row r in the same iteration, so every store is a
  *                      contiguous run of the row-major staged form the synthesis kernels read.  Symbols of
@@ -24,7 +25,11 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "acm_device.h"
+
+#pragma clang diagnostic ignored "-Winline-asm"         /* m0 on a clobber list: see acm_parse_scan_wave */
 
 namespace {
 
@@ -154,7 +159,7 @@ __device__ __forceinline__ uint32_t column_bits(uint32_t code, uint32_t rows)
 }
 
 /*
- * One stream.  LONE = this wavefront has no other stream: everything about the walk is then wave-uniform, the
+ * One stream.  LONE (tuning builds) = this wavefront has no other stream: everything about the walk is then wave-uniform, the
  * compiler keeps it on the scalar unit (s_load through the scalar cache for the window, SALU for the bit
  * arithmetic) and a step costs a few cycles instead of the ~8 per dependent VALU instruction plus an exposed vector
  * memory round trip per window refill.  Otherwise `collen` is this lane's 32-entry table in LDS.
@@ -240,7 +245,8 @@ acm_parse_scan(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8
 	scan_stream<false>(job, files, colpos, hdr, res + j, collen);
 }
 
-/* few streams: one per wavefront, walked on the scalar unit */
+#ifdef ACM_TUNING
+/* round 1's kernel for few streams, kept for A/B runs (ACM_PARSE_SCAN=1): one stream per wavefront, lane 0 only, on the scalar unit */
 __global__ void __launch_bounds__(SCAN_THREADS)
 acm_parse_scan_lone(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
 		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
@@ -249,6 +255,182 @@ acm_parse_scan_lone(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 		return;
 	const AcmParseJob job = jobs[blockIdx.x];
 	scan_stream<true>(job, files, colpos, hdr, res + blockIdx.x, nullptr);
+}
+#endif
+
+/*
+ * One stream per wavefront, the wavefront as the scalar walk's register file.
+ *
+ * The scalar walk above spends ~600 cycles on a fixed-length column and ~2700 on a 16-row k-column (measured, one
+ * filler per stream: profiles/r2_parse_probe.txt): a dependent scalar load per column, the code -> length decision as
+ * a tree of branches, and ~12 dependent scalar instructions per k-symbol.  Here
+ *   - the bitstream window is 65 consecutive dwords held one (dword, next dword) pair per lane, loaded coalesced once
+ *     per ~1900 bits; any 64 bits of it are two v_readlane away;
+ *   - code -> column length and code -> k-prefix table are v_readlane lookups in per-lane tables;
+ *   - column offsets collect in a VGPR (v_writelane) and go out 64 at a time, coalesced;
+ *   - a k-column is resolved by the whole wavefront: lane p assumes "a symbol starts at bit p of the next 64" and looks up
+ *     where it would end and how many rows it stands for; pointer doubling (one ds_bpermute per round) turns that into
+ *     "where do 2, 4, 8, 16 symbols from p end", and a binary descent on the scalar side finds the end of the column from
+ *     the real start, p = 0.
+ */
+struct WaveWindow {
+	const uint32_t *w;
+	uint32_t maxdw;         /* last dword that may be read (inside the zero padding behind the file) */
+	uint32_t base;          /* dword index lane 0 holds */
+	uint32_t lo, hi;        /* this lane: w[base + lane], w[base + lane + 1] */
+	uint32_t lane;
+
+	__device__ __forceinline__ void load(uint32_t dw)
+	{
+		base = dw;
+		const uint32_t i0 = min(dw + lane, maxdw), i1 = min(dw + lane + 1, maxdw);
+		lo = __builtin_nontemporal_load(w + i0);
+		hi = __builtin_nontemporal_load(w + i1);
+	}
+	/* make dwords bit/32 .. bit/32 + 3 readable; returns the lane that holds the first of them */
+	__device__ __forceinline__ uint32_t at(uint32_t bit)
+	{
+		uint32_t r = (bit >> 5) - base;
+		if (r > 60) {
+			load(bit >> 5);
+			r = 0;
+		}
+		return r;
+	}
+	__device__ __forceinline__ uint64_t peek64(uint32_t bit)     /* 64 bits from dword bit/32, shifted down to `bit`: >= 33 valid */
+	{
+		const uint32_t r = at(bit);
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)r);
+		const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)r);
+		return (((uint64_t)b << 32) | a) >> (bit & 31);
+	}
+};
+
+/* returns the bit behind the column's last symbol, or ~0 when the data ends inside the column; rows_left >= 1 */
+template <int LEVELS>
+__device__ __forceinline__ uint32_t walk_k_column(WaveWindow &ww, uint32_t pos, const uint32_t tab, uint32_t rows_left, const uint32_t safe)
+{
+	while (rows_left > 0 && pos < safe) {
+		const uint32_t r = ww.at(pos), sh = pos & 31;
+		const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)ww.lo, (int)r);
+		const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)ww.hi, (int)r);
+		const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)ww.lo, (int)(r + 2));
+		const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)ww.hi, (int)(r + 2));
+		const uint32_t o = sh + ww.lane, d = o >> 5;
+		const uint32_t a = d == 0 ? w0 : d == 1 ? w1 : w2, b = d == 0 ? w1 : d == 1 ? w2 : w3;
+		const uint32_t x = (uint32_t)((((uint64_t)b << 32) | a) >> (o & 31));
+		/* jump[k] = (rows << 8 | end) of 2^k symbols from this lane's bit.  Four symbols are at most 20 bits: the first
+		 * three levels come out of this lane's own 32 bits; from there on pointer doubling, where a chain that has left
+		 * the window (end >= 64) stays as it is - a short jump, still a whole number of symbols. */
+		uint32_t jump[LEVELS];
+		{
+			uint32_t used = 0, got = 0;
+#pragma unroll
+			for (int sy = 0; sy < 4; sy++) {
+				const uint32_t e = (tab >> (((x >> used) & 7u) * 4)) & 15u;
+				used += e & 7u;
+				got += 1 + (e >> 3);
+				if (sy == 0 || sy == 1 || sy == 3)
+					jump[sy == 3 ? 2 : sy] = (ww.lane + used) | got << 8;
+			}
+		}
+#pragma unroll
+		for (int k = 2; k + 1 < LEVELS; k++) {
+			const uint32_t end = jump[k] & 255u;
+			const uint32_t far = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(end << 2), (int)jump[k]);
+			jump[k + 1] = end < 64 ? far + (jump[k] & ~255u) : jump[k];
+		}
+		/* descent from the real start: the largest jumps that stay short of the column's last row ... */
+		uint32_t cur = 0, acc = 0;
+#pragma unroll
+		for (int k = LEVELS - 1; k >= 0; k--) {
+			const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jump[k], (int)(cur & 63u));
+			const bool take = cur < 64 && acc + (j >> 8) < rows_left;
+			cur = take ? (j & 255u) : cur;
+			acc = take ? acc + (j >> 8) : acc;
+		}
+		/* ... then one symbol more: it holds the last row, unless 2^LEVELS - 1 symbols were not enough (next round) */
+		if (cur < 64) {
+			const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jump[0], (int)cur);
+			cur = j & 255u;
+			acc += j >> 8;
+		}
+		pos += cur;
+		rows_left = acc >= rows_left ? 0u : rows_left - acc;
+	}
+	return rows_left ? 0xFFFFFFFFu : pos;
+}
+
+constexpr int WAVE_SCAN_WAVES = 4;      /* streams per workgroup: one per SIMD of the CU */
+
+__global__ void __launch_bounds__(64 * WAVE_SCAN_WAVES)
+acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
+		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
+{
+	const uint32_t jobno = blockIdx.x * WAVE_SCAN_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (jobno >= njobs)
+		return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const AcmParseJob job = jobs[jobno];
+	const uint32_t rows = job.rows, cols = 1u << job.level;
+	const uint32_t safe = job.file_len * 8u;
+	/* per-lane tables, looked up with v_readlane: lane = filler code */
+	const uint32_t code_len = column_bits(lane & 31u, rows);
+	const uint32_t code_tab = k_table_for(lane & 31u);
+	WaveWindow ww;
+	ww.w = reinterpret_cast<const uint32_t *>(files + job.file_off);
+	ww.maxdw = (job.file_len + 15u) / 4u;
+	ww.lane = lane;
+	uint32_t bit = job.data_start * 8u;
+	ww.load(bit >> 5);
+	uint32_t done = 0, status = 1;
+	uint32_t *cp = colpos + job.col_off;
+	for (uint32_t b = 0; b < job.blocks; b++) {
+		if (bit + 20 > safe)
+			goto out;
+		const uint32_t h20 = (uint32_t)ww.peek64(bit) & 0xFFFFFu;
+		bit += 20;
+		for (uint32_t c0 = 0; c0 < cols; c0 += 64) {
+			const uint32_t n = __builtin_amdgcn_readfirstlane(min(64u, cols - c0));
+			uint32_t cpv = 0, k = 0;
+			for (;;) {
+				/* the fast loop: fixed-length columns, one exit; why it ended is sorted out behind it.  A column
+				 * that starts in the last 5 bits of the file ends behind it: one bounds check, at the end. */
+				uint32_t code, len;
+				bool fixed;
+				do {
+					/* cpv[lane k] = bit.  Two scalar operands do not fit one VALU instruction: the lane select goes
+					 * through m0, which compiler-generated gfx950 code does not use here (tests/test_isa_invariants.py) */
+					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cpv) : "s"(bit), "s"(k) : "m0");
+					code = (uint32_t)ww.peek64(bit) & 31u;
+					len = (uint32_t)__builtin_amdgcn_readlane((int)code_len, (int)code);
+					fixed = len < K_WALK;
+					bit += 5 + (fixed ? len : 0u);
+					k++;
+				} while (fixed & (bit <= safe) & (k < n));
+				if (!fixed) {
+					if (len != K_WALK)
+						goto out;
+					const uint32_t tab = (uint32_t)__builtin_amdgcn_readlane((int)code_tab, (int)code);
+					bit = rows <= 16 ? walk_k_column<4>(ww, bit, tab, rows, safe) : walk_k_column<5>(ww, bit, tab, rows, safe);
+				}
+				if (bit > safe)                                 /* the column must end inside the file */
+					goto out;
+				if (k >= n)
+					break;
+			}
+			if (lane < n)
+				cp[c0 + lane] = cpv;
+		}
+		if (lane == 0)
+			hdr[job.hdr_off + b] = acmhip_blkhdr{ h20 >> 4, h20 & 15u };
+		cp += cols;
+		done++;
+	}
+	status = 0;
+out:
+	if (lane == 0)
+		res[jobno] = AcmParseResult{ done, status };
 }
 
 /* ---- kernel 2: decode the columns ---- */
@@ -412,10 +594,22 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 	const uint32_t full = (njobs + SCAN_THREADS - 1) / SCAN_THREADS;
 	const uint32_t scan_waves = njobs < 8192u ? njobs : full < 8192u ? 8192u : full;
 	const uint32_t scan_lanes = (njobs + scan_waves - 1) / scan_waves;
-	/* one scalar unit serves the four SIMDs of a CU: the scalar walk wins while there are at most ~8 streams per CU
-	 * (17 ms against 30 ms for 1024 streams of 512 K samples; level at ~3000 streams; behind at 8192) */
-	if (njobs <= 2048)
+	/* up to ~32 K streams the wave-per-stream walk wins (profiles/r2_parse_probe.txt: 3.0 against 3.4 ms at 32768 streams of
+	 * 8 blocks, 3.9 against 8.5 ms at 4096 of 64); beyond, one stream per lane keeps more streams in flight than waves fit */
+	uint32_t wave_max = 32768;
+#ifdef ACM_TUNING
+	static const int scan_mode = getenv("ACM_PARSE_SCAN") ? atoi(getenv("ACM_PARSE_SCAN")) : 2;     /* 0 lanes, 1 scalar (r1), 2 wave */
+	if (getenv("ACM_PARSE_WAVE_MAX"))
+		wave_max = (uint32_t)atoi(getenv("ACM_PARSE_WAVE_MAX"));
+	if (scan_mode == 0)
+		wave_max = 0;
+	if (njobs <= wave_max && scan_mode == 1)
 		hipLaunchKernelGGL(acm_parse_scan_lone, dim3(njobs), dim3(SCAN_THREADS), 0, st,
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
+	else
+#endif
+	if (njobs <= wave_max)
+		hipLaunchKernelGGL(acm_parse_scan_wave, dim3((njobs + WAVE_SCAN_WAVES - 1) / WAVE_SCAN_WAVES), dim3(64 * WAVE_SCAN_WAVES), 0, st,
 				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
 	else
 		hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,

@@ -340,6 +340,41 @@ def test_batch_parse_auto_many_streams(dev):
         assert hs == ds and np.array_equal(hp, dp), k
 
 
+def test_device_walk_k_columns(dev):
+    """the wave-per-stream walk (acm_parse.hip: acm_parse_scan_wave) on streams that hold ONE k-filler each: every k code,
+    rows around the 16-row switch of the jump table, one row, tall columns that need several 64-bit windows, columns
+    per block below / at / above one wavefront's 64 offsets, truncated files"""
+    from libacm_amd import synth
+    files, at = [], 0
+    for code in (17, 18, 20, 21, 23, 24, 26, 27):
+        for rows in (1, 2, 15, 16, 17, 31, 40, 255):
+            level = (3, 6, 7, 5)[at % 4]
+            f = synth.generate(seed=synth.BASE_SEED + 8800 + at, level=level, rows=rows, nblocks=3, mix=synth.MIX_SINGLE,
+                               single_code=code, pwr_min=12, pwr_max=12)
+            files.append(f if at % 5 else f[:len(f) - 1 - at % 7])
+            at += 1
+    host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
+    devr, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE)
+    assert tm.device_parsed >= len(files) * 3 // 4          # the truncated ones go back to the host reader
+    for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, devr)):
+        assert hs == ds and np.array_equal(hp, dp), k
+    for k in range(0, len(files), 3):
+        want, _ = oracle_pcm(files[k])
+        assert np.array_equal(devr[k][1], want), k
+
+
+def test_device_walk_lane_kernel(dev):
+    """more streams than the wave-per-stream walk takes (32 K): one stream per lane (acm_parse_scan)"""
+    files = [make_stream(9100 + i % 97, 3 + i % 2, 2, 1 + i % 2, cut=i % 3) for i in range(33000)]
+    devr, tm = capi.batch_decode(dev, files, threads=8, parse=capi.PARSE_DEVICE)
+    assert tm.device_parsed >= 32900
+    period = 582                                            # lcm(97, 2, 3): the streams repeat
+    host, _ = capi.batch_decode(dev, files[:period], threads=8, parse=capi.PARSE_HOST)
+    for k in range(len(files)):
+        ws, wp = host[k % period]
+        assert devr[k][0] == ws and np.array_equal(devr[k][1], wp), k
+
+
 @pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE, capi.PARSE_AUTO])
 def test_batch_edge_cases(dev, parse):
     """empty batch, nothing decodable, a single stream, one parser thread, repeated calls on the same handle"""

@@ -134,3 +134,33 @@ def test_every_wait_is_written_by_hand(kernel_asm):
         assert len(stores) in (4, 8), (name[:60], len(stores))
         waits = [l.strip() for l in lines if "vmcnt" in l]
         assert sorted(waits) == ["s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(%d)" % len(stores)], (name[:60], waits)
+
+
+def test_parse_walk_owns_m0(tmp_path):
+    """acm_parse_scan_wave routes a v_writelane lane select through m0 by hand (acm_parse.hip); nothing the compiler
+    generated in that kernel may touch m0, and the kernel must stay free of scratch"""
+    out = tmp_path / "acm_parse.s"
+    cmd = [_build.HIPCC, "-O3", "-std=c++17", "--offload-arch=" + _build.GFX, "-I", _build.INC, "-I", _build.CSRC,
+           "--cuda-device-only", "-S", "-o", str(out), os.path.join(_build.CSRC, "acm_parse.hip")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    asm = out.read_text()
+    m = re.search(r"^(_ZN\S*acm_parse_scan_wave\S*):", asm, re.M)
+    assert m
+    body = asm[m.end():asm.index(".Lfunc_end", m.end())].split("\n")
+    by_hand, mine, writes = False, 0, 0
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            by_hand = True
+        elif t.startswith(";;#ASMEND"):
+            by_hand = False
+        elif t and not t.startswith(";"):
+            code = t.split(";")[0]
+            if by_hand:
+                mine += "m0" in code
+                writes += code.startswith("v_writelane_b32")
+            else:
+                assert not re.search(r"\bm0\b", code), t
+                assert not t.startswith("scratch_"), t
+    assert writes >= 1 and mine == 2 * writes
