@@ -281,17 +281,17 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 	}
 
-	/* AUTO: the device walk takes as long as the longest stream takes one GPU lane (~1/16 of a host core's
-	 * parsing rate, ~1/9 on the scalar unit), the host pool takes total / threads: device when the batch is worth
-	 * more than 16 (9) x threads streams of the longest stream's size */
+	/* AUTO: the device walk takes as long as the longest stream takes one wavefront, the host pool takes total / threads.
+	 * Measured (profiles/r2_parse_probe.txt): a wavefront alone on its SIMD walks at ~1/5 of a host core's parsing rate
+	 * (up to 1024 streams), with four per SIMD at ~1/9 (up to the 32 K streams acm_parse_scan_wave takes), a lane of
+	 * acm_parse_scan at ~1/16: device when the batch is worth more than that many x threads streams of the longest one */
 	bool dev_parse = opts.parse == ACM_BATCH_PARSE_DEVICE;
 	if (opts.parse == ACM_BATCH_PARSE_AUTO) {
 		uint64_t longest = 0;
 		for (const Slot &s : slots)
 			if (s.ok)
 				longest = std::max(longest, s.idx_len);
-		/* up to 2048 streams are walked on the scalar unit, ~1.7x faster per stream than a vector lane */
-		const uint64_t per_thread = n <= 2048 ? 9 : 16;
+		const uint64_t per_thread = n <= 1024 ? 5 : n <= 32768 ? 9 : 16;
 		dev_parse = longest > 0 && idx_total / longest >= per_thread * (uint64_t)threads_wanted;
 	}
 	uint64_t files_total = 0, cols_total = 0;
