@@ -112,8 +112,8 @@ int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t
 		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);
-int acmk_launch_unpack_stage0(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
-			      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_y, uint32_t shift, void *stream);
+int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
+		       uint32_t level, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_y, void *stream);   /* levels 13-15: unpack + level-12 stages */
 int acmk_plane_tile_rows(void);                                 /* tile rows (incl. 2 halo rows) of the level-12 plane kernel */
 int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
 			    const int32_t *d_plane, int16_t *d_pcm, unsigned fmt, void *stream);

@@ -633,7 +633,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			}
 			pl->prefix.push_back(g);
 			st.tiles += g.ntiles;
-			st.launches += (g.prefix_patched ? 1 : 0) + g.prefix_stages + 1;     /* (unpack,) stages, tile kernel */
+			st.launches += g.prefix_patched ? 2 + g.prefix_stages : 2;           /* prefix sweep (or unpack + stages), tile kernel */
 		}
 		if (!lists[lv].empty() && rc == ACMHIP_OK) {
 			LevelGroup g;
@@ -720,16 +720,15 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		}
 		for (const LevelGroup &g : pl->prefix) {
 			int cur = 0;
-			uint32_t k = 0;
 			if (!g.prefix_patched) {
-				/* unpack and stage 0 in one sweep, straight into the plane stage 1 reads */
-				LAUNCHTRY(acmk_launch_unpack_stage0(pl->d_streams, g.d_list, g.nlist, g.max_elems, d_idx, d_hdr, pl->d_plane[1], 16 - g.level, st));
+				/* unpack and all level - 12 stages in one sweep, straight into the plane the tile kernel reads */
+				LAUNCHTRY(acmk_launch_prefix(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, d_idx, d_hdr, pl->d_plane[1], st));
 				cur = 1;
-				k = 1;
+			} else {
+				for (uint32_t k = 0; k < g.prefix_stages; k++, cur ^= 1)
+					LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
+								    pl->d_plane[cur], pl->d_plane[cur ^ 1], 16 - g.level, st));
 			}
-			for (; k < g.prefix_stages; k++, cur ^= 1)
-				LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
-							    pl->d_plane[cur], pl->d_plane[cur ^ 1], 16 - g.level, st));
 			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
 		}
 	}

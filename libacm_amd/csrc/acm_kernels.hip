@@ -115,33 +115,87 @@ acm_sw_stage(const AcmDevStream *__restrict__ streams, const uint32_t *__restric
 	}
 }
 
-/* unpack and stage 0 in one sweep (levels 13-15 without H1 patches): 2 B in, 4 B out instead of 2+4 and 4+4.
- * Stage 0 has stride cols/2: x[e - cols/2] sits in the same row or the one above, x[e - cols] in the row above. */
-__global__ void __launch_bounds__(SW_THREADS)
-acm_sw_unpack_stage0(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
-		     const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
-		     int32_t *__restrict__ y, const uint32_t shift)
+/*
+ * Levels 13-15 without H1 patches: unpack and the first J = level - 12 stages in one sweep, 2 B in and 4 B out per sample
+ * (stage by stage it was 2+4, then 4+4 per further stage).  Those stages have strides of 4096 samples and more, so for a fixed
+ * residue r = e mod 4096 they are a complete level-J cascade over the subsequence q -> x[r + 4096 q] (2^J entries per row): a
+ * thread owns two adjacent residues and walks q with the stage inputs of the last 2^(J+1) - 2 steps in registers; a row of the
+ * stream is one unrolled body of 2^J steps, so sign, "+1" and the block's amplitude step are fixed per body position.  The
+ * walk of a stream is cut into chunks of PREFIX_CHUNK_ROWS rows; a chunk starts two rows early with zero history, which is exact
+ * behind those rows (the cascade reaches back 2^(J+1) - 2 < 2^(J+1) steps), and stores nothing for them.
+ */
+constexpr int PREFIX_CHUNK_ROWS = 64;
+constexpr int PREFIX_THREADS = 256;
+
+template <int J>
+__global__ void __launch_bounds__(PREFIX_THREADS)
+acm_sw_prefix(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict__ list,
+	      const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
+	      int32_t *__restrict__ y, const uint32_t shift)
 {
+	constexpr int U = 1 << J;                               /* steps per row */
+	constexpr uint32_t RB = 2048 / PREFIX_THREADS;          /* workgroups per chunk: 2048 residue pairs */
 	const AcmDevStream s = streams[list[blockIdx.y]];
+	const uint32_t nrows = s.nrows - s.halo_row;
+	const uint32_t chunk = blockIdx.x / RB;
+	const uint32_t row0 = chunk * PREFIX_CHUNK_ROWS;
+	if (row0 >= nrows)
+		return;
+	const uint32_t row_end = min(nrows, row0 + PREFIX_CHUNK_ROWS);
+	const uint32_t pair = (blockIdx.x % RB) * PREFIX_THREADS + threadIdx.x;         /* residues 2 pair, 2 pair + 1 */
 	const uint64_t first = (uint64_t)s.halo_row << s.level;
-	const uint64_t n = ((uint64_t)(s.nrows - s.halo_row)) << s.level;
-	const int16_t *src = idx + s.idx_off + first;
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(idx + s.idx_off + first) + pair;      /* staged rows are 8 KB multiples: aligned */
 	const acmhip_blkhdr *h = hdr + s.hdr_off;
-	uint32_t *dst = reinterpret_cast<uint32_t *>(y) + s.scratch_off;
-	const uint64_t half = (1ull << s.level) >> 1;
-	for (uint64_t e = (uint64_t)blockIdx.x * SW_THREADS + threadIdx.x; e < n;
-	     e += (uint64_t)gridDim.x * SW_THREADS) {
-		const uint32_t row = s.halo_row + (uint32_t)(e >> s.level);
-		const uint32_t v_here = h[row / s.rows].val << shift;
-		const uint32_t v_above = (e >> s.level) ? h[(row - 1) / s.rows].val << shift : 0u;
-		const bool second_half = (e & half) != 0;                              /* odd position of the stage-0 walk */
-		const uint32_t x0 = (uint32_t)(int32_t)src[e] * v_here;
-		const uint32_t x1 = e >= half ? (uint32_t)(int32_t)src[e - half] * (second_half ? v_here : v_above) : 0u;
-		const uint32_t x2 = e >= 2 * half ? (uint32_t)(int32_t)src[e - 2 * half] * v_above : 0u;
-		uint32_t r = second_half ? 2u * x1 - (x2 + x0) : 2u * x1 + (x2 + x0);  /* decode.c:518-519 */
-		if ((e & (half - 1)) == 0)
-			r += 1u << shift;                                               /* :561-564 */
-		dst[e] = r;
+	uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(y) + s.scratch_off) + pair;
+	const uint32_t one = pair == 0 ? 1u << shift : 0u;      /* decode.c:561-564: residue 0 of stage 0 */
+
+	uint32_t ha[J][U], hb[J][U];                            /* [t][x], x < 2d: the 2d inputs of stage t in front of the body */
+#pragma unroll
+	for (int t = 0; t < J; t++)
+#pragma unroll
+		for (int x = 0; x < U; x++)
+			ha[t][x] = hb[t][x] = 0u;
+
+	const uint32_t warm = row0 >= 2 ? 2u : row0;
+	for (uint32_t row = row0 - warm; row < row_end; row++) {
+		const uint32_t val = h[(s.halo_row + row) / s.rows].val << shift;
+		uint32_t a[U], b[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const uint32_t two = __builtin_nontemporal_load(src + (((uint64_t)row << J) + u) * 2048);
+			a[u] = (uint32_t)((int32_t)(two << 16) >> 16) * val;            /* midbuf[idx] == idx*val (:592-600) */
+			b[u] = (uint32_t)((int32_t)two >> 16) * val;
+		}
+#pragma unroll
+		for (int t = 0; t < J; t++) {
+			const int d = 1 << (J - 1 - t);
+			uint32_t ia[U], ib[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				ia[u] = a[u];
+				ib[u] = b[u];
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				const uint32_t a1 = u >= d ? ia[u - d] : ha[t][u + d], a2 = u >= 2 * d ? ia[u - 2 * d] : ha[t][u];
+				const uint32_t b1 = u >= d ? ib[u - d] : hb[t][u + d], b2 = u >= 2 * d ? ib[u - 2 * d] : hb[t][u];
+				const bool odd = (u >> (J - 1 - t)) & 1;
+				a[u] = odd ? 2u * a1 - (a2 + ia[u]) : 2u * a1 + (a2 + ia[u]);  /* :518-519 */
+				b[u] = odd ? 2u * b1 - (b2 + ib[u]) : 2u * b1 + (b2 + ib[u]);
+				if (t == 0 && (u % ((U / 2) > 0 ? (U / 2) : 1)) == 0)
+					a[u] += one;
+			}
+#pragma unroll
+			for (int x = 0; x < 2 * d; x++) {
+				ha[t][x] = ia[U - 2 * d + x];
+				hb[t][x] = ib[U - 2 * d + x];
+			}
+		}
+		if (row >= row0) {
+#pragma unroll
+			for (int u = 0; u < U; u++)
+				dst[(((uint64_t)row << J) + u) * 2048] = make_uint2(a[u], b[u]);
+		}
 	}
 }
 
@@ -1720,14 +1774,19 @@ extern "C" int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, c
 	return 0;
 }
 
-extern "C" int acmk_launch_unpack_stage0(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist,
-					 uint64_t max_elems, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
-					 int32_t *d_y, uint32_t shift, void *stream)
+extern "C" int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
+				 uint32_t level, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_y, void *stream)
 {
+	if (level < 13 || level > 15)
+		return (int)hipErrorInvalidValue;
+	const uint64_t rows = max_elems >> level;
+	const uint32_t chunks = (uint32_t)((rows + PREFIX_CHUNK_ROWS - 1) / PREFIX_CHUNK_ROWS);
+	const uint32_t gx = (chunks ? chunks : 1) * (2048 / PREFIX_THREADS);
 	for (uint32_t at = 0; at < nlist; at += SW_MAX_Y) {
 		const uint32_t n = nlist - at < SW_MAX_Y ? nlist - at : SW_MAX_Y;
-		hipLaunchKernelGGL(acm_sw_unpack_stage0, sw_grid(max_elems, n), dim3(SW_THREADS), 0, (hipStream_t)stream,
-				   d_streams, d_list + at, d_idx, d_hdr, d_y, shift);
+		auto k = level == 13 ? acm_sw_prefix<1> : level == 14 ? acm_sw_prefix<2> : acm_sw_prefix<3>;
+		hipLaunchKernelGGL(k, dim3(gx, n), dim3(PREFIX_THREADS), 0, (hipStream_t)stream,
+				   d_streams, d_list + at, d_idx, d_hdr, d_y, 16 - level);
 		ACMK_CHECK_LAUNCH();
 	}
 	return 0;
