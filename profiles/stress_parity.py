@@ -1,4 +1,4 @@
-"""One-off large-scale parity run (GPU box): ~1.5 Gsamples of random-shaped streams (levels 0-12: register and tile
+"""One-off large-scale parity run (GPU box): ~1.5 Gsamples of random-shaped streams (levels 0-15: register, tile and prefix
 kernels; rows 1-64, mono/stereo, ragged), both tile-kernel flavours x both parse modes of acm_batch_decode against the
 CPU oracle.  usage: python profiles/stress_parity.py [seed]"""
 import sys, os, time
@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 shapes = []
 total = 0
 while total < 1.5e9:
-    level = int(rng.integers(0, 13)); rows = int(rng.integers(1, 65)); bl = rows << level
+    level = int(rng.integers(0, 16)); rows = int(rng.integers(1, 65)); bl = rows << level
     nb = int(rng.integers(max(1, 2000000 // bl // 4), max(2, 2000000 // bl)))
     shapes.append((level, rows, nb, int(rng.integers(1, 3)), int(rng.integers(0, bl))))
     total += nb * bl
