@@ -115,7 +115,8 @@ int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, ui
 int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       uint32_t level, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_y, void *stream);   /* levels 13-15: unpack + level-12 stages */
 int acmk_plane_tile_rows(void);                                 /* tile rows (incl. 2 halo rows) of the level-12 plane kernel */
-int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+int acmk_plane_grid(int cus);                                   /* persistent workgroups of that kernel */
+int acmk_launch_fused_plane(int cus, int carry, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
 			    const int32_t *d_plane, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_patch(const AcmDevPatch *d_patches, uint64_t n, int32_t *d_x, void *stream);
 int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,

@@ -389,7 +389,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	std::vector<std::vector<AcmTile2>> tiles2(16);
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
-	std::vector<std::vector<AcmTile>> prefix_tiles(16);
+	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
 	std::vector<uint8_t> plane_shift(n, 0);                /* levels 13-15: planes carry values scaled by 2^(16 - level) */
 	const bool prefix_allowed = !(flags & ACMHIP_PLAN_STAGEWISE) && !(getenv("ACM_PREFIX") && atoi(getenv("ACM_PREFIX")) == 0);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
@@ -522,6 +522,15 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const uint64_t emit_rows = (s.n_emit + 4095) >> 12;
 			for (uint64_t r = 0; r < emit_rows; r += T12)
 				prefix_tiles[s.level].push_back(AcmTile{ id, (int32_t)(w.row_begin + r), 0u, 0u });
+			{
+				/* the carry-mode table of the same stream (see tiles_carry above) */
+				const uint32_t TC = T12 + 2;
+				std::vector<AcmTile> &tc = prefix_tiles_carry[s.level];
+				if (w.row_begin > 0)
+					tc.push_back(AcmTile{ id, (int32_t)w.row_begin - (int32_t)TC, ACM_TILE_FRESH | ACM_TILE_DISCARD, 0u });
+				for (uint64_t r = 0; r < emit_rows; r += TC)
+					tc.push_back(AcmTile{ id, (int32_t)(w.row_begin + r), (r == 0 && w.row_begin == 0) ? ACM_TILE_FRESH : 0u, 0u });
+			}
 			prefix_lists[s.level].push_back((uint32_t)i);
 			grp_max_elems[s.level] = std::max(grp_max_elems[s.level], elems);
 			sw_max = std::max(sw_max, elems);
@@ -628,8 +637,10 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			g.max_elems = grp_max_elems[lv];
 			rc = to_device(dev, prefix_lists[lv], &g.d_list);
 			if (rc == ACMHIP_OK) {
-				g.ntiles = (uint32_t)prefix_tiles[lv].size();
-				rc = to_device(dev, prefix_tiles[lv], &g.d_tiles);
+				g.carry = carry_wanted(prefix_tiles_carry[lv].size(), (size_t)acmk_plane_grid(dev->cus), (size_t)acmk_plane_tile_rows());
+				const std::vector<AcmTile> &use = g.carry ? prefix_tiles_carry[lv] : prefix_tiles[lv];
+				g.ntiles = (uint32_t)use.size();
+				rc = to_device(dev, use, &g.d_tiles);
 			}
 			pl->prefix.push_back(g);
 			st.tiles += g.ntiles;
@@ -729,7 +740,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 					LAUNCHTRY(acmk_launch_stage(pl->d_streams, g.d_list, g.nlist, g.max_elems, g.level, k,
 								    pl->d_plane[cur], pl->d_plane[cur ^ 1], 16 - g.level, st));
 			}
-			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
+			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
 		}
 	}
 	return ACMHIP_OK;

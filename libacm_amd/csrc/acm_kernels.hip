@@ -611,6 +611,8 @@ struct FirstPass {
 	static constexpr int NB = RPS / 2;                      // bodies (row pairs) per segment
 	static constexpr bool WARM = NSEG > 1;                  // segments > 0 re-run the two rows in front of them
 	static constexpr int NRAW = (NB + (WARM ? 1 : 0)) * BODY;   // loaded registers: one per (row, q), W samples each
+	static constexpr bool PLANE = (ABL & MODE_PLANE) != 0;
+	static constexpr int NREG = NRAW * (PLANE ? W : 1);        // a plane holds int32: the second column of a lane sits NRAW further on
 	static_assert(W == 1 || W == 2, "1 or 2 adjacent columns per lane");
 	static_assert(SIGMA % W == 0 && TPS <= NT && NT % TPS == 0, "segment geometry");
 	static_assert(RPS >= 2 && RPS % 2 == 0 && NSEG * RPS == C::TR, "segments are whole row pairs");
@@ -620,7 +622,7 @@ struct FirstPass {
 	/* every staged index of this thread's walk, issued back to back (one HBM round trip): 2-byte loads for
 	 * W = 1, 4-byte loads (two adjacent columns) for W = 2.  Rows that do not exist are read from a clamped
 	 * address; their rowval is 0. */
-	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const TileCtx &t, const int tid)
+	static __device__ __forceinline__ void load(uint32_t (&raw)[NREG], const TileCtx &t, const int tid)
 	{
 		const int seg = tid / TPS;
 		const int i0 = (tid % TPS) * W;
@@ -630,7 +632,6 @@ struct FirstPass {
 		const int base_row = t.row_first - 2 < 0 ? 0 : (t.row_first - 2 > last_row ? last_row : t.row_first - 2);
 		const uint16_t *tbase = reinterpret_cast<const uint16_t *>(t.src) + ((size_t)base_row << L);   /* wave-uniform; per-lane offsets stay 32-bit */
 		const uint32_t *pbase = reinterpret_cast<const uint32_t *>(t.src) + ((size_t)base_row << L);   /* MODE_PLANE: t.src is an int32 plane */
-		static_assert(!(ABL & MODE_PLANE) || W == 1, "one column per lane from a plane");
 		/* interior tile (the common case): every row from row_first-2 to row_first+TR-1 exists, so the
 		 * offsets are lane-constant + compile-time constants; otherwise clamp each row into the stream */
 		const bool interior = (t.row_first >= 2) && (t.row_first + C::TR <= t.nrows);
@@ -653,7 +654,11 @@ struct FirstPass {
 					uint32_t x;
 					if (ABL & 1)
 						x = off0 + q;
-					else if (ABL & MODE_PLANE)
+					else if (PLANE && W == 2) {
+						const uint2 two = *reinterpret_cast<const uint2 *>(pbase + off0 + q * SIGMA);
+						x = two.x;
+						raw[NRAW + (b + (WARM ? 1 : 0)) * BODY + half * U + q] = two.y;
+					} else if (PLANE)
 						x = pbase[off0 + q * SIGMA];
 					else if (W == 1)
 						x = tbase[off0 + q * SIGMA];
@@ -667,7 +672,7 @@ struct FirstPass {
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
 	template <bool CARRY = false>
-	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NRAW], uint32_t *tile, const int32_t *rowval,
+	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NREG], uint32_t *tile, const int32_t *rowval,
 						       const int row_first, const int tid)
 	{
 		constexpr int LR_MIN = CARRY ? -2 : 0;          /* carry mode: the two rows above the tile carry weight */
@@ -680,7 +685,7 @@ struct FirstPass {
 			clear_hist<G>(h[w]);
 		/* the loads were issued a whole tile ago: touching the YOUNGEST one first makes the compiler emit a
 		 * single s_waitcnt vmcnt for all of them instead of one per consumer */
-		asm volatile("" :: "v"(raw[NRAW - 1]));
+		asm volatile("" :: "v"(raw[NREG - 1]));
 #ifdef ACM_EXP_NOWARM
 #define ACM_WARM_FROM 0
 #else
@@ -694,7 +699,15 @@ struct FirstPass {
 			const uint32_t b0 = (!(ABL & MODE_PLANE) && i0 == 0 && lr0 >= LR_MIN && row_first + lr0 >= 0) ? ONE : 0u;
 			const uint32_t b1 = (!(ABL & MODE_PLANE) && i0 == 0 && lr0 + 1 >= LR_MIN && row_first + lr0 + 1 >= 0) ? ONE : 0u;
 			uint32_t v[W][BODY];
-			if constexpr (W == 2 && U % 4 == 0) {
+			if constexpr (PLANE) {
+				/* rowval is a mask here: all ones for rows that exist, 0 for rows in front of / behind the stream
+				 * (they were read from a clamped address) */
+#pragma unroll
+				for (int w = 0; w < W; w++)
+#pragma unroll
+					for (int u = 0; u < BODY; u++)
+						v[w][u] = raw[w * NRAW + (b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
+			} else if constexpr (W == 2 && U % 4 == 0) {
 #pragma unroll
 				for (int u = 0; u < BODY; u += 4) {
 					const uint32_t *r = &raw[(b + (WARM ? 1 : 0)) * BODY + u];
@@ -706,12 +719,6 @@ struct FirstPass {
 						v[W - 1][u + k] = hi[k];
 					}
 				}
-			} else if constexpr ((ABL & MODE_PLANE) != 0) {
-				/* rowval is a mask here: all ones for rows that exist, 0 for rows in front of / behind the stream
-				 * (they were read from a clamped address) */
-#pragma unroll
-				for (int u = 0; u < BODY; u++)
-					v[0][u] = raw[(b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
 			} else {
 #pragma unroll
 				for (int w = 0; w < W; w++)
@@ -979,7 +986,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		cur.fresh = true;
 		cur.discard = true;
 	}
-	uint32_t raw[FP::NRAW];
+	uint32_t raw[FP::NREG];
 	int32_t hv[NRV];
 	fetch_vals(hv, cur);
 	FP::load(raw, cur, tid);
@@ -1575,8 +1582,9 @@ inline const Tile2Entry &tile2_entry(uint32_t level)
 }
 
 /* levels 13-15: the stage-wise kernels apply the first level-12 stages into an int32 plane, this level-12 build of the tile
- * kernel (halo flavour, one 128 KB tile per CU) reads the plane and does the other twelve */
-const FusedEntry g_fused_plane = { acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 1, false, 3, 3, 3, 3>, 512, 8, 1, nullptr };
+ * kernel (one 128 KB tile per CU; halo or carry flavour like every other group) reads the plane and does the other twelve */
+const FusedEntry g_fused_plane = { acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 2, false, 3, 3, 3, 3>, 512, 8, 1,
+				   acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 2, true, 3, 3, 3, 3> };
 
 inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 {
@@ -1760,7 +1768,12 @@ extern "C" int acmk_plane_tile_rows(void)
 }
 
 /* d_plane stands where the staged indices stand in acmk_launch_fused; the streams' idx_off count int32 units into it */
-extern "C" int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
+extern "C" int acmk_plane_grid(int cus)
+{
+	return (cus > 0 ? cus : 256) * g_fused_plane.wg_per_cu;
+}
+
+extern "C" int acmk_launch_fused_plane(int cus, int carry, const AcmDevStream *d_streams, const AcmTile *d_tiles, uint32_t ntiles,
 				       const int32_t *d_plane, int16_t *d_pcm, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
@@ -1768,7 +1781,7 @@ extern "C" int acmk_launch_fused_plane(int cus, const AcmDevStream *d_streams, c
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * g_fused_plane.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(g_fused_plane.fn, dim3(grid), dim3(g_fused_plane.threads), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(carry ? g_fused_plane.fn_carry : g_fused_plane.fn, dim3(grid), dim3(g_fused_plane.threads), 0, (hipStream_t)stream,
 			   d_streams, d_tiles, ntiles, reinterpret_cast<const int16_t *>(d_plane), nullptr, d_pcm, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;

@@ -86,11 +86,14 @@ def test_stagewise_matrix(dev, level, rows):
     assert st.stagewise_streams == 1
 
 
+@pytest.mark.parametrize("carry", ["0", "1"])
 @pytest.mark.parametrize("level", [13, 14, 15])
 @pytest.mark.parametrize("rows", [1, 2, 5])
-def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows):
-    """levels above the tile kernel's: level - 12 stage-wise stages into a scaled plane, then the level-12 tile kernel on
-    the plane (decode.c:566-571: the later stages of level L are the cascade of level L - j on the same sample sequence)"""
+def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows, carry, monkeypatch):
+    """levels above the tile kernel's: the first level - 12 stages (acm_sw_prefix) into a scaled plane, then the level-12 tile
+    kernel, halo and carry flavour, on the plane (decode.c:566-571: the later stages of level L are the cascade of level
+    L - j on the same sample sequence)"""
+    monkeypatch.setenv("ACM_K1_CARRY", carry)
     f = make_stream(8000 + level * 10 + rows, level, rows, 3, cut=7, val_max=65535, pwr_max=15)
     g = make_stream(8100 + level * 10 + rows, level, rows, 2, channels=2)
     st = check_streams(dev, [f, g])
@@ -99,8 +102,26 @@ def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows):
         check_streams(dev, [f], fmt=fmt)
 
 
-def test_level_13_window_and_patches(dev):
+@pytest.mark.parametrize("carry", ["0", "1"])
+@pytest.mark.parametrize("level,rows,blocks", [(13, 5, 30), (14, 3, 27), (15, 2, 35)])
+def test_levels_13_to_15_long_streams(dev, level, rows, blocks, carry, monkeypatch):
+    """more rows than one chunk of the prefix sweep (64) and than one tile of the plane kernel; windows that start inside"""
+    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    f = make_stream(8400 + level, level, rows, blocks, cut=11)
+    check_streams(dev, [f])
+    s = capi.stage_file(f)
+    want, _ = oracle_pcm(f)
+    cols = 1 << level
+    for row_begin in (1, 63, 64, 66):
+        n_emit = (s.info.blocks * rows - row_begin) * cols - 11
+        got = capi.synth(dev, [s], windows=[(row_begin, n_emit)])[0]
+        assert np.array_equal(got, want[row_begin * cols: row_begin * cols + n_emit]), row_begin
+
+
+@pytest.mark.parametrize("carry", ["0", "1"])
+def test_level_13_window_and_patches(dev, carry, monkeypatch):
     """the prefix path with a window that starts inside the stream, and with H1 patches (scaled like the plane)"""
+    monkeypatch.setenv("ACM_K1_CARRY", carry)
     f = make_stream(8300, 13, 2, 5)
     s = capi.stage_file(f)
     want, _ = oracle_pcm(f)
