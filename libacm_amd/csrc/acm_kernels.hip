@@ -30,9 +30,11 @@
  *     (+2/T halo, mostly L2 hits) + 2 B written per sample.  Two VALU ops per butterfly (sign folding +
  *     v_mad_i32_i24); measured limit is instruction issue, not HBM.
  *   acm_small_level (levels 0..4): the whole cascade in one thread's registers.
- *   stage-wise kernels (any level 0..15; tiles that can see an H1 patch; levels 13..15): unpack to an int32 plane,
- *     one elementwise launch per stage (ping-pong planes), emit.  8*level B of
- *     HBM traffic per sample; generic fallback and cross-check.
+ *   levels 13..15: acm_sw_prefix (unpack + the first level-12 stages, a register cascade per residue mod 4096, into an
+ *     int32 plane) + the plane-input build of the level-12 tile kernel (MODE_PLANE).  12 B of HBM traffic per sample.
+ *   stage-wise kernels (any level 0..15; tiles that can see an H1 patch; patched streams of levels 13..15): unpack
+ *     to an int32 plane, one elementwise launch per stage (ping-pong planes), emit.  8*level B of HBM traffic per
+ *     sample; generic fallback and cross-check.
  *
  * Integer add/shift only: bound by HBM (and LDS/VALU at high levels), no MFMA.
  */
