@@ -508,12 +508,15 @@ def main():
             try:
                 files = [f.tobytes() for f in batch.files]
                 e2e = {"streams": len(files), "host_threads": workload_cpus()}
-                for name, mode in (("host_parse", capi.PARSE_HOST), ("device_parse", capi.PARSE_DEVICE)):
-                    capi.batch_decode(dev, files, threads=0, parse=mode)          # first call sizes the arenas
-                    res, tm = capi.batch_decode(dev, files, threads=0, parse=mode)
+                for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("device_parse", capi.PARSE_DEVICE, False),
+                                        ("device_parse_pinned_out", capi.PARSE_DEVICE, True)):
+                    # pinned_out: the caller's PCM buffers are pinned (acmhip_host_alloc), read-back lands in them directly
+                    capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)          # first call sizes the arenas
+                    res, tm = capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
                     e2e[name] = {"msamples_s": round(tm.samples / tm.total_s / 1e6, 1), "parse_s": round(tm.stage_s, 3),
                                  "h2d_s": round(tm.h2d_s, 3), "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
                                  "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed}
+                    del res
                 out["end_to_end"] = e2e
             except Exception as e:
                 out["end_to_end"] = {"error": str(e)[:200]}

@@ -205,22 +205,26 @@ typedef struct acm_batch_opts {
 	int      threads;        /* host staging threads, 0 = hardware concurrency */
 	unsigned plan_flags;     /* ACMHIP_PLAN_* */
 	unsigned parse;          /* ACM_BATCH_PARSE_* */
-	unsigned reserved;
+	unsigned flags;          /* ACM_BATCH_* below (0: none) */
 	void    *d_pcm;          /* NULL: PCM goes to items[i].pcm in host memory.  Otherwise a device buffer of
 	                            d_pcm_words 16-bit words (>= acm_batch_pcm_words()): PCM stays in HBM, stream i at
 	                            d_pcm + items[i].dev_off, nothing is copied back (items[i].pcm is ignored) */
 	uint64_t d_pcm_words;
 } acm_batch_opts;
 
+/* opts->flags */
+#define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
+                                       the PCM straight into it, stream by stream, instead of through the library's own pinned
+                                       arena and a host copy (taken for streams of 64 KB of PCM and more on average) */
+
 /* where the bit parsing of a batch runs */
 #define ACM_BATCH_PARSE_HOST   0u   /* host thread pool (default; the exact reader, any stream) */
 #define ACM_BATCH_PARSE_DEVICE 1u   /* one GPU lane per stream for clean streams; streams the device parser is not
                                        sure about (data running out, corrupt symbols, hazard H1, files >= 256 MiB) are
                                        re-parsed by the host reader.  Pays off for thousands of streams per batch. */
-#define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch is worth at least 16 x threads streams of its longest
-                                       stream's size (9 x threads up to 2048 streams, which are walked on the scalar
-                                       unit), HOST below that: walking a stream is sequential, and one GPU lane walks
-                                       9-16x slower than one host core parses */
+#define ACM_BATCH_PARSE_AUTO   2u   /* DEVICE when the batch is worth at least 5 x threads streams of its longest stream's
+                                       size (9 x from 1024 streams, 16 x from 32 K streams on), HOST below that: walking a
+                                       stream is sequential, and a wavefront walks 5-16x slower than one host core parses */
 
 typedef struct acm_batch_timing {
 	double stage_s;          /* wall clock until the last stream was bit-parsed (headers included, allocation not) */

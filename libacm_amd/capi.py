@@ -52,7 +52,7 @@ class BatchItem(C.Structure):
 
 class BatchOpts(C.Structure):
     _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint),
-                ("parse", C.c_uint), ("reserved", C.c_uint), ("d_pcm", C.c_void_p), ("d_pcm_words", C.c_uint64)]
+                ("parse", C.c_uint), ("flags", C.c_uint), ("d_pcm", C.c_void_p), ("d_pcm_words", C.c_uint64)]
 
 
 class BatchTiming(C.Structure):
@@ -348,22 +348,46 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
 PARSE_HOST, PARSE_DEVICE, PARSE_AUTO = 0, 1, 2
 
 
-def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST):
-    """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming)."""
+BATCH_PCM_PINNED = 1
+
+
+def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST, pinned=False):
+    """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming).
+
+    pinned=True: the output buffers are carved from one pinned arena (acmhip_host_alloc) and the call is told so
+    (ACM_BATCH_PCM_PINNED: the read-back engine writes them directly); the arrays returned are copies."""
     n = len(files)
     bufs = [_as_u8(f) for f in files]
     infos = [probe(b, force_chans) for b in bufs]
-    outs = [np.zeros(i.total_values if rc == 0 else 0, dtype=np.uint16) for rc, i in infos]
+    sizes = [i.total_values if rc == 0 else 0 for rc, i in infos]
+    arena = C.c_void_p()
+    if pinned:
+        offs, at = [], 0
+        for sz in sizes:
+            offs.append(at)
+            at += (sz + 63) // 64 * 64
+        _check(lib().acmhip_host_alloc(max(at, 1) * 2, C.byref(arena)), "acmhip_host_alloc")
+        whole = np.ctypeslib.as_array(C.cast(arena, C.POINTER(C.c_uint16)), shape=(max(at, 1),))
+        whole[:] = 0
+        outs = [whole[o:o + sz] for o, sz in zip(offs, sizes)]
+    else:
+        outs = [np.zeros(sz, dtype=np.uint16) for sz in sizes]
     items = (BatchItem * max(n, 1))()
     for k in range(n):
         items[k].data = bufs[k].ctypes.data
         items[k].len = bufs[k].size
         items[k].pcm = outs[k].ctypes.data if outs[k].size else None
         items[k].pcm_cap = outs[k].size
-    opts = BatchOpts(force_chans, fmt, threads, flags, parse)
+    opts = BatchOpts(force_chans, fmt, threads, flags, parse, BATCH_PCM_PINNED if pinned else 0)
     tm = BatchTiming()
-    _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
-    return [(items[k].status, outs[k][:items[k].words]) for k in range(n)], tm
+    try:
+        _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
+        res = [(items[k].status, outs[k][:items[k].words].copy() if pinned else outs[k][:items[k].words]) for k in range(n)]
+    finally:
+        if pinned:
+            del outs, whole
+            lib().acmhip_host_free(arena)
+    return res, tm
 
 
 def _batch_items(files):

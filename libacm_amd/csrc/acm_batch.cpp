@@ -244,6 +244,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	}
 	const uint64_t pcm_total = idx_total;
 	const bool keep_on_device = opts.d_pcm != nullptr;
+	/* pinned caller buffers: the copy engine writes every stream's PCM where the caller wants it (one transfer per
+	 * stream, so only for streams big enough that the per-transfer cost disappears) */
+	const bool direct_out = !keep_on_device && (opts.flags & ACM_BATCH_PCM_PINNED) && n > 0 && pcm_total / n >= 32768;
 	if (keep_on_device && opts.d_pcm_words < pcm_total)
 		return ACMHIP_ERR_ARG;
 	for (size_t i = 0; i < n; i++)
@@ -348,9 +351,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	/* arenas live in the device handle and are reused by the next batch */
 	acmhip_arena_lock(dev);
 	BTRY(acmhip_copy_stream(dev, (void **)&st_copy));
-	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
-	BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
-	if (!keep_on_device)
+	if (!dev_parse) {                       /* with device parsing the host staging arenas come later, and only if a stream needs them */
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
+	}
+	if (!keep_on_device && !direct_out)
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
@@ -465,6 +470,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		for (size_t i = 0; i < n; i++)
 			if (slots[i].ok && !on_dev[i])
 				host_ids.push_back(i);              /* ascending, i.e. arena order */
+		if (!host_ids.empty()) {
+			const auto ta = clk::now();
+			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
+			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
+			tm.alloc_s += secs(ta, clk::now());
+		}
 	}
 	tm.host_parsed = host_ids.size();
 	for (size_t i : host_ids)
@@ -473,7 +484,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	/* 2b. the pool: parse in arena order, then copy finished PCM out as the chunks come back */
 	std::vector<size_t> out_ids;
 	for (size_t i = 0; i < n; i++)
-		if (slots[i].ok && items[i].pcm && !keep_on_device)
+		if (slots[i].ok && items[i].pcm && !keep_on_device && !direct_out)
 			out_ids.push_back(i);
 	std::atomic<size_t> parsed{ 0 };
 	clk::time_point t_parsed = clk::now();
@@ -565,9 +576,18 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			HTRY(hipEventRecord(ch.ev[2], st_main));
 			HTRY(hipStreamWaitEvent(st_copy, ch.ev[2], 0));
 			HTRY(hipEventRecord(ch.ev[3], st_copy));
-			if (!keep_on_device)
+			if (direct_out) {
+				for (size_t i = ch.first; i < ch.last; i++) {
+					const Slot &s = slots[i];
+					if (!s.ok || !items[i].pcm || items[i].words == 0)
+						continue;
+					const uint64_t w = std::min<uint64_t>(items[i].words, items[i].pcm_cap);
+					HTRY(hipMemcpyAsync(items[i].pcm, d_pcm + s.pcm_off, w * sizeof(int16_t), hipMemcpyDeviceToHost, st_copy));
+				}
+			} else if (!keep_on_device) {
 				HTRY(hipMemcpyAsync(h_pcm + ch.idx_begin, d_pcm + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
 						    hipMemcpyDeviceToHost, st_copy));
+			}
 		}
 		HTRY(hipEventRecord(ch.ev[4], st_copy));
 		{

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "acm_hip.h"
@@ -241,13 +242,19 @@ static int slurp(const char *name, unsigned char **data, size_t *len)
  *   reader   slurps the files of group g+1, reads their headers and carves one pinned PCM arena per group
  *   decoder  (this thread) runs acm_batch_decode on group g
  *   writers  write the WAV / raw files of group g-1 from a small thread pool, then release the group
- * At most three groups exist at a time, whatever the length of the file list.
+ * At most three groups exist at a time, whatever the length of the file list; their PCM arenas are pinned once and reused,
+ * and the read-back engine writes every file's PCM straight into them (ACM_BATCH_PCM_PINNED).
  */
+typedef struct barena {                 /* PCM of one group; pinned when the device hands it out, else malloc */
+	void *mem;
+	size_t cap;
+	int pinned, busy;
+} barena;
+
 typedef struct bgroup {
 	int first, n;                   /* names[first .. first + n) */
 	acm_batch_item *items;
-	void *arena;                    /* PCM of the whole group: pinned when the device hands it out, else malloc */
-	int arena_pinned;
+	barena *arena;
 	acm_batch_timing tm;
 	int rc;
 	struct bgroup *next;
@@ -310,10 +317,22 @@ static struct {
 	pthread_cond_t cv;
 	int groups_alive;               /* read but not yet written out and freed */
 	acm_batch_timing total;
+	barena arenas[3];               /* one per group in flight, reused: pinning and unpinning a gigabyte costs 0.1-0.2 s each */
 } bt;
 
-#define BATCH_GROUPS_IN_FLIGHT 3
+#define BATCH_GROUPS_IN_FLIGHT 3        /* == number of bt.arenas */
 #define BATCH_WRITERS 4
+
+/* ACMTOOL_BATCH_TRACE=1: wall-clock notes of the three stages on stderr (diagnostics; profiles/cli_batch_probe.sh) */
+static int bt_trace;
+static double bt_t0;
+static double bt_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+#define BT_NOTE(...) do { if (bt_trace) { fprintf(stderr, "[batch %.3f] ", bt_now() - bt_t0); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 static void *batch_reader(void *unused)
 {
@@ -329,6 +348,7 @@ static void *batch_reader(void *unused)
 		bt.groups_alive++;
 		pthread_mutex_unlock(&bt.mu);
 		g->first = i;
+		BT_NOTE("reader: group from file %d", i);
 		g->items = calloc((size_t)(bt.nfiles - i), sizeof(*g->items));
 		while (i < bt.nfiles && (g->n == 0 || bytes < bt.budget)) {
 			acm_batch_item *it = &g->items[g->n];
@@ -346,18 +366,41 @@ static void *batch_reader(void *unused)
 		}
 		/* one arena per group, every file's PCM on a 128-byte boundary inside it; pinned memory lets the
 		 * read-back copy engine write it without a bounce buffer */
+		BT_NOTE("reader: %d files read, %zu MB of PCM to come", g->n, pcm_words * 2 >> 20);
 		if (pcm_words) {
-			if (acmhip_host_alloc(pcm_words * 2, &g->arena) == ACMHIP_OK)
-				g->arena_pinned = 1;
-			else
-				g->arena = malloc(pcm_words * 2);
+			/* groups_alive bounds the groups in flight to the number of arenas: one is free.  It is kept when big
+			 * enough; a new one is sized for a whole budget unless this is the only group */
+			barena *a = NULL;
+			pthread_mutex_lock(&bt.mu);
+			for (k = 0; k < BATCH_GROUPS_IN_FLIGHT && !a; k++)
+				if (!bt.arenas[k].busy)
+					a = &bt.arenas[k];
+			a->busy = 1;
+			pthread_mutex_unlock(&bt.mu);
+			if (a->cap < pcm_words * 2) {
+				size_t want = pcm_words * 2;
+				if (!(g->first == 0 && i == bt.nfiles) && want < bt.budget)
+					want = bt.budget;
+				if (a->mem) {
+					if (a->pinned)
+						acmhip_host_free(a->mem);
+					else
+						free(a->mem);
+				}
+				a->pinned = acmhip_host_alloc(want, &a->mem) == ACMHIP_OK;
+				if (!a->pinned)
+					a->mem = malloc(want);
+				a->cap = a->mem ? want : 0;
+			}
+			g->arena = a;
 		}
 		for (k = 0; k < g->n; k++) {
-			if (g->items[k].pcm_cap && g->arena) {
-				g->items[k].pcm = (int16_t *)g->arena + at;
+			if (g->items[k].pcm_cap && g->arena && g->arena->mem) {
+				g->items[k].pcm = (int16_t *)g->arena->mem + at;
 				at += (g->items[k].pcm_cap + 63) & ~(size_t)63;
 			}
 		}
+		BT_NOTE("reader: arena ready");
 		bq_push(&bt.to_decode, g);
 	}
 	bq_push(&bt.to_decode, NULL);
@@ -451,6 +494,7 @@ static void *batch_writer(void *unused)
 				memset(it->pcm + it->words, 0, (size_t)(whole - it->words) * 2);
 			}
 		}
+		BT_NOTE("writer: group of %d files", g->n);
 		job.g = g;
 		job.next = 0;
 		nth = g->rc == ACMHIP_OK ? (g->n < BATCH_WRITERS ? g->n : BATCH_WRITERS) : 0;
@@ -458,15 +502,15 @@ static void *batch_writer(void *unused)
 			pthread_create(&th[k], NULL, batch_write_worker, &job);
 		for (k = 0; k < nth; k++)
 			pthread_join(th[k], NULL);
+		BT_NOTE("writer: files written");
 		for (k = 0; k < g->n; k++)
 			free((void *)g->items[k].data);
-		if (g->arena_pinned)
-			acmhip_host_free(g->arena);
-		else
-			free(g->arena);
 		free(g->items);
-		free(g);
+		BT_NOTE("writer: group released");
 		pthread_mutex_lock(&bt.mu);
+		if (g->arena)
+			g->arena->busy = 0;
+		free(g);
 		bt.groups_alive--;
 		pthread_cond_broadcast(&bt.cv);
 		pthread_mutex_unlock(&bt.mu);
@@ -489,7 +533,8 @@ static int decode_batch(int nfiles, char **names)
 	memset(&bt, 0, sizeof(bt));
 	bt.nfiles = nfiles;
 	bt.names = names;
-	bt.budget = (size_t)(mb && atoi(mb) > 0 ? atoi(mb) : 1024) << 20;      /* file images + PCM per group */
+	bt.budget = (size_t)(mb && atoi(mb) > 0 ? atoi(mb) : 128) << 20;       /* file images + PCM per group: small groups keep the pinned
+											 * footprint (0.2 s per gigabyte to pin, as much to unpin) low */
 	if (bb && atol(bb) > 0)
 		bt.budget = (size_t)atol(bb);
 	bq_init(&bt.to_decode);
@@ -497,15 +542,22 @@ static int decode_batch(int nfiles, char **names)
 	pthread_mutex_init(&bt.mu, NULL);
 	pthread_cond_init(&bt.cv, NULL);
 
+	bt_trace = getenv("ACMTOOL_BATCH_TRACE") != NULL;
+	bt_t0 = bt_now();
 	rc = acmhip_device_open(0, NULL, &dev);
 	if (rc != ACMHIP_OK) {
 		fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
 		return 1;
 	}
+	BT_NOTE("device open");
 	pthread_create(&reader, NULL, batch_reader, NULL);
 	pthread_create(&writer, NULL, batch_writer, NULL);
 	while ((g = bq_pop(&bt.to_decode)) != NULL) {
+		BT_NOTE("decoder: group of %d files", g->n);
+		opts.flags = (g->arena && g->arena->pinned) ? ACM_BATCH_PCM_PINNED : 0;
 		g->rc = failed ? ACMHIP_ERR_ARG : acm_batch_decode(dev, g->items, (size_t)g->n, &opts, &g->tm);
+		BT_NOTE("decoder: done (parse %.3f h2d %.3f kernel %.3f d2h %.3f total %.3f, device-parsed %llu)", g->tm.stage_s, g->tm.h2d_s,
+			g->tm.kernel_s, g->tm.d2h_s, g->tm.total_s, (unsigned long long)g->tm.device_parsed);
 		if (g->rc != ACMHIP_OK && !failed) {
 			fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
 			failed = 1;
@@ -528,7 +580,17 @@ static int decode_batch(int nfiles, char **names)
 		printf("batch: %llu samples, alloc %.3fs parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
 		       (unsigned long long)bt.total.samples, bt.total.alloc_s, bt.total.stage_s, bt.total.h2d_s,
 		       bt.total.kernel_s, bt.total.d2h_s, bt.total.total_s);
+	{
+		int k;
+		for (k = 0; k < BATCH_GROUPS_IN_FLIGHT; k++) {
+			if (bt.arenas[k].mem && bt.arenas[k].pinned)
+				acmhip_host_free(bt.arenas[k].mem);
+			else
+				free(bt.arenas[k].mem);
+		}
+	}
 	acmhip_device_close(dev);
+	BT_NOTE("done");
 	return failed;
 }
 

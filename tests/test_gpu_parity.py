@@ -361,6 +361,24 @@ def test_batch_parse_auto_many_streams(dev):
         assert hs == ds and np.array_equal(hp, dp), k
 
 
+@pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE])
+def test_batch_pinned_output_buffers(dev, parse):
+    """ACM_BATCH_PCM_PINNED: PCM is read back straight into the caller's pinned buffers, stream by stream (big streams) or
+    through the arena as usual (a batch of small ones); truncated and broken files among them"""
+    big = [make_stream(9300 + i, 7 + i % 3, 16, 6 + i % 5, channels=1 + i % 2, cut=i % 7) for i in range(24)]
+    big[5] = big[5][:len(big[5]) // 2]
+    big[11] = b"RIFFnope"
+    small = [make_stream(9400 + i, 5, 4, 1 + i % 3, cut=i % 3) for i in range(40)]
+    for files in (big, small, big + small):
+        want, _ = capi.batch_decode(dev, files, threads=4, parse=parse)
+        got, tm = capi.batch_decode(dev, files, threads=4, parse=parse, pinned=True)
+        for k, ((ws, wp), (gs, gp)) in enumerate(zip(want, got)):
+            assert ws == gs and np.array_equal(wp, gp), k
+    for k in (0, 7, 23):
+        ref, _ = oracle_pcm(big[k])
+        assert np.array_equal(got[k][1], ref), k
+
+
 def test_device_walk_k_columns(dev):
     """the wave-per-stream walk (acm_parse.hip: acm_parse_scan_wave) on streams that hold ONE k-filler each: every k code,
     rows around the 16-row switch of the jump table, one row, tall columns that need several 64-bit windows, columns
