@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 for t in r2_level9 r2_level7; do
   src=gpurun_out/prof_$t
   cp $src/summary.txt profiles/${t}_summary.txt
-  cp $(ls $src/trace/*/*kernel_stats.csv | head -1) profiles/${t}_kernel_stats.csv
+  cp $(ls -t $src/trace/*/*kernel_stats.csv | head -1) profiles/${t}_kernel_stats.csv       # newest: gpurun merges every call into gpurun_out/
   cp $src/bench_trace.json profiles/${t}_bench_profiled.json
   cp $src/bench_unprofiled.json profiles/${t}_bench.json
 done
