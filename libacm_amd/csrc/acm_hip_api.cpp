@@ -45,6 +45,7 @@ struct acmhip_device {
 	hipStream_t stream;
 	bool own_stream;
 	hipStream_t copy_stream = nullptr;      /* read-back stream of the batch pipeline, created on first use */
+	hipStream_t side[2] = { nullptr, nullptr };     /* plans with several level groups spread them over these too */
 	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
@@ -83,6 +84,10 @@ struct acmhip_plan {
 	uint64_t plane_elems = 0;
 	acmhip_plan_stats stats{};
 	int variant = 0;                        /* fused-kernel variant the tile tables were cut for */
+	/* several tile-kernel groups (a corpus of mixed levels): their launches are independent, so they go round robin
+	 * over the device stream and two side streams - the ramp-up and the tail of one launch overlap the next one's
+	 * instead of leaving the chip half empty three times (fork / join by events on the device stream) */
+	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
 };
 
 extern "C" const char *acmhip_last_error(void)
@@ -152,6 +157,9 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 	}
 	if (dev->copy_stream)
 		(void)hipStreamDestroy(dev->copy_stream);
+	for (hipStream_t s : dev->side)
+		if (s)
+			(void)hipStreamDestroy(s);
 	if (dev->own_stream)
 		(void)hipStreamDestroy(dev->stream);
 	delete dev;
@@ -350,6 +358,11 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	}
 	for (auto &g : plan->small)
 		(void)hipFree(g.d_list);
+	if (plan->ev_fork)
+		(void)hipEventDestroy(plan->ev_fork);
+	for (hipEvent_t e : plan->ev_join)
+		if (e)
+			(void)hipEventDestroy(e);
 	(void)hipFree(plan->d_sink);
 	(void)hipFree(plan->d_sw_all);
 	(void)hipFree(plan->d_patches);
@@ -680,6 +693,19 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		acmhip_plan_destroy(pl);
 		return rc;
 	}
+	if (pl->fused.size() > 1 && !(getenv("ACM_PLAN_STREAMS") && atoi(getenv("ACM_PLAN_STREAMS")) <= 1)) {
+		hipError_t e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+		for (int k = 0; k < 2 && e == hipSuccess; k++) {
+			e = hipEventCreateWithFlags(&pl->ev_join[k], hipEventDisableTiming);
+			if (e == hipSuccess && !dev->side[k])
+				e = hipStreamCreateWithFlags(&dev->side[k], hipStreamNonBlocking);
+		}
+		if (e != hipSuccess) {
+			rc = hip_fail(e, "side streams of a multi-level plan");
+			acmhip_plan_destroy(pl);
+			return rc;
+		}
+	}
 	pl->stats = st;
 	*out = pl;
 	return ACMHIP_OK;
@@ -704,10 +730,25 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		return ACMHIP_ERR_ARG;
 	void *st = (void *)pl->dev->stream;
 
+	const bool spread = pl->ev_fork != nullptr;
+	if (spread) {
+		HIPTRY(hipEventRecord(pl->ev_fork, pl->dev->stream));
+		for (int k = 0; k < 2; k++)
+			HIPTRY(hipStreamWaitEvent(pl->dev->side[k], pl->ev_fork, 0));
+	}
+	size_t gi = 0;
 	for (const LevelGroup &g : pl->fused) {
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, st));
-		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, st));
-		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, st));
+		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
+		gi++;
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
+		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
+	}
+	if (spread) {
+		for (int k = 0; k < 2; k++) {
+			HIPTRY(hipEventRecord(pl->ev_join[k], pl->dev->side[k]));
+			HIPTRY(hipStreamWaitEvent(pl->dev->stream, pl->ev_join[k], 0));
+		}
 	}
 
 	for (const LevelGroup &g : pl->small)
