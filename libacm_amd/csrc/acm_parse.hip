@@ -261,9 +261,9 @@ acm_parse_scan_lone(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 /*
  * One stream per wavefront, the wavefront as the scalar walk's register file.
  *
- * The scalar walk above spends ~600 cycles on a fixed-length column and ~2700 on a 16-row k-column (measured, one
- * filler per stream: profiles/r2_parse_probe.txt): a dependent scalar load per column, the code -> length decision as
- * a tree of branches, and ~12 dependent scalar instructions per k-symbol.  Here
+ * Round 1's scalar walk (scan_stream<true>, still built with ACM_TUNING for A/B runs) spends ~600 cycles on a fixed-length
+ * column and ~2700 on a 16-row k-column (measured, one filler per stream: profiles/r2_parse_probe.txt): a dependent scalar
+ * load per column, the code -> length decision as a tree of branches, and ~12 dependent scalar instructions per k-symbol.  Here
  *   - the bitstream window is 65 consecutive dwords held one (dword, next dword) pair per lane, loaded coalesced once
  *     per ~1900 bits; any 64 bits of it are two v_readlane away;
  *   - code -> column length and code -> k-prefix table are v_readlane lookups in per-lane tables;
