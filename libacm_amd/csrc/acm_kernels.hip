@@ -893,6 +893,24 @@ __device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned
 }
 
 /*
+ * Wave priorities (s_setprio).  The four workgroups of a CU are in different phases of their tiles, and a SIMD issues one
+ * instruction at a time: when a wave in an LDS pass (read, wait, butterflies, write - latency-bound) competes with a wave in
+ * its first pass (a long run of VALU work that can run any time), the LDS-pass wave must win, or its LDS round trips queue
+ * up behind arithmetic that is not urgent.  Measured on the level-9 batch (same box, interleaved runs): 0.542 of the roofline
+ * with equal priorities, 0.568-0.580 with the LDS passes above the first pass, 0.543-0.545 with the first pass at or above
+ * them; the exact levels do not matter (1 against 0 gains as much as 3 against 2), nor does ranking the LDS passes among
+ * themselves.  Loads and the waits stay at 0.  Level 7 +2 %, 8 +3 %, 9 +6.5 %, 10 +9 %, 11 +5 % (profiles/ab_levels.sh).
+ * With one workgroup per CU (level 12) every wave of a SIMD is in the same phase and the priorities only cost (-3 %): off.
+ */
+template <bool ON, int P>
+__device__ __forceinline__ void phase_prio()
+{
+	if constexpr (ON)
+		__builtin_amdgcn_s_setprio(P);
+}
+constexpr int PRIO_IDLE = 0, PRIO_FIRST_PASS = 2, PRIO_LDS_PASSES = 3;
+
+/*
  * Persistent workgroups: workgroup w handles tiles w, w + gridDim.x, ...  While the LDS passes of tile n
  * run, the staged indices and block headers of tile n+1 are already on their way from HBM (registers), so
  * the only exposed memory latency is the very first tile's.
@@ -910,6 +928,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	static_assert(!(ABL & MODE_PLANE) || !NEG_ODD_ROWS, "a plane comes with plain signs");
 	constexpr int NRV = (TR + 2 + NT - 1) / NT;             // rowval entries per thread
 	using FP = FirstPass<C, G0, W0, ABL>;
+	constexpr bool PRIO = WAVES_PER_SIMD * 256 / NT > 1;    // several workgroups per CU: see phase_prio
 
 	constexpr int GUARD = NELEM / 32 + 64;                  // zeros in front of the tile: segment 0's warm-up reads land here
 	__shared__ uint32_t tile_mem[GUARD + NELEM + (NELEM >> C::PS)];
@@ -1007,7 +1026,9 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		}
 		__syncthreads();                                /* rowval[buf] complete; previous write-out done with the tile */
 		ACM_STAMP(0);
+		phase_prio<PRIO, PRIO_FIRST_PASS>();
 		FP::template compute<CARRY>(raw, tile, rowval[buf], cur.row_first, tid);
+		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
 		/* prefetch the next tile: context (scalar), headers and staged indices (registers) */
@@ -1021,8 +1042,10 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		}
 
 		ACM_STAMP(2);
+		phase_prio<PRIO, PRIO_LDS_PASSES>();
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, CARRY, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(3);
 		__syncthreads();
 		ACM_STAMP(4);
@@ -1390,6 +1413,7 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
  * not do is copy or spill such a register between its load and the wait (it would copy the old content);
  * tests/test_isa_invariants.py checks the generated code for that.
  */
+
 template <int YOUNGER>
 __device__ __forceinline__ void k2_wait()
 {
@@ -1406,6 +1430,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
 	using FP = FirstPass2<C, G0, 2, ABL>;
 	static_assert(TR + 2 <= NT, "one row value per thread");
+	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
 
 	__shared__ uint32_t tile_mem[8 + NELEM + (NELEM >> C::PS)];     /* no guard zone: segment 0 always reads the carry */
 	__shared__ int32_t rowval[2][TR + 2];
@@ -1429,7 +1454,6 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 
 	const uint32_t voff = FP::lane_offset(tid);
 	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
-	constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
 
 	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589).  Every lane of every
 	 * wave issues the load (lanes beyond the tile repeat its last row) so that all waves count the same vector-memory
@@ -1493,7 +1517,9 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		__syncthreads();
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
+		phase_prio<PRIO, PRIO_FIRST_PASS>();
 		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
 		hv = fetch_val(nxt);                            /* the last tile of a run fetches its own again: no branch around the loads */
@@ -1501,6 +1527,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
 		FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
+		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
 		ACM_STAMP(3);
@@ -1530,6 +1557,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		/* the next tile's staged indices were requested from inside the LDS passes; behind them only this tile's PCM
 		 * stores may still be on their way.  (Waiting here, inside the iteration that issued the loads, keeps the loaded
 		 * registers out of any copy the compiler places on the loop's back edge.) */
+		phase_prio<PRIO, PRIO_IDLE>();
 		k2_wait<NSTORE>();
 		ACM_STAMP(6);
 		if (!more)
