@@ -1597,13 +1597,17 @@ const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 /* per level the fastest measured geometry and stage grouping (profiles/r2_sweep_levels.txt): 32 KB tiles at four workgroups
  * per CU up to level 10, 64 KB tiles of 512 threads (two workgroups, still four waves per SIMD) above; passes of at most
  * three stages, because with 32-element walks the warm-up of a four-stage pass costs as much as a pass */
+/* per level the fastest measured geometry and stage grouping with the phase priorities on (profiles/r2_sweep_levels.txt;
+ * alternatives built and timed on one box, all CRC-verified: level 7 (2,2,3) and (2,3,2) -2 %; level 8 (2,3,3), (3,2,3)
+ * equal; level 9 as 64 KB tiles of 512 threads -0.4 %; level 10 (2,3,3,2) -1.5 %, (2,2,3,3) -2.5 %, 64 KB tiles -1.5 %;
+ * level 11 as 64 KB tiles of 512 threads, two per CU, (2,3,3,3): -2.7 %, which had been the best without priorities) */
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
-	entry_k2<TileCfg<7, 256, 8192>, 2, 2, 3>(),
+	entry_k2<TileCfg<7, 256, 8192>, 3, 2, 2>(),
 	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
 	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
 	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
-	entry_k2w<TileCfg<11, 512, 16384>, 2, 2, 3, 3, 3>(),
+	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
 	entry_k2w<TileCfg<12, 512, 32768>, 1, 3, 3, 3, 3>(),   /* 64 KB tiles spill at 128 registers; one 128 KB tile per CU is as fast */
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
