@@ -218,14 +218,17 @@ acm_sw_emit(const AcmDevStream *__restrict__ streams, const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 /*
  * For level <= 4 an output depends on fewer than 2*cols - 2 <= 30 earlier samples, so one thread can own SL_K = 32
- * consecutive outputs, load them and the 32 samples in front of them (two aligned 64-byte runs), run every stage over
- * that register array and write 64 bytes of PCM - one launch, 2 B in + 2 B out per sample, instead of the stage-wise
+ * consecutive outputs, load them and the 8 / 16 / 32 samples in front of them that the cascade can reach (sl_halo; aligned
+ * 16-byte loads), run every stage over that register array and write 64 bytes of PCM - one launch, 2 B in + 2 B out per sample, instead of the stage-wise
  * family's launch per stage over int32 planes.  Coordinates are the stage-wise family's: e counts from the first
  * staged sample the kernels may read (row halo_row), samples before it are zeros (exact: the reach is < 2 rows).
  * Because chunks start on multiples of 32 >= cols, column, sign and the "+1" of an element are compile-time
  * functions of its position in the register array.
  */
 constexpr int SL_K = 32;                 /* outputs per thread */
+/* samples in front of them that the thread loads and runs through the stages as well: the cascade reaches back
+ * 2*cols - 2 samples, rounded up to whole 16-byte loads and whole rows */
+constexpr int sl_halo(int level) { return level <= 2 ? 8 : level == 3 ? 16 : 32; }
 /* history the stages 0..k need in front of a position, in samples */
 constexpr int sl_reach(int cols, int k) { int r = 0; for (int i = 0; i <= k; i++) r += 2 * (cols >> (i + 1)); return r; }
 template <int L, int K> struct SlStage {
@@ -234,10 +237,11 @@ template <int L, int K> struct SlStage {
 constexpr int SL_THREADS = 256;
 
 template <int L, int K>
-__device__ __forceinline__ void sl_stages(uint32_t (&x)[2 * SL_K], const int64_t e0)
+__device__ __forceinline__ void sl_stages(uint32_t (&x)[SL_K + sl_halo(L)], const int64_t e0)
 {
 	if constexpr (K < L) {
-		constexpr int ST = SlStage<L, K>::ST, LO = SlStage<L, K>::LO, COLS = 1 << L, N = 2 * SL_K;
+		constexpr int ST = SlStage<L, K>::ST, LO = SlStage<L, K>::LO, COLS = 1 << L, N = SL_K + sl_halo(L);
+		static_assert(SlStage<L, L - 1>::LO <= sl_halo(L), "the halo covers the cascade's reach");
 		/* positions below LO lack history inside the array: never used by a valid output */
 #pragma unroll
 		for (int jj = N - 1; jj >= LO; jj--) {
@@ -257,7 +261,8 @@ acm_small_level(const AcmDevStream *__restrict__ streams, const uint32_t *__rest
 		const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
 		int16_t *__restrict__ pcm, unsigned fmt)
 {
-	constexpr int COLS = 1 << L, N = 2 * SL_K;
+	constexpr int COLS = 1 << L, H = sl_halo(L), N = SL_K + H;
+	static_assert(H % COLS == 0 && N % COLS == 0 && N % 8 == 0, "whole rows, whole 16-byte loads");
 	const AcmDevStream s = streams[list[blockIdx.y]];
 	const int64_t n_in = (int64_t)(s.nrows - s.halo_row) << L;                  /* staged samples the stream has, from e = 0 */
 	const int64_t e_emit = (int64_t)(s.row_begin - s.halo_row) << L;            /* e of the first emitted sample */
@@ -267,9 +272,9 @@ acm_small_level(const AcmDevStream *__restrict__ streams, const uint32_t *__rest
 	const uint64_t nchunks = (s.n_emit + SL_K - 1) / SL_K;
 
 	for (uint64_t q = (uint64_t)blockIdx.x * SL_THREADS + threadIdx.x; q < nchunks; q += (uint64_t)gridDim.x * SL_THREADS) {
-		const int64_t e0 = e_emit + (int64_t)q * SL_K - SL_K;               /* e of x[0]; a multiple of cols */
+		const int64_t e0 = e_emit + (int64_t)q * SL_K - H;                  /* e of x[0]; a multiple of cols */
 		const uint64_t g0 = q * SL_K;                                       /* first output of the chunk */
-		/* staged indices, sign-extended: 64 samples; zeros outside [0, n_in) */
+		/* staged indices, sign-extended: N samples; zeros outside [0, n_in) */
 		int32_t ix[N];
 		const bool inside = e0 >= 0 && e0 + N <= n_in && (reinterpret_cast<uintptr_t>(src + e0) & 15u) == 0;
 		if (inside) {
@@ -320,14 +325,14 @@ acm_small_level(const AcmDevStream *__restrict__ streams, const uint32_t *__rest
 				uint32_t w[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++)
-					w[k] = pcm16((int32_t)x[SL_K + v * 8 + 2 * k], L, fmt) | pcm16((int32_t)x[SL_K + v * 8 + 2 * k + 1], L, fmt) << 16;
+					w[k] = pcm16((int32_t)x[H + v * 8 + 2 * k], L, fmt) | pcm16((int32_t)x[H + v * 8 + 2 * k + 1], L, fmt) << 16;
 				o[v] = make_uint4(w[0], w[1], w[2], w[3]);
 			}
 		} else {
 #pragma unroll
 			for (int k = 0; k < SL_K; k++)
 				if (g0 + k < s.n_emit)
-					dst[g0 + k] = (uint16_t)pcm16((int32_t)x[SL_K + k], L, fmt);
+					dst[g0 + k] = (uint16_t)pcm16((int32_t)x[H + k], L, fmt);
 		}
 	}
 }
