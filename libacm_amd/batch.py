@@ -6,8 +6,8 @@ ACM streams share no state, so the data path has NO collective:
     rank 0:  read the 14-byte headers -> weights (total_values) -> greedy longest-first shards
     C1    :  scatter of the shard TABLE - file ids and paths, a few KB; never file contents   [collective, control]
     rank r:  read its own files, parse them on the host, synthesise them on its GPU           [no communication]
-    C2    :  PCM (2 B/sample) + per-stream status to rank 0: each rank cuts its shard into a few chunks and sends
-             chunk k (point-to-point, exact size, from HBM) while chunk k+1 is being decoded   [results]
+    C2    :  per-stream status and offsets to rank 0 (gather_object), then the PCM (2 B/sample) point-to-point,
+             exact size, straight from the HBM buffer the decoder filled (no compaction pass)      [results]
 
 The decode itself is injected (`decoder`): the product decoder is GpuDecoder below (HIP kernels through
 libacm_hip.so, device memory owned by torch); tests on CPU-only machines inject a stand-in so that
@@ -92,13 +92,19 @@ class GpuDecoder:
         return d_pcm, offsets, words, statuses
 
 
-def decode_sharded(files, decoder, dist=None, root=0, device=None, chunks=2):
+def decode_sharded(files, decoder, dist=None, root=0, device=None, chunks=1):
     """Decode `files` across all ranks of `dist`.
 
     `files`: list of paths (str / PathLike: every rank can open them; only `root` needs the list) and/or file images
     (bytes: every rank must pass the same list - contents are never sent, only ids).
     Returns on root: list of (status, np.uint16 array) in input order; on other ranks: None.
     With dist=None runs single-process.  `decoder(list_of_bytes)` -> (pcm 1-D int16 tensor, offsets, words, statuses).
+
+    Order of communication, identical on every rank (RCCL runs the operations of one communicator in issue order, so a
+    rank that sends before a collective while the root receives after it never completes):
+        C1 scatter_object_list -> [local decode, no communication] -> gather_object(metadata) -> PCM point-to-point.
+    Nothing is in flight while acm_batch_decode runs (its plan teardown frees device memory, which waits for every
+    stream of the device, a pending send kernel included).  `chunks` only bounds the size of one decode call.
     """
     import torch
     world = dist.get_world_size() if dist is not None else 1
@@ -121,24 +127,19 @@ def decode_sharded(files, decoder, dist=None, root=0, device=None, chunks=2):
         if path is None and (files is None or i >= len(files)):
             raise ValueError("decode_sharded: file %d was passed as bytes on the root only; pass paths, or the same list on every rank" % i)
 
-    # ---- local decode in a few chunks; chunk k travels to root while chunk k+1 is decoded (no communication otherwise)
-    nch = max(1, min(chunks if (dist is not None and world > 1) else 1, len(mine)))
+    # ---- local decode (no communication).  The PCM of a call stays where the decoder left it: one dense int16
+    # tensor, stream k at offsets[k] (no compaction pass over HBM); what travels is its used prefix.
+    nch = max(1, min(chunks, len(mine)))
     cuts = [len(mine) * k // nch for k in range(nch + 1)]
-    pieces, pending, keep_alive = [], [], []
+    pieces = []
     for k in range(nch):
         part = mine[cuts[k]:cuts[k + 1]]
         ids = [i for i, _ in part]
         pcm, offsets, words, statuses = decoder([_load(path if path is not None else files[i]) for i, path in part])
         if device is None:
             device = pcm.device
-        # compact the chunk's PCM into one contiguous run (drop the alignment padding between streams)
-        parts = [pcm[o:o + w] for o, w in zip(offsets, words) if w]
-        flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int16, device=device)
-        pieces.append(((ids, list(words), list(statuses)), flat))
-        if dist is not None and rank != root and flat.numel():
-            wire = flat.view(torch.uint8)                # neither RCCL nor gloo moves int16; bytes are bytes
-            keep_alive.append(wire)
-            pending.append(dist.isend(wire, dst=root))   # exact size, straight from HBM
+        used = max([int(o) + int(w) for o, w in zip(offsets, words) if w] or [0])
+        pieces.append(((ids, [int(o) for o in offsets], [int(w) for w in words], [int(x) for x in statuses], used), pcm[:used]))
 
     # ---- C2: results to root
     if dist is None:
@@ -150,30 +151,42 @@ def decode_sharded(files, decoder, dist=None, root=0, device=None, chunks=2):
         if rank == root:
             flats = [None] * world
             flats[root] = [f for _, f in pieces]
-            recvs = []
+            reqs = []
             for r in range(world):
                 if r == root:
                     continue
                 flats[r] = []
-                for (_, words_r, _) in metas[r]:
-                    n = int(sum(words_r))
-                    buf = torch.empty(2 * n, dtype=torch.uint8, device=device)
-                    if n:
-                        recvs.append(dist.irecv(buf, src=r))
+                for m in metas[r]:
+                    buf = torch.empty(2 * m[4], dtype=torch.uint8, device=device)
+                    if m[4]:
+                        reqs.append(dist.irecv(buf, src=r))
                     flats[r].append(buf.view(torch.int16))
-            for q in recvs:
-                q.wait()
-        for q in pending:
+        else:
+            # neither RCCL nor gloo moves int16; bytes are bytes.  Exact size, straight from HBM.
+            reqs = [dist.isend(f.contiguous().view(torch.uint8), dst=root) for _, f in pieces if f.numel()]
+        for q in reqs:
             q.wait()
     if rank != root:
         return None
 
+    # device -> host: every piece into its own pinned buffer, asynchronously, one synchronisation for all of them
+    hosts = []
+    for flats_r in flats:
+        row = []
+        for f in flats_r:
+            if f.is_cuda:
+                h = torch.empty(f.numel(), dtype=torch.int16, pin_memory=True)
+                h.copy_(f, non_blocking=True)
+            else:
+                h = f
+            row.append(h)
+        hosts.append(row)
+    if any(f.is_cuda for fl in flats for f in fl):
+        torch.cuda.synchronize()
     out = [None] * len(files)
-    for metas_r, flats_r in zip(metas, flats):
-        for (ids_r, words_r, st_r), flat_r in zip(metas_r, flats_r):
-            host = flat_r.cpu().numpy().view(np.uint16)
-            pos = 0
-            for i, w, st in zip(ids_r, words_r, st_r):
-                out[i] = (st, host[pos:pos + w].copy())
-                pos += w
+    for metas_r, hosts_r in zip(metas, hosts):
+        for (ids_r, offs_r, words_r, st_r, _), h in zip(metas_r, hosts_r):
+            host = h.numpy().view(np.uint16)
+            for i, o, w, st in zip(ids_r, offs_r, words_r, st_r):
+                out[i] = (st, host[o:o + w].copy())
     return out

@@ -44,6 +44,10 @@
 
 #include "acm_device.h"
 
+#ifndef ACM_EXP_LOAD_POLICY
+#define ACM_EXP_LOAD_POLICY ""
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -363,6 +367,13 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	if constexpr (EXACT32) {
 		return t - (z << 1);
 	} else {
+#ifdef ACM_EXP_ADD3
+		{
+			uint32_t y3;
+			asm("v_add_u32 %0, %2, %2\n\tv_sub_u32 %0, %1, %0" : "=&v"(y3) : "v"(t), "v"(z));
+			return y3;
+		}
+#endif
 #ifdef ACM_NO_ASM
 		return (uint32_t)(__mul24((int32_t)z, -2) + (int32_t)t);
 #else
@@ -416,6 +427,13 @@ __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
 #ifdef ACM_NO_ASM
 	return t + (z << 1);
+#endif
+#ifdef ACM_EXP_ADD3
+	{
+		uint32_t y3;
+		asm("v_add_u32 %0, %2, %2\n\tv_add_u32 %0, %1, %0" : "=&v"(y3) : "v"(t), "v"(z));
+		return y3;
+	}
 #endif
 	uint32_t y;
 	asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(y) : "v"(z), "v"(t));
@@ -571,6 +589,26 @@ __device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G
 		for (int x = 0; x < 2 * d; x++)
 			h[t][x] = in[BODY - 2 * d + x];
 	}
+}
+
+/* every register of a body named as an input of one empty asm statement: the compiler has to have all of them before it,
+ * so it waits ONCE (for the youngest LDS read of the body) instead of once per first use */
+__device__ __forceinline__ void touch_all(uint32_t (&v)[16])
+{
+	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+		     "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+}
+__device__ __forceinline__ void touch_all(uint32_t (&v)[8])
+{
+	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+__device__ __forceinline__ void touch_all(uint32_t (&v)[4])
+{
+	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+__device__ __forceinline__ void touch_all(uint32_t (&v)[32])
+{
+	asm volatile("" :: "v"(v[31]));
 }
 
 template <int G>
@@ -848,6 +886,9 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			for (int u = 0; u < BODY; u++)
 				nxt[u] = pn[P::off(u)];
 		}
+#ifdef ACM_EXP_ONEWAIT
+		touch_all(v);
+#endif
 		if (!(ABL & 2))
 			pass_body<L, K0, G>(v, h, 0u, 0u);
 		if constexpr (!LAST) {
@@ -1389,10 +1430,16 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
 		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
 		constexpr int off = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
 		constexpr int imm = off % 4096, far = off - imm;        /* 12 bits in the instruction, the rest on the scalar base */
+#ifdef ACM_EXP_NOWARM
+		if (b < 0) {
+			raw[K] = voff_warm;
+			return;
+		}
+#endif
 		if (ABL & 1)                            /* timing-only build: no HBM loads */
 			raw[K] = voff + off;
 		else
-			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
+			asm volatile("global_load_dword %0, %1, %2 offset:%3" ACM_EXP_LOAD_POLICY : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
 	template <int... Ks>
 	static __device__ __forceinline__ void load_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
@@ -1400,9 +1447,47 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
 	{
 		(load_one<Ks>(raw, base, voff, voff_warm), ...);
 	}
+#ifdef ACM_EXP_X4
+	/* timing-only experiment: the same bytes as 16-byte loads, coalesced (what a first-pass-ordered staged layout would allow) */
+	template <int GRP>
+	static __device__ __forceinline__ void load_x4(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	{
+		typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+		constexpr int off = (GRP / 2) * COLS * 2 + (GRP % 2) * (COLS);      /* row GRP/2 of the segment's four, half GRP%2 of the row */
+		constexpr int imm = off % 4096, far = off - imm;
+		v4u t;
+#ifdef ACM_EXP_NOWARM
+		if (GRP < 4) {
+			t = v4u{ voff_warm, voff_warm, voff_warm, voff_warm };
+		} else
+#endif
+		asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t) : "v"(GRP < 4 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
+		raw[GRP * 4 + 0] = t.x;
+		raw[GRP * 4 + 1] = t.y;
+		raw[GRP * 4 + 2] = t.z;
+		raw[GRP * 4 + 3] = t.w;
+	}
+	template <int... Gs>
+	static __device__ __forceinline__ void load_x4_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
+							   std::integer_sequence<int, Gs...>)
+	{
+		(load_x4<Gs>(raw, base, voff, voff_warm), ...);
+	}
+	static __device__ __forceinline__ uint32_t lane_offset_x4(const int tid)
+	{
+		const int seg = tid / FP::TPS, j = tid % FP::TPS;
+		return (uint32_t)(seg * FP::RPS * COLS * 2 + j * 16);
+	}
+#endif
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
+#ifdef ACM_EXP_X4
+		if constexpr (NRAW == 32 && COLS * 2 / 2 == FP::TPS * 16) {
+			load_x4_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, 8>{});
+			return;
+		}
+#endif
 		load_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
 	}
 };
@@ -1457,7 +1542,11 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		t--;
 	}
 
+#ifdef ACM_EXP_X4
+	const uint32_t voff = (FP::NRAW == 32 && COLS == FP::TPS * 16) ? FP::lane_offset_x4(tid) : FP::lane_offset(tid);
+#else
 	const uint32_t voff = FP::lane_offset(tid);
+#endif
 	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
 
 	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589).  Every lane of every
@@ -1551,7 +1640,9 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 				const v4u o = { q[0], q[1], q[2], q[3] };
 				if ((ABL & 16) && o.x != 0x12345u)              /* timing-only build: no stores */
 					continue;
-#ifdef ACM_K2_PLAIN_STORES
+#ifdef ACM_EXP_STORE_POLICY
+				asm volatile("global_store_dwordx4 %0, %1, off" ACM_EXP_STORE_POLICY :: "v"(&out[vec]), "v"(o) : "memory");
+#elif defined(ACM_K2_PLAIN_STORES)
 				out[vec] = o;
 #else
 				__builtin_nontemporal_store(o, &out[vec]);      /* PCM is written once and never read back here */
@@ -1596,7 +1687,7 @@ template <int ABL>
 constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
-	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() },
+	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
 };
 #endif
 /* per level the fastest measured geometry and stage grouping (profiles/r2_sweep_levels.txt): 32 KB tiles at four workgroups

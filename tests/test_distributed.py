@@ -45,6 +45,39 @@ def oracle_decoder(files):
     return flat, offsets, words, statuses
 
 
+def host_parse_decoder(files):
+    """GpuDecoder's shape with the PRODUCT's host half in it: probing, bit parsing and H1 resolution are libacm_hip.so's
+    own (acm_stage_probe / acm_stage_file run without a GPU); only the HIP synthesis is replaced, by the oracle's
+    juggle_block + writer over the staged form (value = idx * val, patches applied, decode.c:592-600)"""
+    from libacm_amd import capi
+    parts, offsets, words, statuses, pos = [], [], [], [], 0
+    for f in files:
+        rc, info = capi.probe(f)
+        if rc != 0:
+            offsets.append(0), words.append(0), statuses.append(rc)
+            continue
+        st = capi.stage_file(f)
+        bl, level, rows = st.block_len, st.info.level, st.info.rows
+        x = st.idx.astype(np.int64).reshape(st.info.blocks, bl) * st.hdr[:st.info.blocks, 0].astype(np.int64)[:, None]
+        x = (x & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(-1).copy()
+        if st.patches is not None:
+            for p in st.patches:
+                x[p.sample] = p.value
+        wrap = np.zeros(max(1, 2 * (1 << level) - 2), dtype=np.int32)
+        out = np.zeros(st.info.blocks * bl, dtype=np.int16)
+        for b in range(st.info.blocks):
+            blk = x[b * bl:(b + 1) * bl].copy()
+            O.Oracle.juggle_block(level, rows, blk, wrap)
+            out[b * bl:(b + 1) * bl] = O.Oracle.output(blk, level, 0, 1)[1].view(np.int16)
+        w = st.words
+        pad = (-w) % 64
+        parts.append(np.concatenate([out[:w], np.zeros(pad, np.int16)]))
+        offsets.append(pos), words.append(w), statuses.append(st.info.end_status)
+        pos += w + pad
+    flat = torch.from_numpy(np.concatenate(parts)) if parts else torch.zeros(0, dtype=torch.int16)
+    return flat, offsets, words, statuses
+
+
 def check(out, files):
     assert len(out) == len(files)
     for (st, pcm), f in zip(out, files):
@@ -70,7 +103,24 @@ def test_single_process_front_end():
     check(batch.decode_sharded(files, oracle_decoder), files)
 
 
-def _worker(rank, world, port, q, paths=None):
+def test_host_parse_decoder_single_process():
+    """the stand-in used by the two-rank test below is itself right (product parser + oracle synthesis == oracle)"""
+    files = corpus()
+    check(batch.decode_sharded(files, host_parse_decoder, chunks=3), files)
+
+
+def test_corpus_shards_balance_at_8_ranks():
+    """SURVEY 8e / configs[3]: the ~4000-file corpus over 8 GPUs, weights from the 14-byte headers (decode.c:734-736):
+    greedy longest-first leaves the heaviest rank within 2 % of the mean"""
+    from libacm_amd import workload
+    w = [s["total_values"] for s in workload.corpus_shapes(4000)]
+    shards = batch.shard_longest_first(w, 8)
+    loads = [sum(w[i] for i in s) for s in shards]
+    assert sorted(i for s in shards for i in s) == list(range(len(w)))
+    assert max(loads) / (sum(loads) / 8) <= 1.02, loads
+
+
+def _worker(rank, world, port, q, paths=None, product_parser=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -83,7 +133,8 @@ def _worker(rank, world, port, q, paths=None):
         else:
             # file images: every rank holds the same list, only ids are scattered
             files = corpus()
-        out = batch.decode_sharded(files, oracle_decoder, dist=dist, root=0, device=torch.device("cpu"))
+        out = batch.decode_sharded(files, host_parse_decoder if product_parser else oracle_decoder, dist=dist, root=0,
+                                   device=torch.device("cpu"), chunks=2 if product_parser else 1)
         if rank == 0:
             check(out, corpus())
             q.put("ok")
@@ -95,8 +146,8 @@ def _worker(rank, world, port, q, paths=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("by_path", [False, True])
-def test_two_ranks_gloo(by_path, tmp_path):
+@pytest.mark.parametrize("by_path,product_parser", [(False, False), (True, False), (True, True)])
+def test_two_ranks_gloo(by_path, product_parser, tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -111,7 +162,7 @@ def test_two_ranks_gloo(by_path, tmp_path):
             paths.append(str(p))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, paths)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, paths, product_parser)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -142,10 +193,11 @@ def _nccl_worker(rank, world, port, q, paths):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    ordinal = rank if torch.cuda.device_count() >= world else 0
+    torch.cuda.set_device(ordinal)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", ordinal))
     try:
-        out = batch.decode_sharded(paths if rank == 0 else None, batch.GpuDecoder(0), dist=dist, root=0)
+        out = batch.decode_sharded(paths if rank == 0 else None, batch.GpuDecoder(ordinal), dist=dist, root=0, chunks=2)
         if rank == 0:
             check(out, corpus())
             q.put("ok")
@@ -175,4 +227,33 @@ def test_front_end_on_rccl(dev, tmp_path):
     p.start()
     p.join(300)
     assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
+
+
+@pytest.mark.gpu
+def test_front_end_on_rccl_two_ranks(dev, tmp_path):
+    """two ranks on two GPUs over RCCL: the PCM of rank 1 really travels point-to-point (runs where the box has two GPUs;
+    the one-GPU boxes of the pool skip it - the ordering it guards is described in decode_sharded's docstring)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    paths = []
+    for k, f in enumerate(corpus()):
+        p = tmp_path / ("f%02d.acm" % k)
+        p.write_bytes(bytes(f))
+        paths.append(str(p))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, paths)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
