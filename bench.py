@@ -51,7 +51,7 @@ K2_GEOMETRY = {12: (512, 16384)}      # threads, tile dwords of acm_tile2 (acm_k
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams", type=int, default=1024)
@@ -72,7 +72,10 @@ def parse_args():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the PCM gather leg (C2) that is reported beside the headline")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank - exercises the N>1 code path on a 1-GPU box")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))      # torchrun --nproc-per-node N bench.py  ==  --gpus N
+    return a
 
 
 def visible_gpus():
@@ -95,9 +98,23 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # a rank that dies leaves the others waiting in RCCL until its timeout: end them as soon as one fails
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = max(rc, abs(r))
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     raise SystemExit(rc)
 
 

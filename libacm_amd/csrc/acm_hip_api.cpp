@@ -46,6 +46,8 @@ struct acmhip_device {
 	bool own_stream;
 	hipStream_t copy_stream = nullptr;      /* read-back stream of the batch pipeline, created on first use */
 	hipStream_t side[2] = { nullptr, nullptr };     /* plans with several level groups spread them over these too */
+	hipStream_t upload = nullptr;           /* plan tables go up on a non-blocking stream of their own (to_device) */
+	std::mutex upload_mutex;
 	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
@@ -157,6 +159,8 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 	}
 	if (dev->copy_stream)
 		(void)hipStreamDestroy(dev->copy_stream);
+	if (dev->upload)
+		(void)hipStreamDestroy(dev->upload);
 	for (hipStream_t s : dev->side)
 		if (s)
 			(void)hipStreamDestroy(s);
@@ -300,11 +304,15 @@ int to_device(acmhip_device *dev, const std::vector<T> &v, T **out)
 	if (v.empty())
 		return ACMHIP_OK;
 	HIPTRY(hipMalloc((void **)out, v.size() * sizeof(T)));
-	/* a blocking copy on the null stream: done when it returns (the host vector dies with the caller), and - the device
-	 * stream being a non-blocking one - without waiting for the chunks of a batch that are still in flight on it
-	 * (acm_batch_decode builds the plan of chunk k+1 while chunk k runs) */
-	(void)dev;
-	HIPTRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	/* done when this returns (the host vector dies with the caller), on a non-blocking stream of the handle's own: neither
+	 * the device stream - which may be the caller's and busy with the chunks of a batch still in flight (acm_batch_decode
+	 * builds the plan of chunk k+1 while chunk k runs) - nor the legacy null stream, whose copies join every blocking
+	 * stream of the process and are refused while another thread captures a graph, is involved */
+	std::lock_guard<std::mutex> g(dev->upload_mutex);
+	if (!dev->upload)
+		HIPTRY(hipStreamCreateWithFlags(&dev->upload, hipStreamNonBlocking));
+	HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
+	HIPTRY(hipStreamSynchronize(dev->upload));
 	return ACMHIP_OK;
 }
 
@@ -404,6 +412,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
 	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
 	std::vector<uint8_t> plane_shift(n, 0);                /* levels 13-15: planes carry values scaled by 2^(16 - level) */
+	std::vector<uint8_t> on_tile_kernel(n, 0);             /* patched stream that stays on the tile kernel: its patches live in windows only */
 	const bool prefix_allowed = !(flags & ACMHIP_PLAN_STAGEWISE) && !(getenv("ACM_PREFIX") && atoi(getenv("ACM_PREFIX")) == 0);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
@@ -441,6 +450,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 
 		const bool fused = !(flags & ACMHIP_PLAN_STAGEWISE) && fused_ok(s, variant);
 		if (fused && has_patch[i]) {
+			on_tile_kernel[i] = 1;
 			const uint32_t T = (uint32_t)acmk_fused_tile_rows(s.level, variant) - 2;
 			const uint64_t cols = 1ull << s.level;
 			const uint64_t emit_rows = (s.n_emit + cols - 1) >> s.level;
@@ -569,10 +579,14 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		win_of[windows[w].stream].push_back(w);
 	for (size_t p = 0; p < npatches; p++) {
 		const AcmDevStream &d = ds[patches[p].stream];
-		if (!win_of.empty() && !win_of[patches[p].stream].empty()) {
+		if (on_tile_kernel[patches[p].stream]) {
 			/* a tile-kernel stream: the patch lands in every window that can see it (its own tile, and the next one
-			 * when it sits in that tile's two halo rows) */
+			 * when it sits in that tile's two halo rows); a patch no window sees (behind the last emitted tile, or
+			 * outside a windowed decode) changes nothing that is emitted and has no place in the plane: the stream
+			 * owns no plane run of its own (scratch_off 0 is somebody else's) */
 			const uint64_t row = patches[p].sample >> d.level;
+			if (win_of.empty())
+				continue;
 			for (size_t w : win_of[patches[p].stream]) {
 				const PatchWindow &pw = windows[w];
 				if (row >= pw.lo_row && row < pw.hi_row)
@@ -587,6 +601,11 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		dp.push_back(AcmDevPatch{ d.scratch_off + (patches[p].sample - first),
 					  (int32_t)((uint32_t)patches[p].value << plane_shift[patches[p].stream]), 0 });
 	}
+	for (const AcmDevPatch &q : dp)
+		if (q.dst >= plane) {
+			set_err("internal: H1 patch lands at %llu of a %llu-element plane", (unsigned long long)q.dst, (unsigned long long)plane);
+			return ACMHIP_ERR_ARG;
+		}
 
 	acmhip_plan *pl = new (std::nothrow) acmhip_plan;
 	if (!pl)

@@ -356,8 +356,13 @@ static void *batch_reader(void *unused)
 			acm_stage_info si;
 			if (slurp(bt.names[i], &data, &it->len) == 0) {
 				it->data = data;
-				if (acm_stage_probe(data, it->len, cfg.force_chans, &si) == ACM_OK)
-					it->pcm_cap = si.total_values;
+				if (acm_stage_probe(data, it->len, cfg.force_chans, &si) == ACM_OK) {
+					/* what the file's bytes can hold, not what its header promises: a 19-byte file that claims
+					 * 2^32-1 samples gets one block of arena, not 8 GB of pinned memory (the silence behind a
+					 * short stream is written by write_one, not kept in the arena) */
+					uint64_t fits = acm_batch_pcm_words(it, 1, cfg.force_chans);
+					it->pcm_cap = si.total_values < fits ? si.total_values : (size_t)fits;
+				}
 				bytes += it->len + 2 * it->pcm_cap;
 				pcm_words += (it->pcm_cap + 63) & ~(size_t)63;
 			}
@@ -391,6 +396,8 @@ static void *batch_reader(void *unused)
 				if (!a->pinned)
 					a->mem = malloc(want);
 				a->cap = a->mem ? want : 0;
+				if (!a->mem)
+					fprintf(stderr, "acmtool: cannot allocate %zu MB for the PCM of %d files\n", want >> 20, g->n);
 			}
 			g->arena = a;
 		}
@@ -437,7 +444,17 @@ static void write_one(const char *name, const acm_batch_item *it)
 			p = le32(p, whole * ACM_WORD);
 			fwrite(h, 1, sizeof(h), out);
 		}
-		fwrite(it->pcm, 2, whole, out);
+		{
+			/* the decoded words, then silence for what the stream did not deliver (acmtool.c:293-310) */
+			static const unsigned char zeros[8192];
+			size_t have = it->words < whole ? (size_t)it->words : whole, rest = ((size_t)whole - have) * 2;
+			fwrite(it->pcm, 2, have, out);
+			while (rest) {
+				size_t n = rest < sizeof(zeros) ? rest : sizeof(zeros);
+				fwrite(zeros, 1, n, out);
+				rest -= n;
+			}
+		}
 		fclose(out);
 	}
 	free(dst);
@@ -476,7 +493,10 @@ static void *batch_writer(void *unused)
 				continue;
 			}
 			if (!it->pcm) {
-				fprintf(stderr, "%s: %s\n", name, acm_strerror(it->status));
+				if (it->pcm_cap)
+					fprintf(stderr, "%s: out of memory\n", name);
+				else
+					fprintf(stderr, "%s: %s\n", name, acm_strerror(it->status));
 				continue;
 			}
 			if (it->status < 0 && it->words == 0)
@@ -491,7 +511,6 @@ static void *batch_writer(void *unused)
 			if (it->words < whole) {
 				/* silence for what the stream did not deliver (acmtool.c:293-310) */
 				fprintf(stderr, "%s: adding filler_samples: %d\n", name, (int)((whole - it->words) * ACM_WORD));
-				memset(it->pcm + it->words, 0, (size_t)(whole - it->words) * 2);
 			}
 		}
 		BT_NOTE("writer: group of %d files", g->n);

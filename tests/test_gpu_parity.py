@@ -192,6 +192,32 @@ def test_h1_patches_demote_tiles_not_streams(dev):
         assert st2.fused_streams == 1 and st2.tiles > 0 and np.array_equal(got[0], ref[0])
 
 
+def test_h1_patch_that_no_window_sees(dev):
+    """a tile-kernel stream whose only patches lie behind what is emitted (a windowed decode that stops early) owns no
+    run of the scratch plane: such patches must be dropped, not written over the plane of the stage-wise stream next to
+    it (acm_hip_api.cpp, "H1 patches -> plane coordinates")"""
+    dirty = make_stream(967, 7, 16, 60, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    small = make_stream(903, 3, 4, 8, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)    # level 3 + patches: stage-wise
+    sd, ss = capi.stage_file(dirty), capi.stage_file(small)
+    assert sd.info.npatches > 0 and ss.info.npatches > 0
+    half = sd.info.blocks * sd.block_len // 2
+    late = [k for k in range(sd.info.npatches) if sd.patches[k].sample >= half]
+    assert late
+    keep = late + [sd.info.npatches + k for k in range(ss.info.npatches)]
+    n_emit = (sd.info.blocks * 16 // 4) * 128 - 5                      # the first quarter of the stream: no kept patch in sight
+    windows = [(0, n_emit), (0, ss.words)]
+    for order in ((sd, ss), (ss, sd)):
+        w = windows if order[0] is sd else windows[::-1]
+        k = keep if order[0] is sd else [ss.info.npatches + j for j in late] + list(range(ss.info.npatches))
+        got, st = capi.synth(dev, list(order), windows=w, return_stats=True, patch_subset=k)
+        ref = capi.synth(dev, list(order), flags=capi.PLAN_STAGEWISE, windows=w, patch_subset=k)
+        assert st.fused_streams == 1 and st.stagewise_streams == 1
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+        small_pcm = got[1] if order[0] is sd else got[0]
+        assert np.array_equal(small_pcm, oracle_pcm(small)[0])
+
+
 def test_window_with_halo(dev):
     """a window starting at row_begin > 0 needs only the two staged rows in front of it"""
     for lv, rows in ((7, 16), (9, 16), (5, 3), (11, 4), (2, 5)):
