@@ -182,6 +182,20 @@ struct Chunk {
 	hipEvent_t ev[5] = {};                  /* h2d begin, h2d end, kernel end (device stream); d2h begin, d2h end (copy stream) */
 };
 
+/* device parsing: the files of one chunk as an upload piece (copied into the pinned file arena by the pool, sent up as
+ * soon as the piece is complete, while the pool copies the next ones).  The walk itself is ONE launch over all streams:
+ * a stream's walk is one wavefront's sequential job (~30 ms for two megasamples however many streams walk beside it),
+ * and walks launched group by group on streams of their own were measured to slow each other down (last group done
+ * after 65 / 86 / 103 ms for 1 / 2 / 4 groups of the 1024-stream level-9 batch: the waves of a later launch land on the
+ * compute units - and scalar units - the earlier ones already occupy). */
+struct ParseGroup {
+	size_t k_first = 0, k_last = 0;         /* range of the device-parsed streams (indices into dev_ids) */
+	uint64_t file_begin = 0, file_end = 0;  /* bytes of the file arenas */
+	uint64_t max_columns = 0;
+	std::atomic<int> uncopied{ 0 };         /* files not yet in the pinned arena */
+	hipEvent_t ev[3] = {};                  /* upload begin, upload end; the last piece's third one: parse results on the host */
+};
+
 } // namespace
 
 extern "C" uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, int force_chans)
@@ -209,6 +223,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		return ACMHIP_ERR_ARG;
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
+	static const bool trace = getenv("ACM_BATCH_TRACE") != nullptr;         /* host-side timeline on stderr */
+#define BNOTE(...) do { if (trace) { fprintf(stderr, "[batch %8.3f ms] ", secs(t0, clk::now()) * 1e3); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 	const int threads_wanted = opts.threads > 0 ? opts.threads : default_threads();
 	const int threads = (int)std::min<size_t>((size_t)threads_wanted, std::max<size_t>(1, n));
 	Pool pool(threads);
@@ -325,6 +341,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	std::atomic<size_t> issued{ 0 };                /* chunks whose read-back has been queued */
 	bool aborted = false;
 	bool pool_busy = false;
+	const size_t npg = dev_parse && !dev_ids.empty() ? chunks.size() : 0;
+	hipStream_t st_up = nullptr, st_parse = nullptr;        /* file uploads piece by piece; the walk + column kernels */
+	std::vector<ParseGroup> groups(npg);
 
 	auto cleanup = [&]() {
 		if (pool_busy) {
@@ -335,9 +354,17 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			cv.notify_all();
 			pool.wait();
 		}
+		if (st_up)
+			(void)hipStreamSynchronize(st_up);
+		if (st_parse)
+			(void)hipStreamSynchronize(st_parse);
 		(void)hipStreamSynchronize(st_main);
 		if (st_copy)
 			(void)hipStreamSynchronize(st_copy);
+		for (ParseGroup &g : groups)
+			for (hipEvent_t e : g.ev)
+				if (e)
+					(void)hipEventDestroy(e);
 		for (Chunk &ch : chunks) {
 			acmhip_plan_destroy(ch.plan);
 			for (hipEvent_t e : ch.ev)
@@ -375,8 +402,16 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	for (Chunk &ch : chunks)
 		for (hipEvent_t &e : ch.ev)
 			HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
+	if (!groups.empty()) {
+		BTRY(acmhip_aux_stream(dev, ACM_AUX_STREAMS - 1, (void **)&st_up));
+		BTRY(acmhip_aux_stream(dev, 0, (void **)&st_parse));
+	}
+	for (size_t g = 0; g < groups.size(); g++)
+		for (hipEvent_t &e : groups[g].ev)
+			HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
 	const auto t_alloc = clk::now();
 	tm.alloc_s = secs(t_hdr, t_alloc);
+	BNOTE("headers %.3f ms, arenas + events %.3f ms; %zu chunks, %zu parse groups", secs(t0, t_hdr) * 1e3, tm.alloc_s * 1e3, chunks.size(), groups.size());
 
 	/* the exact host reader, one stream */
 	auto host_stage = [&](size_t i) {
@@ -402,95 +437,85 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		it.words = deliverable_words(info.total_values, (uint64_t)info.rows * info.cols, info.channels, info.blocks);
 	};
 
-	/* 2a. device lanes parse the clean streams (optional); whatever they flag joins the host list */
-	std::vector<size_t> host_ids;
-	double h2d_files_s = 0;
-	if (!dev_parse) {
-		for (size_t i = 0; i < n; i++)
-			if (slots[i].ok)
-				host_ids.push_back(i);
-	} else {
-		std::vector<char> on_dev(n, 0);
-		AcmParseJob *jobs = reinterpret_cast<AcmParseJob *>(h_jobs);
-		AcmParseResult *results = reinterpret_cast<AcmParseResult *>(h_jobs + jobs_bytes);
-		const uint32_t *flags = reinterpret_cast<const uint32_t *>(results + dev_ids.size());
-		uint64_t max_columns = 0, col_off = 0;
+	/* 2a. device parsing (optional): the streams the device parser takes are copied into the pinned file arena by the pool,
+	 * group by group; whatever the device flags later is re-parsed by the exact host reader on this thread (rare) */
+	std::vector<size_t> host_ids;                   /* streams the host pool parses (known up front) */
+	std::vector<char> on_dev(n, 0);
+	AcmParseJob *jobs = reinterpret_cast<AcmParseJob *>(h_jobs);
+	AcmParseResult *results = reinterpret_cast<AcmParseResult *>(h_jobs ? h_jobs + jobs_bytes : nullptr);
+	const uint32_t *flags = reinterpret_cast<const uint32_t *>(results + dev_ids.size());
+	std::vector<size_t> group_of_chunk(chunks.size(), 0);
+	if (!groups.empty()) {
+		for (size_t c = 0; c < chunks.size(); c++)
+			group_of_chunk[c] = c;
+		uint64_t col_off = 0;
+		for (ParseGroup &g : groups)
+			g.k_first = g.k_last = dev_ids.size();
 		for (size_t k = 0; k < dev_ids.size(); k++) {
-			const Slot &s = slots[dev_ids[k]];
-			on_dev[dev_ids[k]] = 1;
+			const size_t i = dev_ids[k];
+			const Slot &s = slots[i];
+			on_dev[i] = 1;
 			AcmParseJob &j = jobs[k];
-			j.file_off = file_off[dev_ids[k]];
+			j.file_off = file_off[i];
 			j.idx_off = s.idx_off;
 			j.hdr_off = s.hdr_off;
 			j.col_off = col_off;
-			j.file_len = (uint32_t)items[dev_ids[k]].len;
+			j.file_len = (uint32_t)items[i].len;
 			j.data_start = (uint32_t)s.info.header_bytes;
 			j.level = s.info.level;
 			j.rows = s.info.rows;
 			j.blocks = (uint32_t)s.need_blocks;
 			j.pad = 0;
 			col_off += s.need_blocks << s.info.level;
-			max_columns = std::max<uint64_t>(max_columns, s.need_blocks << s.info.level);
-		}
-		pool.run(dev_ids.size(), [&](size_t k) {
-			const acm_batch_item &it = items[dev_ids[k]];
-			uint8_t *dst = h_files + file_off[dev_ids[k]];
-			memcpy(dst, it.data, it.len);
-			memset(dst + it.len, 0, round_up(it.len, 16) + 16 - it.len);
-		});
-		if (!dev_ids.empty()) {
-			const auto tu0 = clk::now();
-			HTRY(hipMemcpyAsync(d_files, h_files, files_total, hipMemcpyHostToDevice, st_main));
-			HTRY(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, st_main));
-			HTRY(hipStreamSynchronize(st_main));
-			h2d_files_s = secs(tu0, clk::now());
-			AcmParseResult *d_res = reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes);
-			uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_res + dev_ids.size());
-			HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_main));
-			const int e = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files,
-							d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, st_main);
-			HTRY((hipError_t)e);
-			HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_main));
-			HTRY(hipStreamSynchronize(st_main));
-		}
-		for (size_t k = 0; k < dev_ids.size(); k++) {
-			const size_t i = dev_ids[k];
-			Slot &s = slots[i];
-			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0) {
-				on_dev[i] = 0;
-				continue;
+			ParseGroup &g = groups[group_of_chunk[s.chunk]];
+			if (g.k_first == dev_ids.size()) {
+				g.k_first = k;
+				g.file_begin = file_off[i];
 			}
-			s.info.blocks = (uint32_t)s.need_blocks;
-			s.info.end_status = ACM_OK;
-			items[i].status = ACM_OK;
-			items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols,
-							   s.info.channels, s.need_blocks);
-			tm.device_parsed++;
+			g.k_last = k + 1;
+			g.file_end = file_off[i] + round_up(items[i].len, 16) + 16;
+			g.max_columns = std::max<uint64_t>(g.max_columns, s.need_blocks << s.info.level);
+			g.uncopied.fetch_add(1);
 		}
-		for (size_t i = 0; i < n; i++)
-			if (slots[i].ok && !on_dev[i])
-				host_ids.push_back(i);              /* ascending, i.e. arena order */
-		if (!host_ids.empty()) {
-			const auto ta = clk::now();
-			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
-			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
-			tm.alloc_s += secs(ta, clk::now());
-		}
+	}
+	for (size_t i = 0; i < n; i++)
+		if (slots[i].ok && !on_dev[i])
+			host_ids.push_back(i);                  /* ascending, i.e. arena order */
+	if (dev_parse && !host_ids.empty()) {
+		const auto ta = clk::now();
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
+		tm.alloc_s += secs(ta, clk::now());
 	}
 	tm.host_parsed = host_ids.size();
 	for (size_t i : host_ids)
 		chunks[slots[i].chunk].unparsed.fetch_add(1);
 
-	/* 2b. the pool: parse in arena order, then copy finished PCM out as the chunks come back */
+	/* 2b. the pool: files of the device-parsed streams into the pinned arena (group order), host parsing in arena order,
+	 * then finished PCM out to the callers' buffers as the chunks come back */
 	std::vector<size_t> out_ids;
 	for (size_t i = 0; i < n; i++)
 		if (slots[i].ok && items[i].pcm && !keep_on_device && !direct_out)
 			out_ids.push_back(i);
 	std::atomic<size_t> parsed{ 0 };
 	clk::time_point t_parsed = clk::now();
+	const size_t ncopy = groups.empty() ? 0 : dev_ids.size();
 	const size_t nparse = host_ids.size();
 	pool_busy = true;
-	pool.start(nparse + out_ids.size(), [&](size_t task) {
+	pool.start(ncopy + nparse + out_ids.size(), [&](size_t task) {
+		if (task < ncopy) {
+			const size_t i = dev_ids[task];
+			const acm_batch_item &it = items[i];
+			uint8_t *dst = h_files + file_off[i];
+			memcpy(dst, it.data, it.len);
+			memset(dst + it.len, 0, round_up(it.len, 16) + 16 - it.len);     /* zero tail: the device readers load whole dwords */
+			if (groups[group_of_chunk[slots[i].chunk]].uncopied.fetch_sub(1) == 1) {
+				std::lock_guard<std::mutex> g(m);
+				cv.notify_all();
+			}
+			return;
+		}
+		task -= ncopy;
 		if (task < nparse) {
 			const size_t i = host_ids[task];
 			const uint32_t c = slots[i].chunk;
@@ -522,13 +547,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		memcpy(items[i].pcm, h_pcm + s.pcm_off, w * sizeof(int16_t));
 	});
 
-	/* 3. this thread feeds the device, chunk by chunk */
-	for (size_t c = 0; c < chunks.size(); c++) {
+	/* the launch plan of one chunk from what is known about its streams right now */
+	auto build_plan = [&](size_t c, uint64_t *samples) -> int {
 		Chunk &ch = chunks[c];
-		{
-			std::unique_lock<std::mutex> g(m);
-			cv.wait(g, [&]() { return ch.unparsed.load() == 0; });
-		}
 		std::vector<acmhip_stream_desc> descs;
 		std::vector<acmhip_patch> patches;
 		for (size_t i = ch.first; i < ch.last; i++) {
@@ -549,10 +570,129 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				patches.push_back(p);
 			}
 			descs.push_back(d);
-			tm.samples += d.n_emit;
+			if (samples)
+				*samples += d.n_emit;
 		}
-		if (!descs.empty()) {
-			BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan));
+		if (ch.plan) {
+			acmhip_plan_destroy(ch.plan);
+			ch.plan = nullptr;
+		}
+		if (descs.empty())
+			return ACMHIP_OK;
+		return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
+	};
+	/* chunks made of device-parsed streams only: their plans are cut NOW, from what the headers promise (a stream the
+	 * device parser flags later gets its chunk's plan rebuilt), while the queues are still empty - a plan's small table
+	 * uploads otherwise wait behind whatever long walk kernel shares their hardware queue */
+	std::vector<char> planned(chunks.size(), 0), replan(chunks.size(), 0);
+	if (!groups.empty()) {
+		for (size_t c = 0; c < chunks.size(); c++) {
+			bool all_dev = true;
+			for (size_t i = chunks[c].first; i < chunks[c].last; i++)
+				all_dev = all_dev && (!slots[i].ok || on_dev[i]);
+			if (!all_dev)
+				continue;
+			for (size_t i = chunks[c].first; i < chunks[c].last; i++) {
+				Slot &s = slots[i];
+				if (!s.ok)
+					continue;
+				s.info.blocks = (uint32_t)s.need_blocks;
+				items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols, s.info.channels, s.need_blocks);
+			}
+			BTRY(build_plan(c, nullptr));
+			planned[c] = 1;
+		}
+		BNOTE("plans of the all-device chunks built");
+	}
+
+	/* 2c. every piece goes up as soon as its files are in the pinned arena; behind the last one, one walk over all streams */
+	uint64_t max_columns = 0;
+	hipEvent_t ev_parsed = nullptr;
+	for (ParseGroup &g : groups) {
+		if (g.k_first == g.k_last)
+			continue;
+		{
+			std::unique_lock<std::mutex> lk(m);
+			cv.wait(lk, [&]() { return g.uncopied.load() == 0; });
+		}
+		const size_t nj = g.k_last - g.k_first;
+		HTRY(hipEventRecord(g.ev[0], st_up));
+		HTRY(hipMemcpyAsync(d_files + g.file_begin, h_files + g.file_begin, g.file_end - g.file_begin, hipMemcpyHostToDevice, st_up));
+		HTRY(hipMemcpyAsync(d_jobs + g.k_first * sizeof(AcmParseJob), h_jobs + g.k_first * sizeof(AcmParseJob), nj * sizeof(AcmParseJob),
+				    hipMemcpyHostToDevice, st_up));
+		HTRY(hipEventRecord(g.ev[1], st_up));
+		max_columns = std::max(max_columns, g.max_columns);
+		ev_parsed = g.ev[2];
+		if (&g == &groups.back() || (&g)[1].k_first == (&g)[1].k_last)
+			BNOTE("files up to piece %zu queued for upload", (size_t)(&g - groups.data()));
+	}
+	if (ev_parsed) {
+		AcmParseResult *d_res = reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes);
+		uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_res + dev_ids.size());
+		HTRY(hipEventRecord(ev_parsed, st_up));         /* re-recorded below: here it only orders the walk behind the last upload */
+		HTRY(hipStreamWaitEvent(st_parse, ev_parsed, 0));
+		HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_parse));
+		const int e = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx, d_hdr,
+						d_res, d_flags, max_columns, st_parse);
+		HTRY((hipError_t)e);
+		HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_parse));
+		HTRY(hipEventRecord(ev_parsed, st_parse));
+	}
+	clk::time_point t_dev_parsed = t_alloc;
+	/* what the device parser said; the streams it flags go through the exact host reader here */
+	bool settled = false;
+	auto settle = [&]() -> int {
+		if (settled || !ev_parsed)
+			return ACMHIP_OK;
+		settled = true;
+		if (hipEventSynchronize(ev_parsed) != hipSuccess)
+			return acmhip_report_hip((int)hipGetLastError(), "device parsing");
+		t_dev_parsed = clk::now();
+		BNOTE("device parsing done");
+		for (size_t k = 0; k < dev_ids.size(); k++) {
+			const size_t i = dev_ids[k];
+			Slot &s = slots[i];
+			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0) {
+				if (!h_idx) {
+					int r = acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx);
+					if (r == ACMHIP_OK)
+						r = acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr);
+					if (r != ACMHIP_OK)
+						return r;
+				}
+				host_stage(i);
+				tm.host_parsed++;
+				replan[s.chunk] = 1;
+				continue;
+			}
+			s.info.blocks = (uint32_t)s.need_blocks;
+			s.info.end_status = ACM_OK;
+			items[i].status = ACM_OK;
+			items[i].words = deliverable_words(s.info.total_values, (uint64_t)s.info.rows * s.info.cols,
+							   s.info.channels, s.need_blocks);
+			tm.device_parsed++;
+		}
+		return ACMHIP_OK;
+	};
+
+	/* 3. this thread feeds the device, chunk by chunk */
+	for (size_t c = 0; c < chunks.size(); c++) {
+		Chunk &ch = chunks[c];
+		if (ev_parsed) {
+			BTRY(settle());
+			if (c == 0)
+				HTRY(hipStreamWaitEvent(st_main, ev_parsed, 0));
+		}
+		{
+			std::unique_lock<std::mutex> g(m);
+			cv.wait(g, [&]() { return ch.unparsed.load() == 0; });
+		}
+		if (!planned[c] || replan[c])
+			BTRY(build_plan(c, nullptr));
+		for (size_t i = ch.first; i < ch.last; i++)
+			if (slots[i].ok)
+				tm.samples += items[i].words;
+		if (ch.plan) {
 			HTRY(hipEventRecord(ch.ev[0], st_main));
 			if (!dev_parse) {
 				HTRY(hipMemcpyAsync(d_idx + ch.idx_begin, h_idx + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
@@ -590,6 +730,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			}
 		}
 		HTRY(hipEventRecord(ch.ev[4], st_copy));
+		BNOTE("chunk %zu: synthesis and read-back queued", c);
 		{
 			std::lock_guard<std::mutex> g(m);
 			issued.store(c + 1, std::memory_order_release);
@@ -598,6 +739,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	}
 	pool.wait();
 	pool_busy = false;
+	BNOTE("pool done");
 	HTRY(hipStreamSynchronize(st_copy));
 	HTRY(hipStreamSynchronize(st_main));
 #undef BTRY
@@ -615,10 +757,16 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		if (hipEventElapsedTime(&ms, ch.ev[3], ch.ev[4]) == hipSuccess)
 			tm.d2h_s += ms * 1e-3;
 	}
+	double h2d_files_s = 0;
+	for (ParseGroup &g : groups) {
+		float ms = 0;
+		if (g.k_first != g.k_last && hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess)
+			h2d_files_s += ms * 1e-3;
+	}
 	tm.h2d_s += h2d_files_s;
-	tm.stage_s = secs(t0, t_hdr) + secs(t_alloc, t_parsed) - h2d_files_s;
-	if (tm.stage_s < 0)
-		tm.stage_s = 0;
+	/* host-side staging: headers, then until the last stream was parsed - by the pool, or by the device (whose walks
+	 * overlap the uploads of the later groups and the synthesis / read-back of the earlier ones) */
+	tm.stage_s = secs(t0, t_hdr) + std::max(secs(t_alloc, t_parsed), secs(t_alloc, t_dev_parsed));
 	tm.total_s = secs(t0, clk::now());
 	if (timing)
 		*timing = tm;

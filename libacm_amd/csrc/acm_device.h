@@ -96,6 +96,8 @@ int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
 void acmhip_arena_lock(acmhip_device *dev);
 void acmhip_arena_unlock(acmhip_device *dev);
 int acmhip_copy_stream(acmhip_device *dev, void **out);          /* second stream for overlapped read-back */
+#define ACM_AUX_STREAMS 2
+int acmhip_aux_stream(acmhip_device *dev, int k, void **out);    /* batch pipeline: 0 = device bit parsing, 1 = file uploads */
 int acmhip_report_hip(int hip_error, const char *what);          /* records the text, returns ACMHIP_ERR_HIP */
 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */

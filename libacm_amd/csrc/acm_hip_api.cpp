@@ -47,6 +47,7 @@ struct acmhip_device {
 	hipStream_t copy_stream = nullptr;      /* read-back stream of the batch pipeline, created on first use */
 	hipStream_t side[2] = { nullptr, nullptr };     /* plans with several level groups spread them over these too */
 	hipStream_t upload = nullptr;           /* plan tables go up on a non-blocking stream of their own (to_device) */
+	hipStream_t aux[ACM_AUX_STREAMS] = {};  /* the batch pipeline's per-group upload + bit-parsing streams, created on first use */
 	std::mutex upload_mutex;
 	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
@@ -161,6 +162,9 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 		(void)hipStreamDestroy(dev->copy_stream);
 	if (dev->upload)
 		(void)hipStreamDestroy(dev->upload);
+	for (hipStream_t s : dev->aux)
+		if (s)
+			(void)hipStreamDestroy(s);
 	for (hipStream_t s : dev->side)
 		if (s)
 			(void)hipStreamDestroy(s);
@@ -205,6 +209,17 @@ extern "C" int acmhip_copy_stream(acmhip_device *dev, void **out)
 	if (!dev->copy_stream)
 		HIPTRY(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
 	*out = (void *)dev->copy_stream;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_aux_stream(acmhip_device *dev, int k, void **out)
+{
+	if (!dev || !out || k < 0 || k >= ACM_AUX_STREAMS)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipSetDevice(dev->ordinal));
+	if (!dev->aux[k])
+		HIPTRY(hipStreamCreateWithFlags(&dev->aux[k], hipStreamNonBlocking));
+	*out = (void *)dev->aux[k];
 	return ACMHIP_OK;
 }
 
