@@ -240,6 +240,13 @@ typedef struct acm_batch_timing {
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,
 		      const acm_batch_opts *opts, acm_batch_timing *timing);
 
+/* Optional, for applications that know they are about to decode through the libacm.h calls (acmtool -d): start opening
+ * the process-wide default device - HIP runtime, device handle, the kernels' code object - on a thread of the library's
+ * own and return at once.  The first acm_read() that needs the GPU waits for it; until then the stream keeps parsing
+ * ahead on the calling thread.  Without this call the device is opened by that first acm_read() itself (a process that
+ * only opens, seeks or inspects streams never touches the GPU).  No reference counterpart. */
+void acmhip_prewarm(void);
+
 /* 16-bit words of device memory acm_batch_decode needs for the PCM of these files (headers only are read;
  * every stream is padded to a multiple of 64 words) - the size of opts->d_pcm for device-resident output */
 uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, int force_chans);

@@ -67,7 +67,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
-    "acm_batch_decode", "acm_batch_pcm_words",
+    "acm_batch_decode", "acm_batch_pcm_words", "acmhip_prewarm",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [

@@ -101,6 +101,7 @@ int acmhip_aux_stream(acmhip_device *dev, int k, void **out);    /* batch pipeli
 int acmhip_report_hip(int hip_error, const char *what);          /* records the text, returns ACMHIP_ERR_HIP */
 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
+int acmk_warmup(void *stream);                                   /* an empty launch: makes the runtime load the kernels' code object */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
 int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */
 int acmk_fused_has_carry(uint32_t level, int variant);           /* does a carry-mode build of this geometry exist? */

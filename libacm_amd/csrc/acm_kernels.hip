@@ -1731,6 +1731,17 @@ inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 
 #define ACMK_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+namespace {
+__global__ void acm_warmup_kernel() {}
+}
+
+extern "C" int acmk_warmup(void *stream)
+{
+	hipLaunchKernelGGL(acm_warmup_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
 /* gridDim.y carries the stream index and is limited to 65535: walk long lists in slices */
 constexpr uint32_t SW_MAX_Y = 65535;
 

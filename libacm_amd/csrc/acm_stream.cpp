@@ -17,10 +17,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
+#include "acm_device.h"
 #include "acm_fill.h"
 #include "acm_hip.h"
 #include "libacm.h"
@@ -44,25 +47,78 @@ namespace {
 
 using acmfill::kCleanEof;
 
-constexpr uint64_t kWindowSamplesMax = 4u << 20;        /* read-ahead ceiling per window */
+constexpr uint64_t kWindowSamplesMax = 64u << 20;       /* read-ahead ceiling per window (buffers are sized by min(this, the stream): a
+                                                           whole 40-Msample file fits, so that parsing can run ahead for as long
+                                                           as a prewarmed device takes to come up) */
 constexpr uint64_t kWindowSamplesFirst = 64u << 10;     /* first window: keep time-to-first-sample short */
 
-/* ---- process-wide default device for the single-stream API ---- */
+/* ---- process-wide default device for the single-stream API ----
+ * Opened on first use - or ahead of it, on a thread of its own, when the application says it is going to decode
+ * (acmhip_prewarm, include/acm_hip.h): bringing the HIP runtime up takes ~0.2 s on these boxes, which is as long as the
+ * host parser needs for 40 Msamples.  While the device is still coming up the stream keeps parsing ahead (fill_window). */
 std::mutex g_dev_mutex;
+std::condition_variable g_dev_cv;
 acmhip_device *g_dev = nullptr;
-bool g_dev_tried = false;
+int g_dev_state = 0;                    /* 0 untouched, 1 being opened, 2 settled (g_dev valid or NULL) */
+bool g_dev_reported = false;
+char g_dev_error[256];
+
+void open_default_device()
+{
+	const char *env = getenv("ACM_HIP_DEVICE");
+	const int ord = env ? atoi(env) : 0;
+	acmhip_device *d = nullptr;
+	const int rc = acmhip_device_open(ord, nullptr, &d);
+	if (rc == ACMHIP_OK)
+		(void)acmk_warmup(acmhip_device_stream(d));      /* loads the kernels' code object now, not inside the first decode */
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	if (rc != ACMHIP_OK) {
+		snprintf(g_dev_error, sizeof(g_dev_error), "%s", acmhip_last_error());
+		d = nullptr;
+	}
+	g_dev = d;
+	g_dev_state = 2;
+	g_dev_cv.notify_all();
+}
+
+/* a prewarm thread still inside the HIP runtime when the process leaves main() must be waited for */
+struct PrewarmJoiner {
+	std::thread t;
+	~PrewarmJoiner()
+	{
+		if (t.joinable())
+			t.join();
+	}
+} g_prewarm;
+
+void start_prewarm()
+{
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	if (g_dev_state != 0)
+		return;
+	g_dev_state = 1;
+	g_prewarm.t = std::thread(open_default_device);
+}
+
+bool default_device_pending()
+{
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	return g_dev_state == 1;
+}
 
 acmhip_device *default_device()
 {
-	std::lock_guard<std::mutex> lock(g_dev_mutex);
-	if (!g_dev_tried) {
-		g_dev_tried = true;
-		const char *env = getenv("ACM_HIP_DEVICE");
-		int ord = env ? atoi(env) : 0;
-		if (acmhip_device_open(ord, nullptr, &g_dev) != ACMHIP_OK) {
-			g_dev = nullptr;
-			fprintf(stderr, "libacm_hip: cannot decode: %s\n", acmhip_last_error());
-		}
+	std::unique_lock<std::mutex> lock(g_dev_mutex);
+	if (g_dev_state == 0) {
+		g_dev_state = 1;
+		lock.unlock();
+		open_default_device();
+		lock.lock();
+	}
+	g_dev_cv.wait(lock, []() { return g_dev_state == 2; });
+	if (!g_dev && !g_dev_reported) {
+		g_dev_reported = true;
+		fprintf(stderr, "libacm_hip: cannot decode: %s\n", g_dev_error);
 	}
 	return g_dev;
 }
@@ -175,8 +231,12 @@ int fill_window(HipStream *hs)
 	const uint64_t need = (remaining + bl - 1) / bl;
 	const uint32_t want = (uint32_t)std::min<uint64_t>(std::min(hs->win_cap, hs->grow), need);
 
+	/* while a prewarmed device is still coming up there is nothing to hand the window to: keep parsing */
+	const uint32_t hard = (uint32_t)std::min<uint64_t>(hs->win_cap, need);
 	acmfill::PatchSink sink{ &hs->patches, 0, 0, 0 };
-	for (uint32_t i = 0; i < want; i++) {
+	for (uint32_t i = 0; i < hard; i++) {
+		if (i >= want && (hs->dev || !default_device_pending()))
+			break;
 		const size_t slot = hs->carry + i;
 		sink.base_sample = (uint64_t)slot * bl;
 		if (hs->next_block_no == hs->mark_bit.size())
@@ -332,6 +392,11 @@ void fill_stage_info(const ACMStream *a, acm_stage_info *info)
 /* ======================================================================== */
 /* core API                                                                  */
 /* ======================================================================== */
+
+extern "C" void acmhip_prewarm(void)
+{
+	start_prewarm();
+}
 
 extern "C" int acm_open_decoder(ACMStream **res, void *arg, acm_io_callbacks io_cb, int force_chans)
 {

@@ -115,6 +115,14 @@ static int pad_output(const char *name, FILE *out, char *buf, int done, int tota
 	return done;
 }
 
+/* all outputs written and closed: end the process without the HIP runtime's teardown (profiles/startup_probe.sh: ~0.08 s
+ * of a 0.3 s run) */
+static void fast_exit(int code)
+{
+	fflush(NULL);
+	_exit(code);
+}
+
 static void decode_one(const char *src, const char *dst)
 {
 	ACMStream *acm;
@@ -563,14 +571,15 @@ static int decode_batch(int nfiles, char **names)
 
 	bt_trace = getenv("ACMTOOL_BATCH_TRACE") != NULL;
 	bt_t0 = bt_now();
+	/* the reader starts first: it reads the first group's files while this thread brings the HIP runtime up (~0.2 s) */
+	pthread_create(&reader, NULL, batch_reader, NULL);
+	pthread_create(&writer, NULL, batch_writer, NULL);
 	rc = acmhip_device_open(0, NULL, &dev);
 	if (rc != ACMHIP_OK) {
 		fprintf(stderr, "acmtool: batch decode failed: %s\n", acmhip_last_error());
-		return 1;
+		failed = 1;             /* the groups still flow through the queues so that both threads end */
 	}
 	BT_NOTE("device open");
-	pthread_create(&reader, NULL, batch_reader, NULL);
-	pthread_create(&writer, NULL, batch_writer, NULL);
 	while ((g = bq_pop(&bt.to_decode)) != NULL) {
 		BT_NOTE("decoder: group of %d files", g->n);
 		opts.flags = (g->arena && g->arena->pinned) ? ACM_BATCH_PCM_PINNED : 0;
@@ -599,17 +608,10 @@ static int decode_batch(int nfiles, char **names)
 		printf("batch: %llu samples, alloc %.3fs parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
 		       (unsigned long long)bt.total.samples, bt.total.alloc_s, bt.total.stage_s, bt.total.h2d_s,
 		       bt.total.kernel_s, bt.total.d2h_s, bt.total.total_s);
-	{
-		int k;
-		for (k = 0; k < BATCH_GROUPS_IN_FLIGHT; k++) {
-			if (bt.arenas[k].mem && bt.arenas[k].pinned)
-				acmhip_host_free(bt.arenas[k].mem);
-			else
-				free(bt.arenas[k].mem);
-		}
-	}
-	acmhip_device_close(dev);
+	/* every output file is closed: leave without unpinning the arenas (as slow as pinning them) or taking the HIP
+	 * runtime down (~0.08 s) - the process ends here anyway */
 	BT_NOTE("done");
+	fast_exit(failed);
 	return failed;
 }
 
@@ -694,16 +696,19 @@ int main(int argc, char *argv[])
 		usage(1);
 	if (batch)
 		return decode_batch(argc - optind, argv + optind);
+	/* decoding for sure: the GPU comes up on a thread of the library's own while this one opens and parses */
+	acmhip_prewarm();
 	if (outname) {
 		if (optind + 1 != argc)
 			usage(1);
 		decode_one(argv[optind], outname);
-		return 0;
+		fast_exit(0);
 	}
 	for (i = optind; i < argc; i++) {
 		char *dst = swap_extension(argv[i], cfg.raw ? ".raw" : ".wav");
 		decode_one(argv[i], dst);
 		free(dst);
 	}
+	fast_exit(0);
 	return 0;
 }

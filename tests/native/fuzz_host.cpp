@@ -18,6 +18,8 @@ extern "C" {
 const char *acmhip_last_error(void) { return "stub"; }
 int acmhip_device_open(int, void *, acmhip_device **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
 int acmhip_device_sync(acmhip_device *) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+void *acmhip_device_stream(acmhip_device *) { return nullptr; }
+int acmk_warmup(void *) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
 int acmhip_malloc(acmhip_device *, size_t, void **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
 int acmhip_free(acmhip_device *, void *) { return 0; }
 int acmhip_upload(acmhip_device *, void *, const void *, size_t) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }

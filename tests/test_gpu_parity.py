@@ -135,6 +135,56 @@ def test_level_13_window_and_patches(dev, carry, monkeypatch):
     check_streams(dev, [p])
 
 
+@pytest.mark.parametrize("carry", ["0", "1"])
+@pytest.mark.parametrize("level,rows,blocks", [(5, 4095, 3), (9, 4095, 2), (11, 4095, 2), (12, 4095, 2), (13, 4095, 2), (0, 4095, 3), (3, 4095, 2),
+                                               (5, 1, 900), (9, 1, 700), (11, 1, 40), (12, 1, 24), (13, 1, 9), (2, 1, 5000),
+                                               (15, 64, 2), (14, 64, 2)])
+def test_header_extremes(dev, level, rows, blocks, carry, monkeypatch):
+    """acm_rows is a 12-bit field (decode.c:748-750) and acm_level a 4-bit one (:747): rows 1 and 4095 through every
+    kernel family the planner picks (tile kernels with and without carries, register kernel, prefix + plane kernel), and
+    levels 14 / 15 with as many rows as the stress configuration has; both bit parsers"""
+    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    f = make_stream(88000 + level * 7 + rows, level, rows, blocks, channels=1 + level % 2, cut=11)
+    st = check_streams(dev, [f])
+    assert st.fused_streams == 1 and st.stagewise_streams == 0
+    if carry == "0":
+        want, wst = oracle_pcm(f)
+        for parse in (capi.PARSE_HOST, capi.PARSE_DEVICE):
+            res, _ = capi.batch_decode(dev, [f], parse=parse)
+            assert res[0][0] == wst and np.array_equal(res[0][1], want), parse
+
+
+def test_full_size_config_1(dev):
+    """BASELINE.json configs[1] at its full size - 1024 mono streams, level 7, 16 rows, 1000 blocks each (2.1 Gsamples) -
+    through one plan, every stream's PCM compared with the CPU oracle by CRC-32 (the oracle side runs on all host cores)"""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_api as O
+    from libacm_amd import workload
+    threads = max(4, min(64, workload.usable_cpus()))
+    b = workload.build_uniform(1024, 7, 16, 1000, keep_files=1 << 30, threads=threads)
+    bufs = b.upload(dev)
+    try:
+        plan = capi.Plan(dev, b.descs)
+        plan.launch(*bufs)
+        dev.sync()
+        host = np.empty(b.pcm_words, dtype=np.uint16)
+        dev.download(host, bufs[2])
+        plan.destroy()
+    finally:
+        for p in bufs:
+            dev.free(p)
+    raw = host.view(np.uint8)
+
+    def one(k):
+        d = b.descs[k]
+        want = O.Oracle.decode_all(b.files[k].tobytes())[0]
+        return zlib.crc32(want.view(np.uint8)[:2 * d.n_emit]) == zlib.crc32(raw[2 * d.pcm_off: 2 * (d.pcm_off + d.n_emit)])
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        ok = list(ex.map(one, range(len(b.descs))))
+    assert all(ok), [k for k, v in enumerate(ok) if not v][:10]
+
+
 @pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE])
 @pytest.mark.parametrize("flags", [capi.PLAN_AUTO, capi.PLAN_STAGEWISE])
 def test_output_formats(dev, fmt, flags):
@@ -385,6 +435,14 @@ def test_batch_parse_auto_many_streams(dev):
     host, _ = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_HOST)
     for k, ((hs, hp), (ds, dp)) in enumerate(zip(host, auto)):
         assert hs == ds and np.array_equal(hp, dp), k
+    import oracle_api as O
+    for k in list(range(0, len(files), 41)) + [16, 17, 18, 1998, 1999, 2000]:     # a sample against the oracle itself
+        o = O.Oracle(files[k])
+        if o.err < 0:
+            assert auto[k][0] == o.err and auto[k][1].size == 0, k
+            continue
+        want, wst = oracle_pcm(files[k])
+        assert auto[k][0] == wst and np.array_equal(auto[k][1], want), k
 
 
 @pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE])
@@ -438,6 +496,9 @@ def test_device_walk_lane_kernel(dev):
     for k in range(len(files)):
         ws, wp = host[k % period]
         assert devr[k][0] == ws and np.array_equal(devr[k][1], wp), k
+    for k in list(range(0, period, 7)) + [len(files) - 1, 32768, 32767]:      # a sample of them against the oracle itself
+        want, wst = oracle_pcm(files[k])
+        assert devr[k][0] == wst and np.array_equal(devr[k][1], want), k
 
 
 @pytest.mark.parametrize("parse", [capi.PARSE_HOST, capi.PARSE_DEVICE, capi.PARSE_AUTO])
