@@ -435,6 +435,21 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	acmhip_plan_stats st{};
 	const int variant = pick_variant();
 
+	/* level 13: four rows are one 128 KB tile of the lean kernel.  Whether the batch is worth its one lead-in tile per
+	 * workgroup is known only from all its streams: counted here, decided before the streams are cut */
+	bool k2_level13 = false;
+	{
+		const uint32_t T13 = (uint32_t)acmk_tile2_rows(13);
+		uint64_t whole = 0;
+		for (size_t i = 0; i < n && T13; i++) {
+			const acmhip_stream_desc &s = streams[i];
+			if (s.level == 13 && s.row_begin == 0 && !has_patch[i] && s.nrows >= s.row_begin)
+				whole += std::min<uint64_t>(s.nrows, s.n_emit >> 13) / T13;
+		}
+		const size_t grid13 = (size_t)acmk_tile2_grid(13, dev->cus);
+		k2_level13 = k2_allowed && prefix_allowed && T13 && grid13 && (getenv("ACM_K2") ? whole > 0 : whole >= 8 * grid13);
+	}
+
 	for (size_t i = 0; i < n; i++) {
 		const acmhip_stream_desc &s = streams[i];
 		if (s.level > 15 || s.rows == 0 || s.rows > 4095 || (s.idx_off & 7) || (s.pcm_off & 7) ||
@@ -537,27 +552,54 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			grp_max_emit[s.level] = std::max(grp_max_emit[s.level], (uint64_t)s.n_emit);
 			st.fused_streams++;
 		} else if (prefix_allowed && s.level > ACM_K1_MAX_LEVEL) {
+			uint32_t sid = (uint32_t)i;             /* the stream the prefix + plane pair works on: this one, or the rest of it */
+			AcmDevStream src = d;
+			if (k2_level13 && s.level == 13 && s.row_begin == 0 && !has_patch[i]) {
+				/* the whole four-row tiles go to the lean tile kernel; whatever is left - the ragged tail - is a window of the
+				 * stream (a pseudo stream behind the n real ones) for the prefix + plane pair */
+				const uint32_t T2 = (uint32_t)acmk_tile2_rows(13);
+				const uint64_t rows2 = std::min<uint64_t>(s.nrows, s.n_emit >> 13) / T2 * T2;
+				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
+				for (uint64_t r = 0; r < rows2; r += T2) {
+					const uint64_t rh = r >= 2 ? r - 2 : 0;
+					tiles2[13].push_back(AcmTile2{ s.idx_off + (r << 13), s.pcm_off + (r << 13),
+								       (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
+								       r == 0 ? ACM_TILE_FRESH : 0u });
+				}
+				if (rows2 > 0) {
+					src.pcm_off = s.pcm_off + (rows2 << 13);
+					src.n_emit = s.n_emit - (rows2 << 13);
+					src.row_begin = (uint32_t)rows2;
+					src.halo_row = (uint32_t)rows2 - 2;
+					if (src.n_emit) {
+						sid = (uint32_t)ds.size();
+						ds.push_back(src);
+					}
+				}
+			}
+			if (src.n_emit) {
 			/* levels 13-15: level - 12 stages by the stage-wise kernels into a plane (scaled, see acmk_launch_unpack), then the
 			 * plane is a level-12 stream of 2^(level-12) times as many rows for the tile kernel: stage k of level L has the
 			 * stride of stage k - j of level L - j, and the "+1" belongs to stage 0 alone (decode.c:555-571) */
 			const uint32_t j = s.level - 12;
-			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
-			ds[i].scratch_off = plane;
-			plane_shift[i] = (uint8_t)(16 - s.level);
+			const uint64_t elems = (uint64_t)(src.nrows - src.halo_row) << s.level;
+			ds[sid].scratch_off = plane;
+			if (sid < n)
+				plane_shift[sid] = (uint8_t)(16 - s.level);
 			AcmDevStream w{};
 			w.idx_off = plane;                              /* int32 units into the plane */
-			w.pcm_off = s.pcm_off;
-			w.n_emit = s.n_emit;
+			w.pcm_off = src.pcm_off;
+			w.n_emit = src.n_emit;
 			w.level = 12;
 			w.rows = 1;
-			w.nrows = (s.nrows - d.halo_row) << j;
-			w.row_begin = (s.row_begin - d.halo_row) << j;
+			w.nrows = (src.nrows - src.halo_row) << j;
+			w.row_begin = (src.row_begin - src.halo_row) << j;
 			w.halo_row = w.row_begin >= 2 ? w.row_begin - 2 : 0;
 			plane += (elems + 63) & ~63ull;
 			const uint32_t id = (uint32_t)ds.size();
 			ds.push_back(w);
 			const uint32_t T12 = (uint32_t)acmk_plane_tile_rows() - 2;
-			const uint64_t emit_rows = (s.n_emit + 4095) >> 12;
+			const uint64_t emit_rows = (src.n_emit + 4095) >> 12;
 			for (uint64_t r = 0; r < emit_rows; r += T12)
 				prefix_tiles[s.level].push_back(AcmTile{ id, (int32_t)(w.row_begin + r), 0u, 0u });
 			{
@@ -569,9 +611,10 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 				for (uint64_t r = 0; r < emit_rows; r += TC)
 					tc.push_back(AcmTile{ id, (int32_t)(w.row_begin + r), (r == 0 && w.row_begin == 0) ? ACM_TILE_FRESH : 0u, 0u });
 			}
-			prefix_lists[s.level].push_back((uint32_t)i);
+			prefix_lists[s.level].push_back(sid);
 			grp_max_elems[s.level] = std::max(grp_max_elems[s.level], elems);
 			sw_max = std::max(sw_max, elems);
+			}
 			st.fused_streams++;
 		} else {
 			const uint64_t elems = (uint64_t)(s.nrows - d.halo_row) << s.level;
@@ -629,7 +672,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	pl->variant = variant;
 	int rc = to_device(dev, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
-		if (!tiles[lv].empty() || !tiles_extra[lv].empty()) {
+		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
 			if (!tiles_extra[lv].empty()) {
@@ -643,7 +686,8 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
-			const bool k2 = grid2 && (getenv("ACM_K2") ? !tiles2[lv].empty() : tiles2[lv].size() >= 8 * grid2);
+			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? !tiles2[lv].empty()         /* level 13: decided before the cut */
+						  : getenv("ACM_K2") ? !tiles2[lv].empty() : tiles2[lv].size() >= 8 * grid2);
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
@@ -679,7 +723,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			g.level = lv;
 			g.prefix_stages = lv - 12;
 			for (uint32_t id : prefix_lists[lv])
-				g.prefix_patched = g.prefix_patched || has_patch[id];
+				g.prefix_patched = g.prefix_patched || (id < n && has_patch[id]);
 			g.nlist = (uint32_t)prefix_lists[lv].size();
 			g.max_elems = grp_max_elems[lv];
 			rc = to_device(dev, prefix_lists[lv], &g.d_list);

@@ -44,6 +44,9 @@
 
 #include "acm_device.h"
 
+#ifndef ACM_L13_GROUPS
+#define ACM_L13_GROUPS 3, 2, 3, 3, 2
+#endif
 #ifndef ACM_EXP_LOAD_POLICY
 #define ACM_EXP_LOAD_POLICY ""
 #endif
@@ -921,16 +924,28 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #endif
 
 /* the passes after the first: stage groups G, Rest... starting at stage K0; the last one emits PCM */
-template <class C, int ABL, bool CARRY, int CW, int K0, int G, int... Rest>
-__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt, uint32_t (*carry)[CW] = nullptr)
+/* dwords of carry buffer the LDS passes G, Rest... (starting at stage K0) need between them: every pass its own size - the
+ * first one's is the widest by far (two bodies of its smallest stride) */
+template <class C, int K0, int G, int... Rest>
+constexpr int carry_total()
+{
+	constexpr int mine = carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA, C::PS);
+	if constexpr (sizeof...(Rest) == 0)
+		return mine;
+	else
+		return mine + carry_total<C, K0 + G, Rest...>();
+}
+
+template <class C, int ABL, bool CARRY, int K0, int G, int... Rest>
+__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt, uint32_t *carry = nullptr)
 {
 	constexpr bool last = sizeof...(Rest) == 0;
 	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
-	static_assert(!CARRY || carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA, C::PS) <= CW, "carry buffer too small");
-	uint32_t *cb = CARRY ? carry[0] : nullptr;
+	uint32_t *cb = CARRY ? carry : nullptr;
 	if constexpr (!last) {
 		lds_pass<C, K0, G, false, ABL, true, true, CARRY>(tile, tid, fmt, cb);
-		run_lds_passes<C, ABL, CARRY, CW, K0 + G, Rest...>(tile, tid, fmt, CARRY ? carry + 1 : nullptr);
+		run_lds_passes<C, ABL, CARRY, K0 + G, Rest...>(tile, tid, fmt,
+							       CARRY ? carry + carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA, C::PS) : nullptr);
 	} else if (fmt == ACMHIP_FMT_S16LE) {
 		lds_pass<C, K0, G, true, ABL, false, false, CARRY>(tile, tid, fmt, cb);   /* the common layout: no xor, no byte swap */
 	} else {
@@ -982,9 +997,8 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	uint32_t *const tile = tile_mem + GUARD;
 	/* carry mode: per LDS pass, the tail of the previous tile's input to that pass (the first LDS pass has the
 	 * widest: two bodies of its smallest stride) */
-	constexpr int NCARRY = CARRY ? (int)sizeof...(Gs) : 1;
-	constexpr int CW = CARRY ? carry_words(2 * (COLS >> G0), C::PS) : 1;
-	__shared__ uint32_t carry_mem[NCARRY][CW];
+	constexpr int NCARRY_WORDS = CARRY ? carry_total<C, G0, Gs...>() : 1;
+	__shared__ uint32_t carry_mem[NCARRY_WORDS];
 	/* payload rows of a tile: all of them in carry mode, all but the two halo rows otherwise */
 	constexpr int HALO = CARRY ? 0 : 2;
 
@@ -1067,8 +1081,8 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 	for (;;) {
 		if constexpr (CARRY) {
 			if (cur.fresh)                          /* nothing in front of this tile: history is zeros (util.c:241) */
-				for (int k = tid; k < NCARRY * CW; k += NT)
-					(&carry_mem[0][0])[k] = 0u;
+				for (int k = tid; k < NCARRY_WORDS; k += NT)
+					carry_mem[k] = 0u;
 		}
 		__syncthreads();                                /* rowval[buf] complete; previous write-out done with the tile */
 		ACM_STAMP(0);
@@ -1090,7 +1104,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 		ACM_STAMP(2);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();
 		if (!(ABL & 8))
-			run_lds_passes<C, ABL, CARRY, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+			run_lds_passes<C, ABL, CARRY, G0, Gs...>(tile, tid, fmt, carry_mem);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(3);
 		__syncthreads();
@@ -1524,9 +1538,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 
 	__shared__ uint32_t tile_mem[8 + NELEM + (NELEM >> C::PS)];     /* no guard zone: segment 0 always reads the carry */
 	__shared__ int32_t rowval[2][TR + 2];
-	constexpr int NCARRY = (int)sizeof...(Gs);
-	constexpr int CW = carry_words(2 * (COLS >> G0), C::PS);
-	__shared__ uint32_t carry_mem[NCARRY][CW];
+	constexpr int NCARRY_WORDS = carry_total<C, G0, Gs...>();
+	__shared__ uint32_t carry_mem[NCARRY_WORDS];
 	uint32_t *const tile = tile_mem + 8;
 
 	const int tid = threadIdx.x;
@@ -1604,8 +1617,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
 		if (fresh)
-			for (int k = tid; k < NCARRY * CW; k += NT)
-				(&carry_mem[0][0])[k] = 0u;
+			for (int k = tid; k < NCARRY_WORDS; k += NT)
+				carry_mem[k] = 0u;
 		if (tid < TR + 2)
 			rowval[buf][tid] = finish_val(hv, cur);  /* fetched (and waited for) while the previous tile was in the LDS passes */
 		__syncthreads();
@@ -1623,7 +1636,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
-			run_lds_passes<C, ABL, true, CW, G0, Gs...>(tile, tid, fmt, carry_mem);
+			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
 		ACM_STAMP(3);
 		__syncthreads();
 		ACM_STAMP(4);
@@ -1705,6 +1718,9 @@ const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
 	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
 	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
+	/* level 13: four rows are 128 KB - one workgroup of sixteen waves per CU (still four per SIMD), no plane, no prefix sweep:
+	 * 4 B of HBM traffic per sample instead of the 12 B of the prefix + plane pair */
+	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),      /* (3,3,3,2,2) spills six registers */
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {
