@@ -135,6 +135,75 @@ def workload_cpus():
     return workload.usable_cpus()
 
 
+class PowerSampler:
+    """Socket power and shader clock of the GPU while a timed loop runs, from the amdgpu hwmon files (power1_input in uW,
+    power1_cap, freq1_input in Hz).  The level-9 kernel runs into the package power cap: the clock the chip holds under
+    it, not the issue slots or HBM, is what the launch time follows."""
+
+    def __init__(self, period=0.05):
+        import glob
+        import threading
+        self.dir = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                int(open(os.path.join(d, "power1_input")).read())
+                int(open(os.path.join(d, "freq1_input")).read())
+                self.dir = d
+                break
+            except (OSError, ValueError):
+                continue
+        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
+
+    def _read(self, name):
+        return int(open(os.path.join(self.dir, name)).read())
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self._read("power1_input") / 1e6, self._read("freq1_input") / 1e6))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.dir:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join()
+        s = self.samples[1:-1] if len(self.samples) > 4 else self.samples
+        if not s:
+            return None
+        try:
+            cap = self._read("power1_cap") / 1e6
+        except (OSError, ValueError):
+            cap = None
+        w = sorted(x[0] for x in s)
+        f = sorted(x[1] for x in s)
+        return {"socket_w_median": round(w[len(w) // 2], 1), "socket_w_max": round(w[-1], 1), "power_cap_w": cap,
+                "sclk_mhz_median": round(f[len(f) // 2]), "sclk_mhz_min": round(f[0]), "samples": len(s),
+                "source": "amdgpu hwmon (power1_input, freq1_input), sampled during the sustained run"}
+
+
+def copy_ceiling():
+    """the box's practical HBM ceiling: best of the 16-byte-per-lane copy kernels of profiles/ubench/copy_bw.hip (read +
+    written bytes / time), run in this process through profiles/ubench/libcopybw.so"""
+    path = os.path.join(ROOT, "profiles", "ubench", "libcopybw.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.acm_copy_ceiling_gbs.restype = C.c_double
+    lib.acm_copy_ceiling_gbs.argtypes = [C.c_size_t, C.c_char_p, C.c_size_t]
+    name = C.create_string_buffer(96)
+    gbs = lib.acm_copy_ceiling_gbs(4 << 30, name, 96)
+    return (round(gbs, 1), name.value.decode()) if gbs > 0 else None
+
+
 def kernel_source_sha():
     with open(os.path.join(ROOT, "libacm_amd", "csrc", "acm_kernels.hip"), "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
@@ -283,18 +352,37 @@ def precondition(dev, plan, bufs, seconds):
     return n
 
 
-def side_measure(dev, capi, workload, level, rows, blocks, streams, steps):
-    """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11)"""
-    b = workload.build_uniform(streams, level, rows, blocks, seed0=1 << 20)
+def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1):
+    """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11); the PCM the
+    timed launches leave behind is compared with the CPU oracle on the first `verify` streams (CRC-32 each)"""
+    import oracle_api as O
+    from concurrent.futures import ThreadPoolExecutor
+    b = workload.build_uniform(streams, level, rows, blocks, channels=channels, seed0=1 << 20, keep_files=verify)
     bufs = b.upload(dev)
     plan = capi.Plan(dev, b.descs)
     precondition(dev, plan, bufs, 0.2)
     _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None)
+    checked = 0
+    if b.files:
+        d_last = b.descs[len(b.files) - 1]
+        host = np.empty(d_last.pcm_off + d_last.n_emit, dtype=np.uint16)
+        dev.download(host, bufs[2])
+        raw = host.view(np.uint8)
+
+        def one(k):
+            d = b.descs[k]
+            want = O.Oracle.decode_all(b.files[k].tobytes())[0]
+            return zlib.crc32(want.view(np.uint8)[:2 * d.n_emit]) == zlib.crc32(raw[2 * d.pcm_off: 2 * (d.pcm_off + d.n_emit)])
+        with ThreadPoolExecutor(max_workers=max(4, min(64, workload.usable_cpus()))) as ex:
+            ok = list(ex.map(one, range(len(b.files))))
+        if not all(ok):
+            raise RuntimeError("side measurement level %d: HIP output differs from the oracle on %d of %d streams" % (level, ok.count(False), len(ok)))
+        checked = len(ok)
     plan.destroy()
     for p in bufs:
         dev.free(p)
     rate = b.samples * steps / (ms * 1e-3)
-    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "steps": steps,
+    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "steps": steps, "verified_streams": checked,
             "msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
             "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -385,11 +473,18 @@ def main():
         verified, n_verified = True, len(want)
 
     pre = precondition(dev, plan, bufs, PRECONDITION_S)
+    sampler = PowerSampler() if rank == 0 else None
+    if sampler and args.steps >= SUSTAINED_STEPS:
+        sampler.start()
     wall, ev_ms = time_plan(dev, plan, bufs, args.steps, args.warmup, barrier)
+    power = sampler.stop() if sampler and args.steps >= SUSTAINED_STEPS else None
     sustained = None
     if args.steps < SUSTAINED_STEPS:
         # the contract's K is short (tens of ms): the same loop again, long, right behind it
+        if sampler:
+            sampler.start()
         swall, sev = time_plan(dev, plan, bufs, SUSTAINED_STEPS, 0, barrier)
+        power = sampler.stop() if sampler else None
         sustained = {"steps": SUSTAINED_STEPS, "ms_per_step": round(swall / SUSTAINED_STEPS * 1e3, 4),
                      "launch_ms": round(sev / SUSTAINED_STEPS, 4),
                      "msamples_s_per_gpu": round(batch.samples * SUSTAINED_STEPS / swall / 1e6, 1),
@@ -488,6 +583,8 @@ def main():
     }
     if sustained:
         out["sustained"] = sustained
+    if power:
+        out["power"] = power
     if gather:
         out["gather_c2"] = gather
 
@@ -506,11 +603,20 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-                out["roofline"]["d2d_copy_gbs"] = round(copy_gbs, 1)
-                out["roofline"]["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
+                out["roofline"]["torch_copy_gbs"] = round(copy_gbs, 1)
                 del x, y
+                torch.cuda.empty_cache()
             except Exception:
+                out["roofline"]["torch_copy_gbs"] = None
+            try:
+                best = copy_ceiling()
+                if best:
+                    out["roofline"]["d2d_copy_gbs"] = best[0]
+                    out["roofline"]["d2d_copy_kernel"] = best[1] + " (profiles/ubench/copy_bw.hip, best of five 16-B-per-lane copy kernels)"
+                    out["roofline"]["frac_of_d2d_copy"] = round(achieved / best[0], 4)
+            except Exception as e:
                 out["roofline"]["d2d_copy_gbs"] = None
+                out["roofline"]["d2d_copy_error"] = str(e)[:120]
         if not args.no_extra and not args.stagewise:
             extra = []
             for (lv, rw, bl, ns) in ((7, 16, 1000, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch

@@ -90,6 +90,15 @@ def build_tools(force=False):
     return out
 
 
+def build_bench_tools(force=False):
+    """Measurement infrastructure (not the product): the copy kernels bench.py calls for the box's practical HBM ceiling."""
+    src = os.path.join(ROOT, "profiles", "ubench", "copy_bw.hip")
+    out = os.path.join(ROOT, "profiles", "ubench", "libcopybw.so")
+    if os.path.exists(src) and (force or _stale(out, [src])):
+        _run([HIPCC, "-O3", "-fPIC", "-shared", "-DCOPY_BW_LIB=1", "--offload-arch=" + GFX, "-o", out, src])
+    return out
+
+
 def build_oracle():
     """Test infrastructure: our CPU restatement, and (only where /root/reference exists) the real reference."""
     _run(["make", "-C", os.path.join(ROOT, "oracle"), "all", "ref"])
@@ -99,4 +108,5 @@ def build_all(force=False):
     build_synth(force)
     build_hip(force)
     build_tools(force)
+    build_bench_tools(force)
     build_oracle()

@@ -47,9 +47,6 @@
 #ifndef ACM_L13_GROUPS
 #define ACM_L13_GROUPS 3, 2, 3, 3, 2
 #endif
-#ifndef ACM_EXP_LOAD_POLICY
-#define ACM_EXP_LOAD_POLICY ""
-#endif
 
 namespace {
 
@@ -370,13 +367,6 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	if constexpr (EXACT32) {
 		return t - (z << 1);
 	} else {
-#ifdef ACM_EXP_ADD3
-		{
-			uint32_t y3;
-			asm("v_add_u32 %0, %2, %2\n\tv_sub_u32 %0, %1, %0" : "=&v"(y3) : "v"(t), "v"(z));
-			return y3;
-		}
-#endif
 #ifdef ACM_NO_ASM
 		return (uint32_t)(__mul24((int32_t)z, -2) + (int32_t)t);
 #else
@@ -431,13 +421,6 @@ __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 #ifdef ACM_NO_ASM
 	return t + (z << 1);
 #endif
-#ifdef ACM_EXP_ADD3
-	{
-		uint32_t y3;
-		asm("v_add_u32 %0, %2, %2\n\tv_add_u32 %0, %1, %0" : "=&v"(y3) : "v"(t), "v"(z));
-		return y3;
-	}
-#endif
 	uint32_t y;
 	asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(y) : "v"(z), "v"(t));
 	return y;
@@ -459,11 +442,12 @@ struct StageKind {
 };
 
 /*
- * LDS layout of the tile: one pad dword after every 64 elements,
- * addr(m) = m + (m >> 6).  With it every access pattern of every pass is
- * bank-conflict free for 4-byte accesses: a wave reading residue i of stride
- * sigma < 64 touches 64/sigma walk segments whose starts are 64*sigma apart -
- * all on the same banks without the pad, rotated by sigma banks each with it.
+ * LDS layout of the tile: one pad dword after every 2^PS elements (PS = 5 or 6: one last-pass walk),
+ * addr(m) = m + (m >> PS).  A wave reading residue i of stride sigma < 64 touches 64/sigma walk segments whose
+ * starts are 64*sigma apart - all on the same banks without the pad, rotated by sigma banks each with it.  That
+ * removes the systematic n-way conflicts; what the counters still see at level 9 (SQ_LDS_BANK_CONFLICT = 9 % of
+ * SQ_LDS_IDX_ACTIVE, profiles/r2_level9_summary.txt) comes from the two-address ds_read2 / ds_write2 forms, whose
+ * halves land on the same bank for part of the (segment, residue) pairs of a half-wave.
  */
 template <int PS = 6>
 __device__ __forceinline__ int lds_at(int m) { return m + (m >> PS); }
@@ -594,26 +578,6 @@ __device__ __forceinline__ void pass_body(uint32_t (&v)[2 << G], uint32_t (&h)[G
 	}
 }
 
-/* every register of a body named as an input of one empty asm statement: the compiler has to have all of them before it,
- * so it waits ONCE (for the youngest LDS read of the body) instead of once per first use */
-__device__ __forceinline__ void touch_all(uint32_t (&v)[16])
-{
-	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
-		     "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
-}
-__device__ __forceinline__ void touch_all(uint32_t (&v)[8])
-{
-	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-}
-__device__ __forceinline__ void touch_all(uint32_t (&v)[4])
-{
-	asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-}
-__device__ __forceinline__ void touch_all(uint32_t (&v)[32])
-{
-	asm volatile("" :: "v"(v[31]));
-}
-
 template <int G>
 __device__ __forceinline__ void clear_hist(uint32_t (&h)[G][1 << G])
 {
@@ -734,13 +698,8 @@ struct FirstPass {
 		/* the loads were issued a whole tile ago: touching the YOUNGEST one first makes the compiler emit a
 		 * single s_waitcnt vmcnt for all of them instead of one per consumer */
 		asm volatile("" :: "v"(raw[NREG - 1]));
-#ifdef ACM_EXP_NOWARM
-#define ACM_WARM_FROM 0
-#else
-#define ACM_WARM_FROM (WARM ? -1 : 0)
-#endif
 #pragma unroll
-		for (int b = ACM_WARM_FROM; b < NB; b++) {
+		for (int b = (WARM ? -1 : 0); b < NB; b++) {
 			const int lr0 = lr_seg + 2 * b;
 			const int32_t v0 = rowval[lr0 + 2], v1 = rowval[lr0 + 3];
 			constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
@@ -889,9 +848,6 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			for (int u = 0; u < BODY; u++)
 				nxt[u] = pn[P::off(u)];
 		}
-#ifdef ACM_EXP_ONEWAIT
-		touch_all(v);
-#endif
 		if (!(ABL & 2))
 			pass_body<L, K0, G>(v, h, 0u, 0u);
 		if constexpr (!LAST) {
@@ -1232,182 +1188,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
 		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
 		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
 	},
-#ifdef ACM_TUNING
-	{	/* variant 1: 64 KB tiles shared by 8 waves (4 waves per SIMD, 32 elements per thread) */
-		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 512, 16384>, 4, 2, 2, 2>(),
-		entry2<TileCfg<7, 512, 16384>, 4, 2, 2, 3>(),
-		entry2<TileCfg<8, 512, 16384>, 4, 2, 3, 3>(),
-		entry2<TileCfg<9, 512, 16384>, 4, 2, 2, 2, 3>(),
-		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
-	},
-	{	/* variant 2: 128 KB tiles (one workgroup of 8 waves per CU): half the halo share of the 64 KB tiles */
-		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 512, 32768>, 2, 2, 2, 2>(),
-		entry2<TileCfg<7, 512, 32768>, 2, 2, 2, 3>(),
-		entry2<TileCfg<8, 512, 32768>, 2, 3, 3, 2>(),
-		entry2<TileCfg<9, 512, 32768>, 2, 3, 3, 3>(),
-		entry2<TileCfg<10, 512, 32768>, 2, 3, 3, 4>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
-	},
-	{	/* variant 3 */
-		entry<TileCfg<5, 256, 8192>, 4, 2, 3>(),
-		entry<TileCfg<6, 256, 8192>, 4, 2, 2, 2>(),
-		entry<TileCfg<7, 256, 8192>, 4, 2, 2, 3>(),
-		entry<TileCfg<8, 256, 8192>, 4, 2, 3, 3>(),
-		entry<TileCfg<9, 256, 8192>, 4, 3, 3, 3>(),
-		entry<TileCfg<10, 512, 16384>, 4, 3, 2, 2, 3>(),
-		entry<TileCfg<11, 512, 32768>, 2, 3, 3, 2, 3>(),
-	},
-	{	/* variant 4 */
-		entry2<TileCfg<5, 256, 16384>, 2, 1, 2, 2>(),
-		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
-		entry2<TileCfg<7, 256, 16384>, 2, 2, 2, 3>(),
-		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		entry2<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
-		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry2<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{	/* variant 5 */
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		entry<TileCfg<7, 256, 16384>, 2, 3, 4>(),
-		entry<TileCfg<8, 256, 16384>, 2, 4, 4>(),
-		entry<TileCfg<9, 256, 16384>, 2, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
-	},
-	{	/* variant 6: alternative stage groupings (tuning) */
-		entry2<TileCfg<5, 256, 8192>, 4, 1, 2, 2>(),
-		entry2<TileCfg<6, 256, 16384>, 2, 1, 2, 3>(),
-		entry2<TileCfg<7, 256, 16384>, 2, 1, 3, 3>(),
-		entry2<TileCfg<8, 256, 16384>, 2, 2, 3, 3>(),
-		entry2<TileCfg<9, 256, 16384>, 2, 2, 2, 2, 3>(),
-		entry2<TileCfg<10, 256, 16384>, 2, 3, 2, 2, 3>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 2, 3, 3>(),
-	},
-	{	/* variant 7: alternative stage groupings (tuning) */
-		entry2<TileCfg<5, 256, 16384>, 2, 2, 3>(),
-		entry2<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		entry2<TileCfg<7, 256, 16384>, 2, 3, 2, 2>(),
-		entry2<TileCfg<8, 256, 16384>, 2, 3, 2, 3>(),
-		entry2<TileCfg<9, 256, 16384>, 2, 3, 2, 2, 2>(),
-		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
-	},
-	{	/* variant 8: 128-thread workgroups, 128 samples per thread per pass (half the warm-up share) */
-		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 128, 16384>, 1, 2, 2, 2>(),
-		entry2<TileCfg<7, 128, 16384>, 1, 2, 2, 3>(),
-		entry2<TileCfg<8, 128, 16384>, 1, 3, 3, 2>(),
-		entry2<TileCfg<9, 128, 16384>, 1, 3, 3, 3>(),
-		entry2<TileCfg<10, 128, 16384>, 1, 3, 3, 4>(),
-		entry2<TileCfg<11, 256, 32768>, 1, 3, 4, 4>(),
-	},
-	{	/* variant 9: 32 KB tiles, four workgroups per CU (4 waves per SIMD), carry mode */
-		entry2c<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2c<TileCfg<6, 256, 8192>, 4, 2, 2, 2>(),
-		entry2c<TileCfg<7, 256, 8192>, 4, 2, 2, 3>(),
-		entry2c<TileCfg<8, 256, 8192>, 4, 3, 3, 2>(),
-		entry2c<TileCfg<9, 256, 8192>, 4, 3, 3, 3>(),
-		entry2c<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
-		entry2c<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
-		entry2c<TileCfg<12, 512, 32768>, 2, 3, 3, 3, 3>(),
-	},
-#endif
-#ifdef ACM_ABLATION
-	{	/* timing only: default geometry without the barriers inside the LDS passes */
-		entry2<TileCfg<5, 128, 8192>, 2, 2, 3>(),
-		entry2<TileCfg<6, 256, 16384>, 2, 2, 2, 2>(),
-		abl2<TileCfg<7, 256, 16384>, 2, 32, 2, 2, 3>(),
-		entry2<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl2<TileCfg<9, 256, 16384>, 2, 32, 3, 3, 3>(),
-		entry2<TileCfg<10, 256, 16384>, 2, 3, 3, 4>(),
-		entry2<TileCfg<11, 512, 32768>, 2, 3, 4, 4>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 1, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 1, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 2, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 2, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 4, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 4, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 6, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 6, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 8, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 8, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 16, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 16, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 17, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 17, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 23, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 23, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-	{
-		entry<TileCfg<5, 256, 16384>, 2, 3, 2>(),
-		entry<TileCfg<6, 256, 16384>, 2, 3, 3>(),
-		abl<TileCfg<7, 256, 16384>, 2, 19, 3, 2, 2>(),
-		entry<TileCfg<8, 256, 16384>, 2, 3, 3, 2>(),
-		abl<TileCfg<9, 256, 16384>, 2, 19, 3, 3, 3>(),
-		entry<TileCfg<10, 256, 16384>, 2, 3, 3, 2, 2>(),
-		entry<TileCfg<11, 256, 32768>, 1, 3, 3, 3, 2>(),
-	},
-#endif
+#include "acm_kernels_tuning.inc"     /* variants 1.. (-DACM_TUNING) and the timing-only ablation builds (-DACM_ABLATION) */
 };
 
 
@@ -1444,16 +1225,10 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
 		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
 		constexpr int off = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
 		constexpr int imm = off % 4096, far = off - imm;        /* 12 bits in the instruction, the rest on the scalar base */
-#ifdef ACM_EXP_NOWARM
-		if (b < 0) {
-			raw[K] = voff_warm;
-			return;
-		}
-#endif
 		if (ABL & 1)                            /* timing-only build: no HBM loads */
 			raw[K] = voff + off;
 		else
-			asm volatile("global_load_dword %0, %1, %2 offset:%3" ACM_EXP_LOAD_POLICY : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
+			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
 	template <int... Ks>
 	static __device__ __forceinline__ void load_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
@@ -1461,47 +1236,9 @@ struct FirstPass2 : FirstPass<C, G, W, ABL> {
 	{
 		(load_one<Ks>(raw, base, voff, voff_warm), ...);
 	}
-#ifdef ACM_EXP_X4
-	/* timing-only experiment: the same bytes as 16-byte loads, coalesced (what a first-pass-ordered staged layout would allow) */
-	template <int GRP>
-	static __device__ __forceinline__ void load_x4(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
-	{
-		typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-		constexpr int off = (GRP / 2) * COLS * 2 + (GRP % 2) * (COLS);      /* row GRP/2 of the segment's four, half GRP%2 of the row */
-		constexpr int imm = off % 4096, far = off - imm;
-		v4u t;
-#ifdef ACM_EXP_NOWARM
-		if (GRP < 4) {
-			t = v4u{ voff_warm, voff_warm, voff_warm, voff_warm };
-		} else
-#endif
-		asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t) : "v"(GRP < 4 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
-		raw[GRP * 4 + 0] = t.x;
-		raw[GRP * 4 + 1] = t.y;
-		raw[GRP * 4 + 2] = t.z;
-		raw[GRP * 4 + 3] = t.w;
-	}
-	template <int... Gs>
-	static __device__ __forceinline__ void load_x4_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
-							   std::integer_sequence<int, Gs...>)
-	{
-		(load_x4<Gs>(raw, base, voff, voff_warm), ...);
-	}
-	static __device__ __forceinline__ uint32_t lane_offset_x4(const int tid)
-	{
-		const int seg = tid / FP::TPS, j = tid % FP::TPS;
-		return (uint32_t)(seg * FP::RPS * COLS * 2 + j * 16);
-	}
-#endif
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
-#ifdef ACM_EXP_X4
-		if constexpr (NRAW == 32 && COLS * 2 / 2 == FP::TPS * 16) {
-			load_x4_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, 8>{});
-			return;
-		}
-#endif
 		load_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
 	}
 };
@@ -1555,11 +1292,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		t--;
 	}
 
-#ifdef ACM_EXP_X4
-	const uint32_t voff = (FP::NRAW == 32 && COLS == FP::TPS * 16) ? FP::lane_offset_x4(tid) : FP::lane_offset(tid);
-#else
 	const uint32_t voff = FP::lane_offset(tid);
-#endif
 	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
 
 	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589).  Every lane of every
@@ -1653,13 +1386,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 				const v4u o = { q[0], q[1], q[2], q[3] };
 				if ((ABL & 16) && o.x != 0x12345u)              /* timing-only build: no stores */
 					continue;
-#ifdef ACM_EXP_STORE_POLICY
-				asm volatile("global_store_dwordx4 %0, %1, off" ACM_EXP_STORE_POLICY :: "v"(&out[vec]), "v"(o) : "memory");
-#elif defined(ACM_K2_PLAIN_STORES)
-				out[vec] = o;
-#else
-				__builtin_nontemporal_store(o, &out[vec]);      /* PCM is written once and never read back here */
-#endif
+				__builtin_nontemporal_store(o, &out[vec]);      /* PCM is written once and never read back here (+1 % over plain stores;
+										 * sc1 / sc0 sc1 / sc1 nt: -0.8 ... +0.3 %, profiles/r3_level9_experiments.txt) */
 			}
 		}
 		ACM_STAMP(5);

@@ -37,6 +37,34 @@ __global__ void __launch_bounds__(256) copy_runs(const uint4 *__restrict__ src_,
     for (int k = 0; k < 4; k++) { if (NT_STORE) __builtin_nontemporal_store(v[k], &d[i + 256 * k]); else d[i + 256 * k] = v[k]; }
   }
 }
+#ifdef COPY_BW_LIB
+/* bench.py's "practical HBM ceiling of this box": the best of the copy kernels above on two fresh buffers of `bytes` each
+ * (read + written bytes / time); built into profiles/ubench/libcopybw.so by libacm_amd/_build.py, called through ctypes */
+extern "C" double acm_copy_ceiling_gbs(size_t bytes, char *best_name, size_t best_cap) {
+  const size_t n = bytes / 16;
+  uint4 *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return -1.0; }
+  (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  double best = 0;
+  auto timeit = [&](const char *name, auto launch) {
+    launch(); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); for (int r = 0; r < 5; r++) launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double gbs = 5 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    if (gbs > best) { best = gbs; if (best_name && best_cap) snprintf(best_name, best_cap, "%s", name); }
+  };
+  for (int rep = 0; rep < 2; rep++) {
+    timeit("copy unroll4, 4096 WGs", [&]() { hipLaunchKernelGGL(copy_unroll4, dim3(4096), dim3(256), 0, 0, a, b, n); });
+    timeit("contiguous runs, 1024 WGs", [&]() { hipLaunchKernelGGL((copy_runs<0, 0>), dim3(1024), dim3(256), 0, 0, a, b, n); });
+    timeit("contiguous runs, 1024 WGs, nt stores", [&]() { hipLaunchKernelGGL((copy_runs<0, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); });
+    timeit("contiguous runs, 1024 WGs, nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); });
+    timeit("contiguous runs, 2048 WGs, nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(2048), dim3(256), 0, 0, a, b, n); });
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+  return best;
+}
+#else
 int main() {
   const size_t bytes = 4ull << 30, n = bytes / 16;
   uint4 *a, *b; (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
@@ -65,3 +93,4 @@ int main() {
   timeit("write only, 2048 WGs", [&]() { hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, a, b, n); }, 1.0 * bytes);
   return 0;
 }
+#endif
