@@ -136,38 +136,32 @@ def workload_cpus():
 
 
 class PowerSampler:
-    """Socket power and shader clock of the GPU while a timed loop runs, from the amdgpu hwmon files (power1_input in uW,
-    power1_cap, freq1_input in Hz).  The level-9 kernel runs into the package power cap: the clock the chip holds under
-    it, not the issue slots or HBM, is what the launch time follows."""
+    """Socket power and shader clock of the GPU while the kernel runs, as `rocm-smi --showpower --showclocks` reads them
+    (the amdgpu hwmon power1_input file lags by seconds).  The level-9 kernel runs into the package power cap: the clock
+    the chip holds under it, not the issue slots or HBM, is what the launch time follows."""
 
-    def __init__(self, period=0.05):
-        import glob
+    def __init__(self):
+        import shutil
         import threading
-        self.dir = None
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-            try:
-                int(open(os.path.join(d, "power1_input")).read())
-                int(open(os.path.join(d, "freq1_input")).read())
-                self.dir = d
-                break
-            except (OSError, ValueError):
-                continue
-        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
-
-    def _read(self, name):
-        return int(open(os.path.join(self.dir, name)).read())
+        self.tool = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.samples, self._stop, self._th = [], threading.Event(), None
 
     def _run(self):
         while not self._stop.is_set():
             try:
-                self.samples.append((self._read("power1_input") / 1e6, self._read("freq1_input") / 1e6))
-            except (OSError, ValueError):
+                r = subprocess.run([self.tool, "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, text=True, timeout=5)
+                card = list(json.loads(r.stdout).values())[0]
+                w = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
+                f = [int(v.strip("()Mhz")) for k, v in card.items() if "sclk clock speed" in k]
+                if w and f:
+                    self.samples.append((w[0], f[0]))
+            except Exception:
                 pass
-            self._stop.wait(self.period)
 
     def start(self):
         import threading
-        if self.dir:
+        if self.tool:
             self._th = threading.Thread(target=self._run, daemon=True)
             self._th.start()
 
@@ -176,18 +170,22 @@ class PowerSampler:
             return None
         self._stop.set()
         self._th.join()
-        s = self.samples[1:-1] if len(self.samples) > 4 else self.samples
+        s = [x for x in self.samples if x[1] > 900]         # samples taken while the kernel was running
+        if len(s) > 4:
+            s = s[1:-1]
         if not s:
             return None
+        cap = None
         try:
-            cap = self._read("power1_cap") / 1e6
-        except (OSError, ValueError):
-            cap = None
+            r = subprocess.run([self.tool, "--showmaxpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5)
+            cap = [float(v) for k, v in list(json.loads(r.stdout).values())[0].items() if "ower" in k][0]
+        except Exception:
+            pass
         w = sorted(x[0] for x in s)
         f = sorted(x[1] for x in s)
         return {"socket_w_median": round(w[len(w) // 2], 1), "socket_w_max": round(w[-1], 1), "power_cap_w": cap,
-                "sclk_mhz_median": round(f[len(f) // 2]), "sclk_mhz_min": round(f[0]), "samples": len(s),
-                "source": "amdgpu hwmon (power1_input, freq1_input), sampled during the sustained run"}
+                "sclk_mhz_median": f[len(f) // 2], "sclk_mhz_max_of_device": 2400, "samples": len(s),
+                "source": "rocm-smi --showpower --showclocks, sampled during a 2 s run of the same launches behind the timed region"}
 
 
 def copy_ceiling():
@@ -473,22 +471,23 @@ def main():
         verified, n_verified = True, len(want)
 
     pre = precondition(dev, plan, bufs, PRECONDITION_S)
-    sampler = PowerSampler() if rank == 0 else None
-    if sampler and args.steps >= SUSTAINED_STEPS:
-        sampler.start()
     wall, ev_ms = time_plan(dev, plan, bufs, args.steps, args.warmup, barrier)
-    power = sampler.stop() if sampler and args.steps >= SUSTAINED_STEPS else None
     sustained = None
     if args.steps < SUSTAINED_STEPS:
         # the contract's K is short (tens of ms): the same loop again, long, right behind it
-        if sampler:
-            sampler.start()
         swall, sev = time_plan(dev, plan, bufs, SUSTAINED_STEPS, 0, barrier)
-        power = sampler.stop() if sampler else None
         sustained = {"steps": SUSTAINED_STEPS, "ms_per_step": round(swall / SUSTAINED_STEPS * 1e3, 4),
                      "launch_ms": round(sev / SUSTAINED_STEPS, 4),
                      "msamples_s_per_gpu": round(batch.samples * SUSTAINED_STEPS / swall / 1e6, 1),
                      "frac": round(batch.samples * ALGO_BYTES_PER_SAMPLE / (sev / SUSTAINED_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # what the chip's power and clock read while this kernel runs (untimed: 2 s of the same launches)
+    power = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        sampler = PowerSampler()
+        sampler.start()
+        precondition(dev, plan, bufs, 2.0)
+        power = sampler.stop()
 
     # the timed launches must have left exactly the verified PCM behind (the hot path carries no state between launches)
     if want is not None:
@@ -543,12 +542,14 @@ def main():
     # collect counters on itself.  The file records the kernel source it was measured on; another source -> null.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as f:
             tj = json.load(f)
         key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
+        if args.channels != 1:
+            key += "_ch%d" % args.channels
         if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
             traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r2_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
+            traffic_src = "profiles/r3_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
     except Exception:
         traffic = None
 

@@ -4,14 +4,20 @@
 # Counters are collected in passes of their own (never together with the trace), as MI355X_MICROARCH.md prescribes;
 # FETCH_SIZE is doubled by summarize.py / traffic_json.py (gfx950 counts 128-byte requests at 64 B).
 set -u
-TAG=${1:-r2}; shift || true
+# PROFILE_LIGHT=1: kernel trace + the two traffic passes + the clock pass only (big workloads whose staging takes minutes)
+TAG=${1:-r3}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 100 --warmup 20 --no-cpu --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 python3 bench.py $ARGS > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+if [ -n "${PROFILE_LIGHT:-}" ]; then GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"); else GROUPS_=(); fi
+for grp in "${GROUPS_[@]}"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-extra --no-verify $* > /dev/null 2> $OUT/pmc_$name.err
+done
+[ -n "${PROFILE_LIGHT:-}" ] || for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
