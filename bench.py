@@ -503,7 +503,15 @@ def main():
         s = torch.tensor([float(batch.samples), float(n_verified)], device="cuda:%d" % local, dtype=torch.float64)
         dist.all_reduce(s)
         total_samples, n_verified = float(s[0].item()), int(s[1].item())
+        # why the N-rank number is what it is: every rank's own launch time and sample count (the corpus is sharded
+        # longest-first by header weight; a rank that got more samples, or a slower chip, sets the job's time)
+        mine = torch.tensor([ev_ms / args.steps, float(batch.samples), float(len(batch.descs))], device="cuda:%d" % local, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "launch_ms": round(float(e[0]), 4), "msamples": round(float(e[1]) / 1e6, 1), "streams": int(e[2])}
+                    for r, e in enumerate(every)]
     else:
+        per_rank = None
         wall_max, total_samples = wall, float(batch.samples)
 
     # ---- C2 (N > 1): gather of every rank's PCM into rank 0's HBM over RCCL/xGMI, reported beside the headline
@@ -582,6 +590,12 @@ def main():
                                 if args.workload == "corpus" or 6 <= args.level <= 12 else "see DESIGN.md section 2 for level %s" % lv_txt),
                      "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
+    if per_rank:
+        ms = [p["launch_ms"] for p in per_rank]
+        sm = [p["msamples"] for p in per_rank]
+        out["per_rank"] = per_rank
+        out["imbalance"] = {"launch_ms_max_over_mean": round(max(ms) / (sum(ms) / len(ms)), 4),
+                            "samples_max_over_mean": round(max(sm) / (sum(sm) / len(sm)), 4)}
     if sustained:
         out["sustained"] = sustained
     if power:
