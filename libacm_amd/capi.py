@@ -371,7 +371,11 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
         whole[:] = 0
         outs = [whole[o:o + sz] for o, sz in zip(offs, sizes)]
     else:
-        outs = [np.zeros(sz, dtype=np.uint16) for sz in sizes]
+        # resident buffers (np.zeros hands out untouched pages: the library's copy-out threads would spend the call
+        # taking first-touch page faults, which is the caller's allocation policy, not the decode)
+        outs = [np.empty(sz, dtype=np.uint16) for sz in sizes]
+        for o in outs:
+            o.fill(0)
     items = (BatchItem * max(n, 1))()
     for k in range(n):
         items[k].data = bufs[k].ctypes.data

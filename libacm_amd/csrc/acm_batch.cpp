@@ -262,7 +262,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	const bool keep_on_device = opts.d_pcm != nullptr;
 	/* pinned caller buffers: the copy engine writes every stream's PCM where the caller wants it (one transfer per
 	 * stream, so only for streams big enough that the per-transfer cost disappears) */
-	const bool direct_out = !keep_on_device && (opts.flags & ACM_BATCH_PCM_PINNED) && n > 0 && pcm_total / n >= 32768;
+	bool direct_out = !keep_on_device && (opts.flags & ACM_BATCH_PCM_PINNED) && n > 0 && pcm_total / n >= 32768;
 	if (keep_on_device && opts.d_pcm_words < pcm_total)
 		return ACMHIP_ERR_ARG;
 	for (size_t i = 0; i < n; i++)
@@ -329,6 +329,52 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 	}
 
+	/* Block ranges (device parsing of a big batch into host buffers): the walk of a stream is one wavefront's sequential job -
+	 * 33 ms for two megasamples - and nothing can be synthesised or read back before it ends.  So the walk is cut into R
+	 * launches, each taking every stream R-th of its blocks further (the bit offset it stopped at stays on the device), and
+	 * the synthesis and the read-back of range r run while range r + 1 is walked.  The PCM arenas are range-major for that:
+	 * range r of every stream back to back, one transfer per range; the copy-out puts the pieces where the caller wants them. */
+	size_t R = 1;
+	{
+		size_t ok_streams = 0;
+		for (const Slot &s : slots)
+			ok_streams += s.ok;
+		/* a range of ~128 Msamples is walked in ~2 ms and read back in ~5: 2 ... 16 ranges from 256 Msamples on (measured on
+		 * the 2.1-Gsample batch: 0.136 / 0.114 / 0.106 / 0.104 s with 1 / 4 / 8 / 16 ranges, profiles/r3_batch_timeline.txt) */
+		size_t want = idx_total >= (256u << 20) ? (size_t)std::min<uint64_t>(16, idx_total >> 27) : 1;
+		if (const char *e = getenv("ACM_BATCH_RANGES"))         /* tests / measurements: force a range count (1 = off) */
+			want = (size_t)std::max(1, atoi(e));
+		if (want > 1 && want <= 64 && dev_parse && !keep_on_device && !dev_ids.empty() && dev_ids.size() == ok_streams &&
+		    dev_ids.size() <= ACM_PARSE_RANGE_MAX_STREAMS)
+			R = want;
+		if (R > 1)
+			direct_out = false;     /* one transfer per range into the library's arena; pinned caller buffers make the copy-out fault-free */
+	}
+	std::vector<uint64_t> piece_off, piece_len, rbase;      /* [r * n + i]: where range r of stream i sits in the PCM arenas, words */
+	uint64_t pcm_arena_words = pcm_total;
+	if (R > 1) {
+		piece_off.assign(R * n, 0);
+		piece_len.assign(R * n, 0);
+		rbase.assign(R + 1, 0);
+		uint64_t at = 0;
+		for (size_t r = 0; r < R; r++) {
+			rbase[r] = at;
+			for (size_t i = 0; i < n; i++) {
+				const Slot &s = slots[i];
+				if (!s.ok)
+					continue;
+				const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+				const uint64_t words = deliverable_words(s.info.total_values, bl, s.info.channels, s.need_blocks);
+				const uint64_t lo = std::min(words, s.need_blocks * r / R * bl), hi = std::min(words, s.need_blocks * (r + 1) / R * bl);
+				piece_off[r * n + i] = at;
+				piece_len[r * n + i] = hi - lo;
+				at += round_up(hi - lo, 64);
+			}
+		}
+		rbase[R] = at;
+		pcm_arena_words = std::max(at, pcm_total);
+	}
+
 	const auto t_hdr = clk::now();
 	int16_t *h_idx = nullptr, *h_pcm = nullptr, *d_idx = nullptr, *d_pcm = nullptr;
 	uint32_t *d_colpos = nullptr;
@@ -344,6 +390,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	const size_t npg = dev_parse && !dev_ids.empty() ? chunks.size() : 0;
 	hipStream_t st_up = nullptr, st_parse = nullptr;        /* file uploads piece by piece; the walk + column kernels */
 	std::vector<ParseGroup> groups(npg);
+	std::vector<Chunk> rchunks(R > 1 ? R : 0);              /* block ranges: plan, events and read-back state of each */
 
 	auto cleanup = [&]() {
 		if (pool_busy) {
@@ -365,12 +412,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			for (hipEvent_t e : g.ev)
 				if (e)
 					(void)hipEventDestroy(e);
-		for (Chunk &ch : chunks) {
-			acmhip_plan_destroy(ch.plan);
-			for (hipEvent_t e : ch.ev)
-				if (e)
-					(void)hipEventDestroy(e);
-		}
+		for (std::vector<Chunk> *v : { &chunks, &rchunks })
+			for (Chunk &ch : *v) {
+				acmhip_plan_destroy(ch.plan);
+				for (hipEvent_t e : ch.ev)
+					if (e)
+						(void)hipEventDestroy(e);
+			}
 		acmhip_arena_unlock(dev);
 	};
 #define BTRY(call) do { rc = (call); if (rc != ACMHIP_OK) { cleanup(); return rc; } } while (0)
@@ -383,13 +431,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
 	}
 	if (!keep_on_device && !direct_out)
-		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_total * sizeof(int16_t), (void **)&h_pcm));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_arena_words * sizeof(int16_t), (void **)&h_pcm));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&d_hdr));
 	if (keep_on_device)
 		d_pcm = static_cast<int16_t *>(opts.d_pcm);
 	else
-		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_total * sizeof(int16_t), (void **)&d_pcm));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_arena_words * sizeof(int16_t), (void **)&d_pcm));
 	const size_t jobs_bytes = round_up(dev_ids.size() * sizeof(AcmParseJob), 64);
 	const size_t res_bytes = dev_ids.size() * (sizeof(AcmParseResult) + sizeof(uint32_t));  /* results, then flags */
 	if (!dev_ids.empty()) {
@@ -399,9 +447,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, jobs_bytes + res_bytes, (void **)&h_jobs));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, jobs_bytes + res_bytes, (void **)&d_jobs));
 	}
-	for (Chunk &ch : chunks)
-		for (hipEvent_t &e : ch.ev)
-			HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
+	for (std::vector<Chunk> *v : { &chunks, &rchunks })
+		for (Chunk &ch : *v)
+			for (hipEvent_t &e : ch.ev)
+				HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
 	if (!groups.empty()) {
 		BTRY(acmhip_aux_stream(dev, ACM_AUX_STREAMS - 1, (void **)&st_up));
 		BTRY(acmhip_aux_stream(dev, 0, (void **)&st_parse));
@@ -502,7 +551,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	const size_t ncopy = groups.empty() ? 0 : dev_ids.size();
 	const size_t nparse = host_ids.size();
 	pool_busy = true;
-	pool.start(ncopy + nparse + out_ids.size(), [&](size_t task) {
+	pool.start(ncopy + nparse + out_ids.size() * R, [&](size_t task) {
 		if (task < ncopy) {
 			const size_t i = dev_ids[task];
 			const acm_batch_item &it = items[i];
@@ -528,20 +577,36 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			}
 			return;
 		}
-		const size_t i = out_ids[task - nparse];
+		/* copy-out: a whole stream of its chunk - or, with block ranges, one range's piece of a stream */
+		const size_t piece = (task - nparse) / out_ids.size();          /* 0 without ranges */
+		const size_t i = out_ids[(task - nparse) % out_ids.size()];
 		const Slot &s = slots[i];
-		Chunk &ch = chunks[s.chunk];
+		const size_t unit = R > 1 ? piece : s.chunk;
+		Chunk &ch = R > 1 ? rchunks[piece] : chunks[s.chunk];
 		if (ch.back.load(std::memory_order_acquire) == 0) {     /* first one here waits for the chunk */
-			if (issued.load(std::memory_order_acquire) <= s.chunk) {
+			if (issued.load(std::memory_order_acquire) <= unit) {
 				std::unique_lock<std::mutex> g(m);
-				cv.wait(g, [&]() { return aborted || issued.load() > s.chunk; });
+				cv.wait(g, [&]() { return aborted || issued.load() > unit; });
 				if (aborted)
 					return;
 			}
 			const bool good = hipEventSynchronize(ch.ev[4]) == hipSuccess;
 			ch.back.store(good ? 1 : -1, std::memory_order_release);
+			BNOTE("%s %zu is back", R > 1 ? "range" : "chunk", unit);
 		}
-		if (ch.back.load(std::memory_order_acquire) < 0 || !s.ok || items[i].words == 0)
+		if (ch.back.load(std::memory_order_acquire) < 0 || !s.ok)
+			return;
+		if (R > 1) {
+			/* the piece starts where the stream's earlier ranges end (they are whole blocks); a stream the device flags
+			 * later is decoded again from the host reader's staging and copied out whole (fix-up, below) */
+			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+			const uint64_t lo = s.need_blocks * piece / R * bl, len = piece_len[piece * n + i];
+			if (lo >= items[i].pcm_cap || len == 0)
+				return;
+			memcpy(items[i].pcm + lo, h_pcm + piece_off[piece * n + i], std::min<uint64_t>(len, items[i].pcm_cap - lo) * sizeof(int16_t));
+			return;
+		}
+		if (items[i].words == 0)
 			return;
 		const uint64_t w = std::min<uint64_t>(items[i].words, items[i].pcm_cap);
 		memcpy(items[i].pcm, h_pcm + s.pcm_off, w * sizeof(int16_t));
@@ -585,7 +650,29 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * device parser flags later gets its chunk's plan rebuilt), while the queues are still empty - a plan's small table
 	 * uploads otherwise wait behind whatever long walk kernel shares their hardware queue */
 	std::vector<char> planned(chunks.size(), 0), replan(chunks.size(), 0);
-	if (!groups.empty()) {
+	/* block ranges: one plan per range over every stream's piece (a window of the stream that starts at the range's first row;
+	 * the staged rows in front of it are on the device by then: earlier ranges) */
+	for (size_t r = 0; r < rchunks.size(); r++) {
+		std::vector<acmhip_stream_desc> descs;
+		for (size_t i = 0; i < n; i++) {
+			const Slot &s = slots[i];
+			if (!s.ok || piece_len[r * n + i] == 0)
+				continue;
+			acmhip_stream_desc d{};
+			d.idx_off = s.idx_off;
+			d.hdr_off = s.hdr_off;
+			d.pcm_off = piece_off[r * n + i];
+			d.level = s.info.level;
+			d.rows = s.info.rows;
+			d.nrows = (uint32_t)(s.need_blocks * (r + 1) / R) * s.info.rows;
+			d.row_begin = (uint32_t)(s.need_blocks * r / R) * s.info.rows;
+			d.n_emit = piece_len[r * n + i];
+			descs.push_back(d);
+		}
+		if (!descs.empty())
+			BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), nullptr, 0, opts.plan_flags, &rchunks[r].plan));
+	}
+	if (!groups.empty() && R == 1) {
 		for (size_t c = 0; c < chunks.size(); c++) {
 			bool all_dev = true;
 			for (size_t i = chunks[c].first; i < chunks[c].last; i++)
@@ -632,15 +719,39 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		HTRY(hipEventRecord(ev_parsed, st_up));         /* re-recorded below: here it only orders the walk behind the last upload */
 		HTRY(hipStreamWaitEvent(st_parse, ev_parsed, 0));
 		HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_parse));
-		const int e = acmk_launch_parse(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx, d_hdr,
-						d_res, d_flags, max_columns, st_parse);
-		HTRY((hipError_t)e);
+		for (size_t r = 0; r < R; r++) {
+			const int e = acmk_launch_parse_range(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx,
+							      d_hdr, d_res, d_flags, max_columns, (uint32_t)r, (uint32_t)R, st_parse);
+			HTRY((hipError_t)e);
+			if (R == 1)
+				break;
+			/* range r is staged: synthesise it and read it back while the walk goes on */
+			Chunk &rg = rchunks[r];
+			HTRY(hipEventRecord(rg.ev[1], st_parse));
+			HTRY(hipStreamWaitEvent(st_main, rg.ev[1], 0));
+			HTRY(hipEventRecord(rg.ev[0], st_main));
+			if (rg.plan)
+				BTRY(acmhip_plan_launch(rg.plan, d_idx, d_hdr, d_pcm, opts.fmt));
+			HTRY(hipEventRecord(rg.ev[2], st_main));
+			HTRY(hipStreamWaitEvent(st_copy, rg.ev[2], 0));
+			HTRY(hipEventRecord(rg.ev[3], st_copy));
+			if (rbase[r + 1] > rbase[r])
+				HTRY(hipMemcpyAsync(h_pcm + rbase[r], d_pcm + rbase[r], (rbase[r + 1] - rbase[r]) * sizeof(int16_t), hipMemcpyDeviceToHost, st_copy));
+			HTRY(hipEventRecord(rg.ev[4], st_copy));
+			BNOTE("range %zu: walk, synthesis and read-back queued", r);
+			{
+				std::lock_guard<std::mutex> g(m);
+				issued.store(r + 1, std::memory_order_release);
+			}
+			cv.notify_all();
+		}
 		HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_parse));
 		HTRY(hipEventRecord(ev_parsed, st_parse));
 	}
 	clk::time_point t_dev_parsed = t_alloc;
 	/* what the device parser said; the streams it flags go through the exact host reader here */
 	bool settled = false;
+	std::vector<size_t> redo;               /* block ranges: streams the device flagged - decoded again from the host reader's staging */
 	auto settle = [&]() -> int {
 		if (settled || !ev_parsed)
 			return ACMHIP_OK;
@@ -652,6 +763,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		for (size_t k = 0; k < dev_ids.size(); k++) {
 			const size_t i = dev_ids[k];
 			Slot &s = slots[i];
+			if (R > 1 && (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0)) {
+				redo.push_back(i);
+				continue;
+			}
 			if (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0) {
 				if (!h_idx) {
 					int r = acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx);
@@ -675,8 +790,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		return ACMHIP_OK;
 	};
 
-	/* 3. this thread feeds the device, chunk by chunk */
-	for (size_t c = 0; c < chunks.size(); c++) {
+	/* 3. this thread feeds the device, chunk by chunk (with block ranges the loop above has queued everything already) */
+	for (size_t c = 0; c < chunks.size() && R == 1; c++) {
 		Chunk &ch = chunks[c];
 		if (ev_parsed) {
 			BTRY(settle());
@@ -737,16 +852,79 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 		cv.notify_all();
 	}
+	if (R > 1)
+		BTRY(settle());
 	pool.wait();
 	pool_busy = false;
 	BNOTE("pool done");
 	HTRY(hipStreamSynchronize(st_copy));
 	HTRY(hipStreamSynchronize(st_main));
+	if (R > 1) {
+		/* fix-up (rare): what the device parser flagged goes through the exact host reader and one more plan, stream by
+		 * stream in the now idle arenas; its PCM replaces whatever the ranges copied out for these streams */
+		if (!redo.empty()) {
+			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
+			BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
+			std::vector<acmhip_stream_desc> descs;
+			std::vector<acmhip_patch> patches;
+			std::vector<size_t> live;
+			for (size_t i : redo) {
+				host_stage(i);
+				tm.host_parsed++;
+				Slot &s = slots[i];
+				if (!s.ok || items[i].words == 0 || s.info.blocks == 0)
+					continue;
+				const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+				HTRY(hipMemcpyAsync(d_idx + s.idx_off, h_idx + s.idx_off, s.info.blocks * bl * sizeof(int16_t), hipMemcpyHostToDevice, st_main));
+				HTRY(hipMemcpyAsync(d_hdr + s.hdr_off, h_hdr + s.hdr_off, s.info.blocks * sizeof(acmhip_blkhdr), hipMemcpyHostToDevice, st_main));
+				acmhip_stream_desc d{};
+				d.idx_off = s.idx_off;
+				d.hdr_off = s.hdr_off;
+				d.pcm_off = s.pcm_off;
+				d.level = s.info.level;
+				d.rows = s.info.rows;
+				d.nrows = s.info.blocks * s.info.rows;
+				d.n_emit = items[i].words;
+				for (acmhip_patch p : s.patches) {
+					p.stream = (uint32_t)descs.size();
+					patches.push_back(p);
+				}
+				descs.push_back(d);
+				live.push_back(i);
+			}
+			if (!descs.empty()) {
+				acmhip_plan *fix = nullptr;
+				BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &fix));
+				rc = acmhip_plan_launch(fix, d_idx, d_hdr, d_pcm, opts.fmt);
+				for (size_t i : live)
+					if (rc == ACMHIP_OK && items[i].pcm) {
+						const uint64_t w = std::min<uint64_t>(items[i].words, items[i].pcm_cap);
+						if (hipMemcpyAsync(h_pcm + slots[i].pcm_off, d_pcm + slots[i].pcm_off, w * sizeof(int16_t), hipMemcpyDeviceToHost, st_main) != hipSuccess)
+							rc = acmhip_report_hip((int)hipGetLastError(), "fix-up read-back");
+					}
+				if (rc == ACMHIP_OK && hipStreamSynchronize(st_main) != hipSuccess)
+					rc = acmhip_report_hip((int)hipGetLastError(), "fix-up");
+				acmhip_plan_destroy(fix);
+				if (rc != ACMHIP_OK) {
+					cleanup();
+					return rc;
+				}
+				for (size_t i : live)
+					if (items[i].pcm)
+						memcpy(items[i].pcm, h_pcm + slots[i].pcm_off, std::min<uint64_t>(items[i].words, items[i].pcm_cap) * sizeof(int16_t));
+			}
+			BNOTE("fix-up of %zu flagged streams done", redo.size());
+		}
+		for (size_t i = 0; i < n; i++)
+			if (slots[i].ok)
+				tm.samples += items[i].words;
+	}
 #undef BTRY
 #undef HTRY
 
 	/* the phases overlap; report the device-side time each one took (summed over chunks) and the wall clock */
-	for (Chunk &ch : chunks) {
+	for (std::vector<Chunk> *v : { &chunks, &rchunks })
+	for (Chunk &ch : *v) {
 		if (!ch.plan)
 			continue;
 		float ms = 0;

@@ -69,7 +69,9 @@ struct AcmParseJob {
 };
 struct AcmParseResult {
 	uint32_t blocks_done;
-	uint32_t status;       /* 0 = the scan walked every block; else the host must re-parse this stream */
+	uint32_t status;       /* 0 = the scan walked every block it was asked for; else the host must re-parse this stream */
+	uint32_t end_bit;      /* bit offset behind the last block walked: where the next block range of the stream resumes */
+	uint32_t pad;
 };
 
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
@@ -127,6 +129,12 @@ int acmk_launch_stage(const AcmDevStream *d_streams, const uint32_t *d_list, uin
 int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file_len, uint64_t blocks);
 int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 		      acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream);
+/* the same for block range r of R: stream j's blocks [blocks * r / R, blocks * (r + 1) / R), resuming at the bit offset range
+ * r - 1 left in d_res (ranges are launched in order on one stream; njobs <= ACM_PARSE_RANGE_MAX_STREAMS) */
+#define ACM_PARSE_RANGE_MAX_STREAMS 32768
+int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
+			    acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,
+			    void *stream);
 int acmk_launch_small(uint32_t level, const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
 		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,

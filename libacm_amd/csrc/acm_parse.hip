@@ -365,7 +365,8 @@ constexpr int WAVE_SCAN_WAVES = 4;      /* streams per workgroup: one per SIMD o
 
 __global__ void __launch_bounds__(64 * WAVE_SCAN_WAVES)
 acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
-		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res)
+		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res,
+		    const uint32_t range, const uint32_t nranges)
 {
 	const uint32_t jobno = blockIdx.x * WAVE_SCAN_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (jobno >= njobs)
@@ -381,11 +382,19 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	ww.w = reinterpret_cast<const uint32_t *>(files + job.file_off);
 	ww.maxdw = (job.file_len + 15u) / 4u;
 	ww.lane = lane;
+	/* block range `range` of `nranges` (1 of 1: the whole stream): a later range resumes where the one before stopped */
+	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges), b_hi = (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges);
 	uint32_t bit = job.data_start * 8u;
+	if (range > 0) {
+		const AcmParseResult prev = res[jobno];
+		if (prev.status != 0 || prev.blocks_done != b_lo)
+			return;                                 /* the stream failed earlier: its record stays as it is */
+		bit = prev.end_bit;
+	}
 	ww.load(bit >> 5);
-	uint32_t done = 0, status = 1;
-	uint32_t *cp = colpos + job.col_off;
-	for (uint32_t b = 0; b < job.blocks; b++) {
+	uint32_t done = b_lo, status = 1;
+	uint32_t *cp = colpos + job.col_off + (uint64_t)b_lo * cols;
+	for (uint32_t b = b_lo; b < b_hi; b++) {
 		if (bit + 20 > safe)
 			goto out;
 		const uint32_t h20 = (uint32_t)ww.peek64(bit) & 0xFFFFFu;
@@ -430,7 +439,7 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	status = 0;
 out:
 	if (lane == 0)
-		res[jobno] = AcmParseResult{ done, status };
+		res[jobno] = AcmParseResult{ done, status, bit, 0u };
 }
 
 /* ---- kernel 2: decode the columns ---- */
@@ -507,7 +516,8 @@ __device__ uint32_t lut_entry(uint32_t code, uint32_t bits)
 __global__ void __launch_bounds__(COL_THREADS)
 acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__restrict__ res,
 		  const uint8_t *__restrict__ files, const uint32_t *__restrict__ colpos,
-		  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ idx, uint32_t *__restrict__ flags)
+		  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ idx, uint32_t *__restrict__ flags,
+		  const uint32_t range, const uint32_t nranges)
 {
 	__shared__ uint32_t lut[LUT_CLASSES * 128];
 	{
@@ -521,12 +531,15 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 	if (rs.status != 0)
 		return;                                         /* the host redoes the whole stream */
 	const uint32_t rows = job.rows, level = job.level, cols = 1u << level;
-	const uint32_t ncol = rs.blocks_done << level;          /* blocks * cols < 2^32 (acmk_parse_supported) */
+	/* the columns of the blocks the walk has just covered (block range `range` of `nranges`) */
+	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges);
+	const uint32_t b_hi = min(rs.blocks_done, (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges));
+	const uint32_t ncol = b_hi << level;                    /* blocks * cols < 2^32 (acmk_parse_supported) */
 	const uint64_t bl = (uint64_t)rows << level;
 	const uint32_t *base = reinterpret_cast<const uint32_t *>(files + job.file_off);
 	uint32_t bad = 0;
 
-	for (uint32_t g = blockIdx.x * COL_THREADS + threadIdx.x; g < ncol; g += gridDim.x * COL_THREADS) {
+	for (uint32_t g = (b_lo << level) + blockIdx.x * COL_THREADS + threadIdx.x; g < ncol; g += gridDim.x * COL_THREADS) {
 		const uint32_t b = g >> level, c = g & (cols - 1);
 		const int lim = 1 << hdr[job.hdr_off + b].pwr;
 		int16_t *out = idx + job.idx_off + (uint64_t)b * bl + c;
@@ -584,12 +597,15 @@ extern "C" int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file
  * d_flags[njobs] must be zero on entry; after the kernels a stream is clean iff
  * d_res[j].status == 0 && d_res[j].blocks_done == jobs[j].blocks && d_flags[j] == 0.
  */
-extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files,
-				 uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
-				 AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream)
+extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files,
+				       uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
+				       AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t range, uint32_t nranges,
+				       void *stream)
 {
 	if (njobs == 0)
 		return 0;
+	if (nranges == 0 || range >= nranges || (nranges > 1 && njobs > ACM_PARSE_RANGE_MAX_STREAMS))
+		return (int)hipErrorInvalidValue;
 	hipStream_t st = (hipStream_t)stream;
 	const uint32_t full = (njobs + SCAN_THREADS - 1) / SCAN_THREADS;
 	const uint32_t scan_waves = njobs < 8192u ? njobs : full < 8192u ? 8192u : full;
@@ -603,14 +619,18 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 		wave_max = (uint32_t)atoi(getenv("ACM_PARSE_WAVE_MAX"));
 	if (scan_mode == 0)
 		wave_max = 0;
-	if (njobs <= wave_max && scan_mode == 1)
+	if (nranges > 1)                                        /* block ranges exist in the wave-per-stream walk only */
+		wave_max = ACM_PARSE_RANGE_MAX_STREAMS;
+	else if (njobs <= wave_max && scan_mode == 1)
 		hipLaunchKernelGGL(acm_parse_scan_lone, dim3(njobs), dim3(SCAN_THREADS), 0, st,
 				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
+	if (nranges == 1 && njobs <= wave_max && scan_mode == 1)
+		;
 	else
 #endif
 	if (njobs <= wave_max)
 		hipLaunchKernelGGL(acm_parse_scan_wave, dim3((njobs + WAVE_SCAN_WAVES - 1) / WAVE_SCAN_WAVES), dim3(64 * WAVE_SCAN_WAVES), 0, st,
-				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res, range, nranges);
 	else
 		hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
 				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
@@ -623,8 +643,15 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 	for (uint32_t at = 0; at < njobs; at += 65535) {
 		const uint32_t n = njobs - at < 65535 ? njobs - at : 65535;
 		hipLaunchKernelGGL(acm_parse_columns, dim3((unsigned)gx, n), dim3(COL_THREADS), 0, st,
-				   d_jobs + at, d_res + at, d_files, d_colpos, d_hdr, d_idx, d_flags + at);
+				   d_jobs + at, d_res + at, d_files, d_colpos, d_hdr, d_idx, d_flags + at, range, nranges);
 		ACMP_CHECK();
 	}
 	return 0;
+}
+
+extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files,
+				 uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
+				 AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream)
+{
+	return acmk_launch_parse_range(d_jobs, njobs, d_files, d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, 0, 1, stream);
 }

@@ -501,6 +501,36 @@ def test_device_walk_k_columns(dev):
         assert np.array_equal(devr[k][1], want), k
 
 
+@pytest.mark.parametrize("ranges", ["2", "3", "8"])
+def test_batch_block_ranges(dev, ranges, monkeypatch):
+    """device parsing in block ranges (acm_batch.cpp: the walk of every stream is cut into R launches, the synthesis and the
+    read-back of range r overlap the walk of range r + 1, PCM arenas range-major): forced on a small batch - streams with
+    fewer blocks than ranges, ragged ends, stereo, levels with and without the lean kernel, a truncated file and streams
+    with out-of-range indices (the device flags them: fix-up through the host reader), something that is not ACM"""
+    monkeypatch.setenv("ACM_BATCH_RANGES", ranges)
+    files = []
+    for i in range(41):
+        lv = [7, 9, 5, 3, 11, 0, 13, 8][i % 8]
+        rows = [16, 3, 1, 33][i % 4]
+        nb = 1 + (i * 7) % 23
+        files.append(make_stream(9700 + i, lv, rows, nb, channels=1 + i % 2, cut=i % 5))
+    files[6] = files[6][:len(files[6]) * 2 // 3]
+    files[13] = b"RIFFnope"
+    files[20] = make_stream(9790, 7, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    files[21] = make_stream(9791, 9, 4, 9, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6, cut=3)
+    import oracle_api as O
+    for rep in range(2):
+        res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE)
+        assert tm.host_parsed >= 2 and tm.device_parsed >= 30
+        for k, f in enumerate(files):
+            o = O.Oracle(f)
+            if o.err < 0:
+                assert res[k][0] == o.err and res[k][1].size == 0, k
+                continue
+            want, wst = oracle_pcm(f)
+            assert res[k][0] == wst and np.array_equal(res[k][1], want), (k, ranges)
+
+
 def test_device_walk_lane_kernel(dev):
     """more streams than the wave-per-stream walk takes (32 K): one stream per lane (acm_parse_scan)"""
     files = [make_stream(9100 + i % 97, 3 + i % 2, 2, 1 + i % 2, cut=i % 3) for i in range(33000)]
