@@ -45,7 +45,7 @@
 #include "acm_device.h"
 
 #ifndef ACM_L13_GROUPS
-#define ACM_L13_GROUPS 3, 2, 3, 3, 2
+#define ACM_L13_GROUPS 2, 3, 3, 3, 2
 #endif
 
 namespace {
@@ -612,7 +612,7 @@ struct TileCtx {
  * the stage-wise kernels: levels 13-15) instead of staged indices - no unpack multiply, no "+1" */
 constexpr int MODE_PLANE = 64;
 
-template <class C, int G, int W, int ABL = 0>
+template <class C, int G, int W, int ABL = 0, bool FORCE_WARM = false>
 struct FirstPass {
 	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS;
 	static constexpr int U = 1 << G, BODY = 2 * U;
@@ -621,7 +621,7 @@ struct FirstPass {
 	static constexpr int NSEG = NT / TPS;                   // row segments per tile
 	static constexpr int RPS = C::TR / NSEG;                // rows per segment
 	static constexpr int NB = RPS / 2;                      // bodies (row pairs) per segment
-	static constexpr bool WARM = NSEG > 1;                  // segments > 0 re-run the two rows in front of them
+	static constexpr bool WARM = NSEG > 1 || FORCE_WARM;    // segments > 0 re-run the two rows in front of them (FORCE_WARM: segment 0 too)
 	static constexpr int NRAW = (NB + (WARM ? 1 : 0)) * BODY;   // loaded registers: one per (row, q), W samples each
 	static constexpr bool PLANE = (ABL & MODE_PLANE) != 0;
 	static constexpr int NREG = NRAW * (PLANE ? W : 1);        // a plane holds int32: the second column of a lane sits NRAW further on
@@ -1205,8 +1205,8 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
  * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
  */
 template <class C, int G, int W, int ABL = 0>
-struct FirstPass2 : FirstPass<C, G, W, ABL> {
-	using FP = FirstPass<C, G, W, ABL>;
+struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segment, the first one included, re-runs the two rows in front of it */
+	using FP = FirstPass<C, G, W, ABL, true>;
 	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
 	static constexpr bool WARM = FP::WARM;
 	static_assert(FP::WARM, "K2 geometry: every segment re-runs the two rows in front of it");
@@ -1447,8 +1447,11 @@ const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
 	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
 	/* level 13: four rows are 128 KB - one workgroup of sixteen waves per CU (still four per SIMD), no plane, no prefix sweep:
-	 * 4 B of HBM traffic per sample instead of the 12 B of the prefix + plane pair */
-	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),      /* (3,3,3,2,2) spills six registers */
+	 * 4 B of HBM traffic per sample instead of the 12 B of the prefix + plane pair.  A two-stage first pass makes the
+	 * whole tile ONE segment (1024 threads x two adjacent columns = the 2048 residues of stride 2048): two warm-up rows per
+	 * four rows instead of per two, 24 instead of 32 prefetch registers: +8 % over (3,2,3,3,2) (2.94 against 3.18 ms for
+	 * 2.1 Gsamples; at levels 10 and 11 the same trade loses 3 %: an LDS-pass stage costs more than a first-pass stage) */
+	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {
