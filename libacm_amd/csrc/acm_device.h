@@ -79,7 +79,7 @@ struct AcmParseResult {
 #define ACM_K1_MAX_LEVEL 12
 /* levels the lean tile kernel (acm_tile2) covers (measured: 32 KB tiles lose to the 64-128 KB tiles of acm_fused_tile from level 10 on) */
 #define ACM_K2_MIN_LEVEL 6
-#define ACM_K2_MAX_LEVEL 13
+#define ACM_K2_MAX_LEVEL 14
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 

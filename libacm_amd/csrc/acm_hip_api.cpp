@@ -435,19 +435,19 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	acmhip_plan_stats st{};
 	const int variant = pick_variant();
 
-	/* level 13: four rows are one 128 KB tile of the lean kernel.  Whether the batch is worth its one lead-in tile per
-	 * workgroup is known only from all its streams: counted here, decided before the streams are cut */
-	bool k2_level13 = false;
-	{
-		const uint32_t T13 = (uint32_t)acmk_tile2_rows(13);
+	/* levels 13 and 14: four rows / two rows are one 128 KB tile of the lean kernel.  Whether a batch is worth its one
+	 * lead-in tile per workgroup is known only from all its streams: counted here, decided before the streams are cut */
+	bool k2_high[16] = {};
+	for (uint32_t lv = ACM_K1_MAX_LEVEL + 1; lv <= ACM_K2_MAX_LEVEL; lv++) {
+		const uint32_t TH = (uint32_t)acmk_tile2_rows(lv);
 		uint64_t whole = 0;
-		for (size_t i = 0; i < n && T13; i++) {
+		for (size_t i = 0; i < n && TH; i++) {
 			const acmhip_stream_desc &s = streams[i];
-			if (s.level == 13 && s.row_begin == 0 && !has_patch[i] && s.nrows >= s.row_begin)
-				whole += std::min<uint64_t>(s.nrows, s.n_emit >> 13) / T13;
+			if (s.level == lv && s.row_begin == 0 && !has_patch[i])
+				whole += std::min<uint64_t>(s.nrows, s.n_emit >> lv) / TH;
 		}
-		const size_t grid13 = (size_t)acmk_tile2_grid(13, dev->cus);
-		k2_level13 = k2_allowed && prefix_allowed && T13 && grid13 && (getenv("ACM_K2") ? whole > 0 : whole >= 8 * grid13);
+		const size_t gridh = (size_t)acmk_tile2_grid(lv, dev->cus);
+		k2_high[lv] = k2_allowed && prefix_allowed && TH && gridh && (getenv("ACM_K2") ? whole > 0 : whole >= 8 * gridh);
 	}
 
 	for (size_t i = 0; i < n; i++) {
@@ -554,21 +554,21 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		} else if (prefix_allowed && s.level > ACM_K1_MAX_LEVEL) {
 			uint32_t sid = (uint32_t)i;             /* the stream the prefix + plane pair works on: this one, or the rest of it */
 			AcmDevStream src = d;
-			if (k2_level13 && s.level == 13 && s.row_begin == 0 && !has_patch[i]) {
-				/* the whole four-row tiles go to the lean tile kernel; whatever is left - the ragged tail - is a window of the
+			if (k2_high[s.level] && s.row_begin == 0 && !has_patch[i]) {
+				/* the whole tiles go to the lean tile kernel; whatever is left - the ragged tail - is a window of the
 				 * stream (a pseudo stream behind the n real ones) for the prefix + plane pair */
-				const uint32_t T2 = (uint32_t)acmk_tile2_rows(13);
-				const uint64_t rows2 = std::min<uint64_t>(s.nrows, s.n_emit >> 13) / T2 * T2;
+				const uint32_t T2 = (uint32_t)acmk_tile2_rows(s.level);
+				const uint64_t rows2 = std::min<uint64_t>(s.nrows, s.n_emit >> s.level) / T2 * T2;
 				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
 				for (uint64_t r = 0; r < rows2; r += T2) {
 					const uint64_t rh = r >= 2 ? r - 2 : 0;
-					tiles2[13].push_back(AcmTile2{ s.idx_off + (r << 13), s.pcm_off + (r << 13),
-								       (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-								       r == 0 ? ACM_TILE_FRESH : 0u });
+					tiles2[s.level].push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
+									    (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
+									    r == 0 ? ACM_TILE_FRESH : 0u });
 				}
 				if (rows2 > 0) {
-					src.pcm_off = s.pcm_off + (rows2 << 13);
-					src.n_emit = s.n_emit - (rows2 << 13);
+					src.pcm_off = s.pcm_off + (rows2 << s.level);
+					src.n_emit = s.n_emit - (rows2 << s.level);
 					src.row_begin = (uint32_t)rows2;
 					src.halo_row = (uint32_t)rows2 - 2;
 					if (src.n_emit) {
@@ -686,7 +686,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
-			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? !tiles2[lv].empty()         /* level 13: decided before the cut */
+			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? !tiles2[lv].empty()         /* levels 13, 14: decided before the cut */
 						  : getenv("ACM_K2") ? !tiles2[lv].empty() : tiles2[lv].size() >= 8 * grid2);
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];

@@ -44,6 +44,9 @@
 
 #include "acm_device.h"
 
+#ifndef ACM_L14_GROUPS
+#define ACM_L14_GROUPS 3, 3, 3, 3, 2
+#endif
 #ifndef ACM_L13_GROUPS
 #define ACM_L13_GROUPS 2, 3, 3, 3, 2
 #endif
@@ -355,7 +358,7 @@ struct TileCfg {
 	static constexpr int NJ_LAST = NELEM_ / NT_;      // samples per thread in the last pass
 	static constexpr int PS = NJ_LAST >= 64 ? 6 : 5;  // LDS pad: one dword per 2^PS elements (= one last-pass walk)
 	static_assert(NJ_LAST == 64 || NJ_LAST == 32 || NJ_LAST == 128, "walk length of the last pass");
-	static_assert(TR >= 4 && (TR % 2) == 0, "tile must hold the halo and at least two payload rows");
+	static_assert(TR >= 2 && (TR % 2) == 0, "whole row pairs (the halo flavour of acm_fused_tile needs four: two of them are halo)");
 };
 
 /* t - 2*z: one VALU op when 25 result bits suffice (level <= 9: the write-out
@@ -1452,6 +1455,9 @@ const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
 	 * four rows instead of per two, 24 instead of 32 prefetch registers: +8 % over (3,2,3,3,2) (2.94 against 3.18 ms for
 	 * 2.1 Gsamples; at levels 10 and 11 the same trade loses 3 %: an LDS-pass stage costs more than a first-pass stage) */
 	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),
+	/* level 14: one row pair is the 128 KB tile (the first pass's body is two rows: the least a tile can be), 155 KB of LDS
+	 * with the carries of the first LDS pass (two bodies of stride 256 = 4096 elements) */
+	entry_k2w<TileCfg<14, 1024, 32768>, 1, ACM_L14_GROUPS>(),
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {

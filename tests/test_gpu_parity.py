@@ -63,7 +63,7 @@ def test_lean_tile_kernel_batch(dev, force_k2, fmt):
     """many streams in one plan: workgroups start inside streams (lead-in tiles) and cross stream boundaries"""
     files = []
     for i in range(37):
-        lv = 6 + i % 8
+        lv = 6 + i % 9
         rows = [16, 5, 33, 1][i % 4]
         files.append(make_stream(5000 + i, lv, rows, 2 + (i * 5) % 11 + ((16384 >> lv) * (1 + i % 3)) // rows,
                                  channels=1 + i % 2, cut=i % 3, val_max=65535 if i % 5 == 0 else 255, pwr_max=15 if i % 5 == 0 else 12))
@@ -71,14 +71,16 @@ def test_lean_tile_kernel_batch(dev, force_k2, fmt):
 
 
 @pytest.mark.parametrize("rows", [1, 3, 16, 700])
-def test_lean_tile_kernel_level_13(dev, force_k2, rows):
-    """level 13: four rows are one 128 KB tile of the lean kernel (one sixteen-wave workgroup per CU); the ragged tail of
-    the stream goes through the prefix sweep + plane kernel as a window that starts inside the stream"""
-    nblocks = max(2, (5 * 4 + rows - 1) // rows + 1)
-    f = make_stream(4000 + 1300 + rows, 13, rows, nblocks, cut=5, channels=1 + rows % 2)
+@pytest.mark.parametrize("level", [13, 14])
+def test_lean_tile_kernel_levels_13_14(dev, force_k2, level, rows):
+    """levels 13 / 14: four / two rows are one 128 KB tile of the lean kernel (one sixteen-wave workgroup per CU); the ragged
+    tail of the stream goes through the prefix sweep + plane kernel as a window that starts inside the stream"""
+    tr = 4 if level == 13 else 2
+    nblocks = max(2, (5 * tr + rows - 1) // rows + 1)
+    f = make_stream(4000 + level * 100 + rows, level, rows, nblocks, cut=5, channels=1 + rows % 2)
     st = check_streams(dev, [f])
     assert st.fused_streams == 1 and st.stagewise_streams == 0 and st.tiles >= 5
-    g = make_stream(4242 + 13, 13, 4, 6)                # 24 rows = 6 whole tiles: nothing left for the prefix pair
+    g = make_stream(4242 + level, level, 4, 6)          # 24 rows = whole tiles only: nothing left for the prefix pair
     st = check_streams(dev, [g, f])
     assert st.fused_streams == 2
     for fmt in (capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE):
