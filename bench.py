@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 4   # 2 B idx16 read + 2 B PCM16 written
 PRECONDITION_S = 0.5        # untimed launches in front of the warm-up (clock ramp), whatever --warmup says
 SUSTAINED_STEPS = 300       # the long run reported beside the contract's K steps when K is short
-K2_GEOMETRY = {12: (512, 16384)}      # threads, tile dwords of acm_tile2 (acm_kernels.hip: g_tile2); 256 x 8192 below
+K2_GEOMETRY = {12: (512, 16384), 13: (1024, 32768), 14: (1024, 32768)}      # threads, tile dwords of acm_tile2 (acm_kernels.hip: g_tile2); 256 x 8192 below
 
 
 def parse_args():
@@ -587,7 +587,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
                      "kernel": ("acm_tile2<TileCfg<%s,%d,%d>> (+ acm_fused_tile on ragged tails)" % ((lv_txt,) + K2_GEOMETRY.get(args.level, (256, 8192)))
-                                if args.workload == "corpus" or 6 <= args.level <= 12 else "see DESIGN.md section 2 for level %s" % lv_txt),
+                                if args.workload == "corpus" or 6 <= args.level <= 14 else "see DESIGN.md section 2 for level %s" % lv_txt),
                      "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
     if per_rank:
