@@ -950,4 +950,5 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		*timing = tm;
 	cleanup();
 	return ACMHIP_OK;
+#undef BNOTE
 }
