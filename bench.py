@@ -30,6 +30,7 @@ import ctypes as C
 import hashlib
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -203,8 +204,14 @@ def copy_ceiling():
 
 
 def kernel_source_sha():
-    with open(os.path.join(ROOT, "libacm_amd", "csrc", "acm_kernels.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """sha256 of the kernel source with comments and white space stripped (what the compiler sees, line numbers aside): a
+    comment edit does not orphan the committed PMC traffic figures, a code edit does"""
+    with open(os.path.join(ROOT, "libacm_amd", "csrc", "acm_kernels.hip"), "r", encoding="utf-8", errors="replace") as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"\s+", " ", text)
+    return hashlib.sha256(text.encode()).hexdigest()[:16]
 
 
 def cpu_baseline(batch, budget_s):

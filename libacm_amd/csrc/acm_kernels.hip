@@ -18,9 +18,9 @@
  * before it ("halo").  No state is carried between launches.
  *
  * Kernel families:
- *   acm_tile2 (levels 6..12, the whole tiles of streams decoded from row 0: the bulk of a batch): the lean form of the
- *     tile kernel below - 32 KB tiles at four workgroups per CU, one record per tile, vector memory issued and
- *     waited for by hand.  See the comment in front of it.
+ *   acm_tile2 (levels 6..14, the whole tiles of streams decoded from row 0: the bulk of a batch): the lean form of the
+ *     tile kernel below - 32 KB tiles at four workgroups per CU (levels 13 and 14: one 128 KB tile, one sixteen-wave
+ *     workgroup per CU), one record per tile, vector memory issued and waited for by hand.  See the comment in front of it.
  *   fused tile kernel acm_fused_tile (levels 5..12; ragged tails, windows, level 5): persistent workgroups, one tile at a time.  A tile is
  *     TR rows (2 halo + T payload) of one stream held in LDS as int32.  The stages are grouped into passes of
  *     G = 2..4: each thread owns one residue class of the pass's smallest stride and walks it with the inputs
@@ -30,8 +30,9 @@
  *     (+2/T halo, mostly L2 hits) + 2 B written per sample.  Two VALU ops per butterfly (sign folding +
  *     v_mad_i32_i24); measured limit is instruction issue, not HBM.
  *   acm_small_level (levels 0..4): the whole cascade in one thread's registers.
- *   levels 13..15: acm_sw_prefix (unpack + the first level-12 stages, a register cascade per residue mod 4096, into an
- *     int32 plane) + the plane-input build of the level-12 tile kernel (MODE_PLANE).  12 B of HBM traffic per sample.
+ *   level 15, and what acm_tile2 leaves of levels 13..14 (ragged tails, windows, small plans): acm_sw_prefix (unpack + the
+ *     first level-12 stages, a register cascade per residue mod 4096, into an int32 plane) + the plane-input build of
+ *     the level-12 tile kernel (MODE_PLANE).  12 B of HBM traffic per sample.
  *   stage-wise kernels (any level 0..15; tiles that can see an H1 patch; patched streams of levels 13..15): unpack
  *     to an int32 plane, one elementwise launch per stage (ping-pong planes), emit.  8*level B of HBM traffic per
  *     sample; generic fallback and cross-check.

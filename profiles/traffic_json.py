@@ -10,7 +10,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sha = hashlib.sha256(open(os.path.join(ROOT, "libacm_amd", "csrc", "acm_kernels.hip"), "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha       # comments and white space stripped: what the compiler sees
+sha = kernel_source_sha()
 out = {"kernel_source_sha16": sha, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; per dispatch of the dominant kernel; "
        "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B); the counters are in KiB"}
 for arg in sys.argv[1:]:
