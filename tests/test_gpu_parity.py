@@ -591,13 +591,15 @@ def test_batch_device_resident_output(dev):
     dev.free(d_pcm)
 
 
-def test_random_batch_fuzz(dev):
-    """200 random shapes (level 0-12, rows 1-70, 1-5 blocks, mono/stereo, ragged ends, WAVC, all four formats) in one
-    batch: host parse, device parse and the oracle agree stream by stream"""
+@pytest.mark.parametrize("ranges", ["1", "5"])
+def test_random_batch_fuzz(dev, ranges, monkeypatch):
+    """200 random shapes (level 0-14, rows 1-70, 1-5 blocks, mono/stereo, ragged ends, WAVC, all four formats) in one
+    batch: host parse, device parse (one walk, and block ranges) and the oracle agree stream by stream"""
+    monkeypatch.setenv("ACM_BATCH_RANGES", ranges)
     rng = np.random.default_rng(0xACD)
     files = []
     for i in range(200):
-        level = int(rng.integers(0, 13))
+        level = int(rng.integers(0, 15)) if i % 10 == 0 else int(rng.integers(0, 13))
         rows = int(rng.integers(1, 71))
         nb = int(rng.integers(1, 6))
         bl = rows << level
