@@ -65,8 +65,30 @@ extern "C" double acm_copy_ceiling_gbs(size_t bytes, char *best_name, size_t bes
   return best;
 }
 #else
-int main() {
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+int main(int argc, char **argv) {
   const size_t bytes = 4ull << 30, n = bytes / 16;
+  if (argc >= 4 && !strcmp(argv[1], "loop")) {
+    /* copy_bw.bin loop <pattern> <seconds>: one pattern back to back (power / clock readings beside it: profiles/power_probe.sh) */
+    uint4 *a, *b; (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
+    const int pat = atoi(argv[2]); const double secs = atof(argv[3]);
+    const auto t0 = std::chrono::steady_clock::now(); size_t reps = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+      for (int k = 0; k < 20; k++, reps++) {
+        if (pat == 0) hipLaunchKernelGGL((copy_runs<1, 1>), dim3(1024), dim3(256), 0, 0, a, b, n);
+        else if (pat == 1) hipLaunchKernelGGL(copy_unroll4, dim3(4096), dim3(256), 0, 0, a, b, n);
+        else if (pat == 2) hipLaunchKernelGGL(copy_persist, dim3(16384), dim3(256), 0, 0, a, b, n);
+        else if (pat == 3) hipLaunchKernelGGL(read_only, dim3(2048), dim3(256), 0, 0, a, b, n);
+        else hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, a, b, n);
+      }
+      (void)hipDeviceSynchronize();
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("pattern %d: %.1f GB/s over %.1f s\n", pat, reps * (pat >= 3 ? 1.0 : 2.0) * bytes / dt / 1e9, dt);
+    return 0;
+  }
   uint4 *a, *b; (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 2, bytes);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto timeit = [&](const char *name, auto launch, double bytes_moved) {
