@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other levels, D2D copy rate, end to end)")
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
+    ap.add_argument("--no-narrow", action="store_true",
+                    help="int16 staged indices only: do not give the plan the int8 copy of the tiles that fit a byte "
+                         "(acmhip_plan_attach_narrow; with it the line also carries the int16-only time of the same run)")
     ap.add_argument("--workload", choices=["uniform", "corpus"], default="uniform",
                     help="uniform = one shape for every stream (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
@@ -357,7 +360,7 @@ def precondition(dev, plan, bufs, seconds):
     return n
 
 
-def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1):
+def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1, narrow=True):
     """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11); the PCM the
     timed launches leave behind is compared with the CPU oracle on the first `verify` streams (CRC-32 each)"""
     import oracle_api as O
@@ -366,7 +369,10 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
     bufs = b.upload(dev)
     plan = capi.Plan(dev, b.descs)
     precondition(dev, plan, bufs, 0.2)
-    _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None)
+    _, ms_wide = time_plan(dev, plan, bufs, steps, 5, lambda: None)
+    n_narrow = plan.attach_narrow(bufs[0]) if narrow else 0      # the verified PCM below is that of the launches with the int8 plane
+    _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None) if n_narrow else (None, ms_wide)
+    tiles = plan.stats().tiles
     checked = 0
     if b.files:
         d_last = b.descs[len(b.files) - 1]
@@ -389,7 +395,9 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
     rate = b.samples * steps / (ms * 1e-3)
     return {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "steps": steps, "verified_streams": checked,
             "msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
-            "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
+            "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+            "narrow_tiles": int(n_narrow), "tiles": int(tiles),
+            "int16_only_frac_hbm": round(b.samples * ALGO_BYTES_PER_SAMPLE / (ms_wide / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -462,6 +470,13 @@ def main():
         pcm_t = None
         bufs = batch.upload(dev)
     plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
+    # the narrow staged form (part of staging, untimed like the bit parsing): an int8 copy of the lean kernel's tiles, read
+    # instead of the int16 arena by the tiles whose indices fit a byte - the oracle check below runs with it attached
+    narrow = None
+    if not args.no_narrow and not args.stagewise:
+        t0 = time.perf_counter()
+        plan.attach_narrow(bufs[0])
+        narrow = {"pack_seconds": round(time.perf_counter() - t0, 4)}
     stats = plan.stats()
 
     # setup-time check (untimed): every stream of the workload against the CPU oracle, CRC-32 of its PCM
@@ -487,6 +502,18 @@ def main():
                      "launch_ms": round(sev / SUSTAINED_STEPS, 4),
                      "msamples_s_per_gpu": round(batch.samples * SUSTAINED_STEPS / swall / 1e6, 1),
                      "frac": round(batch.samples * ALGO_BYTES_PER_SAMPLE / (sev / SUSTAINED_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the same loop on the int16 arena alone, right behind (the int8 plane detached, then attached again)
+    if narrow is not None:
+        narrow.update(tiles=int(stats.narrow_tiles), tiles_with_rows_in_front=int(stats.narrow_front_tiles))
+        if stats.narrow_tiles:
+            plan.attach_narrow(None)
+            nsteps = max(args.steps, min(SUSTAINED_STEPS, 100))
+            _, wev = time_plan(dev, plan, bufs, nsteps, 5, lambda: None)
+            plan.attach_narrow(bufs[0])
+            wms = wev / nsteps
+            narrow.update(int16_only_launch_ms=round(wms, 4), int16_only_steps=nsteps,
+                          int16_only_frac=round(batch.samples * ALGO_BYTES_PER_SAMPLE / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
     # what the chip's power and clock read while this kernel runs (untimed: 2 s of the same launches)
     power = None
@@ -589,6 +616,9 @@ def main():
                    "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
                    "kernel": "stagewise" if args.stagewise else "acm_tile2 + acm_fused_tile", "tiles": int(stats.tiles),
                    "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2),
+                   "staged_form": "int16 index per sample + {val, pwr} per block" + (
+                       "; int8 copy of %d of the %d tiles (indices that fit a byte), packed on the device while staging" % (
+                           stats.narrow_tiles, stats.tiles) if narrow is not None else ""),
                    "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -603,6 +633,8 @@ def main():
         out["per_rank"] = per_rank
         out["imbalance"] = {"launch_ms_max_over_mean": round(max(ms) / (sum(ms) / len(ms)), 4),
                             "samples_max_over_mean": round(max(sm) / (sum(sm) / len(sm)), 4)}
+    if narrow is not None:
+        out["narrow_tiles"] = narrow
     if sustained:
         out["sustained"] = sustained
     if power:
@@ -645,7 +677,7 @@ def main():
                 if (lv, rw, bl, ns) == (args.level, args.rows, args.blocks, args.streams):
                     continue
                 try:
-                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(20, args.steps // 3)))
+                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(20, args.steps // 3), narrow=not args.no_narrow))
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra

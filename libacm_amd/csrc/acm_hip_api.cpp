@@ -78,6 +78,12 @@ struct acmhip_plan {
 	AcmDevStream *d_streams = nullptr;
 	std::vector<LevelGroup> fused, stagewise, small, prefix;   /* small: levels 0-4, one register-cascade launch; prefix: levels 13-15 */
 	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
+	/* narrow staged form (acmhip_plan_attach_narrow): the int8 plane of the lean kernel's tiles, the staged arena it was
+	 * packed from (launches on any other arena read int16 only) and the extent of that arena the tiles cover */
+	uint8_t *d_idx8 = nullptr;
+	const int16_t *narrow_src = nullptr;
+	uint64_t narrow_extent = 0;            /* int16 units */
+	uint32_t *d_narrow_count = nullptr;
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
 	uint64_t sw_max_elems = 0;
@@ -387,6 +393,8 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		if (e)
 			(void)hipEventDestroy(e);
 	(void)hipFree(plan->d_sink);
+	(void)hipFree(plan->d_idx8);
+	(void)hipFree(plan->d_narrow_count);
 	(void)hipFree(plan->d_sw_all);
 	(void)hipFree(plan->d_patches);
 	(void)hipFree(plan->d_plane[0]);
@@ -699,6 +707,8 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			}
 			if (k2 && rc == ACMHIP_OK) {
 				g.ntiles2 = (uint32_t)tiles2[lv].size();
+				for (const AcmTile2 &t2 : tiles2[lv])
+					pl->narrow_extent = std::max<uint64_t>(pl->narrow_extent, t2.idx_off + ((uint64_t)acmk_tile2_rows(lv) << lv));
 				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
 				st.tiles += g.ntiles2;
 				st.launches += 1;
@@ -818,7 +828,8 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->fused) {
 		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
 		gi++;
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_idx == pl->narrow_src ? pl->d_idx8 : nullptr,
+					    d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}
@@ -862,6 +873,36 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
 		}
 	}
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, uint64_t *narrow_tiles)
+{
+	if (!pl)
+		return ACMHIP_ERR_ARG;
+	HIPTRY(hipSetDevice(pl->dev->ordinal));
+	pl->narrow_src = nullptr;
+	pl->stats.narrow_tiles = pl->stats.narrow_front_tiles = 0;
+	if (narrow_tiles)
+		*narrow_tiles = 0;
+	if (!d_idx || pl->narrow_extent == 0)
+		return ACMHIP_OK;                       /* detached / nothing the lean kernel takes */
+	if (!pl->d_idx8) {
+		HIPTRY(hipMalloc((void **)&pl->d_idx8, pl->narrow_extent * 2));
+		HIPTRY(hipMalloc((void **)&pl->d_narrow_count, 2 * sizeof(uint32_t)));
+	}
+	hipStream_t st = pl->dev->stream;
+	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, 2 * sizeof(uint32_t), st));
+	for (const LevelGroup &g : pl->fused)
+		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count, (void *)st));
+	uint32_t count[2] = { 0, 0 };
+	HIPTRY(hipMemcpyAsync(count, pl->d_narrow_count, sizeof count, hipMemcpyDeviceToHost, st));
+	HIPTRY(hipStreamSynchronize(st));
+	pl->narrow_src = d_idx;
+	pl->stats.narrow_tiles = count[0] + count[1];
+	pl->stats.narrow_front_tiles = count[0];
+	if (narrow_tiles)
+		*narrow_tiles = count[0] + count[1];
 	return ACMHIP_OK;
 }
 

@@ -419,6 +419,18 @@ __device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t
 #undef ACM_SDWA_MUL
 }
 
+/* narrow tiles: one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1), (row + 1, col),
+ * (row + 1, col + 1) - and SDWA picks and sign-extends the byte inside the multiply, as it does with the 16-bit words */
+__device__ __forceinline__ void mul_idx8_val(const uint32_t r, const int32_t val0, const int32_t val1, uint32_t &r0c0, uint32_t &r0c1,
+					     uint32_t &r1c0, uint32_t &r1c1)
+{
+#define ACM_SDWA_MUL8(D, VAL, BYTE) "v_mul_i32_i24_sdwa " D ", sext(%4), " VAL " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" BYTE " src1_sel:DWORD\n\t"
+	asm(ACM_SDWA_MUL8("%0", "%5", "BYTE_0") ACM_SDWA_MUL8("%1", "%5", "BYTE_1") ACM_SDWA_MUL8("%2", "%6", "BYTE_2") ACM_SDWA_MUL8("%3", "%6", "BYTE_3")
+	    : "=&v"(r0c0), "=&v"(r0c1), "=&v"(r1c0), "=&v"(r1c1)
+	    : "v"(r), "v"(val0), "v"(val1));
+#undef ACM_SDWA_MUL8
+}
+
 /* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
 __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
@@ -689,7 +701,7 @@ struct FirstPass {
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
 	template <bool CARRY = false>
 	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NREG], uint32_t *tile, const int32_t *rowval,
-						       const int row_first, const int tid)
+						       const int row_first, const int tid, const bool narrow_warm = false, const bool narrow_body = false)
 	{
 		constexpr int LR_MIN = CARRY ? -2 : 0;          /* carry mode: the two rows above the tile carry weight */
 		const int seg = tid / TPS;
@@ -718,6 +730,11 @@ struct FirstPass {
 #pragma unroll
 					for (int u = 0; u < BODY; u++)
 						v[w][u] = raw[w * NRAW + (b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
+			} else if (W == 2 && !PLANE && (b < 0 ? narrow_warm : narrow_body)) {
+				/* narrow tile (wave-uniform): register (body, q) = int8 indices of this lane's two columns in both rows of the body */
+#pragma unroll
+				for (int q = 0; q < U; q++)
+					mul_idx8_val(raw[(b + (WARM ? 1 : 0)) * BODY + q], v0, v1, v[0][q], v[W - 1][q], v[0][U + q], v[W - 1][U + q]);
 			} else if constexpr (W == 2 && U % 4 == 0) {
 #pragma unroll
 				for (int u = 0; u < BODY; u += 4) {
@@ -1224,9 +1241,11 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	 * whose two rows in front do not exist (they are read from rows 0..1 instead and weigh 0).
 	 * The loads are issued by hand (see k2_wait): one SGPR base, one VGPR offset, compile-time immediates. */
 	template <int K>
-	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
+							const uint32_t voff_warm)
 	{
 		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
+		const uint8_t *const base = b < 0 ? base_warm : base_body;
 		constexpr int off = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
 		constexpr int imm = off % 4096, far = off - imm;        /* 12 bits in the instruction, the rest on the scalar base */
 		if (ABL & 1)                            /* timing-only build: no HBM loads */
@@ -1234,17 +1253,70 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 		else
 			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
-	template <int... Ks>
-	static __device__ __forceinline__ void load_seq(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
-							std::integer_sequence<int, Ks...>)
+	/* Narrow tiles (ACM_TILE_NARROW): the indices of the tile and of the two rows in front of it fit a byte and sit in the
+	 * int8 plane in 2 x 2 blocks - the dword at the byte offset the int16 plane has for (row 2p, columns 2j, 2j + 1) holds
+	 * rows 2p, 2p + 1 x columns 2j, 2j + 1 - so the load of a body's FIRST row, from the other base, brings both rows, and
+	 * the loads of its second row are skipped: half the loads, half the bytes, the same instructions.
+	 * The skip is a scalar branch INSIDE the asm statement that holds a body's second-row loads: every register has one
+	 * definition on every path, so the compiler has nothing to merge where the paths meet (a merge is a copy, and a copy
+	 * of a register whose load is in flight copies the old content: tests/test_isa_invariants.py). */
+	template <int B, int Q>
+	static constexpr int off2() { return (((2 * B + 1) * COLS) + Q * SIGMA) * 2; }       /* body B (0 = the warm-up), second row, column group Q */
+	template <int B>
+	static __device__ __forceinline__ void load_second_row(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, const uint32_t narrow)
 	{
-		(load_one<Ks>(raw, base, voff, voff_warm), ...);
+		static_assert(U == 4 || U == 8, "a first pass of two or three stages");
+		constexpr int K = B * BODY + U;
+#define ACM_LD2(N) "global_load_dword %" #N ", %[vo], %[b" #N "] offset:%[i" #N "]\n\t"
+#define ACM_IN2(N) [b##N] "s"(base + (off2<B, N>() - off2<B, N>() % 4096)), [i##N] "n"(off2<B, N>() % 4096)
+		if constexpr (ABL & 1) {
+#pragma unroll
+			for (int q = 0; q < U; q++)
+				raw[K + q] = vo + q;
+		} else if constexpr (U == 4) {
+			asm volatile("s_cmp_lg_u32 %[nar], 0\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ".Lacm_narrow%=:"
+				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3])
+				     : [vo] "v"(vo), [nar] "s"(narrow), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3)
+				     : "memory", "scc");
+		} else {
+			asm volatile("s_cmp_lg_u32 %[nar], 0\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ACM_LD2(4)
+				     ACM_LD2(5) ACM_LD2(6) ACM_LD2(7) ".Lacm_narrow%=:"
+				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3]), "=&v"(raw[K + 4]), "=&v"(raw[K + 5]),
+				       "=&v"(raw[K + 6]), "=&v"(raw[K + 7])
+				     : [vo] "v"(vo), [nar] "s"(narrow), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3), ACM_IN2(4), ACM_IN2(5), ACM_IN2(6), ACM_IN2(7)
+				     : "memory", "scc");
+		}
+#undef ACM_LD2
+#undef ACM_IN2
 	}
-	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	template <int... Ks>
+	static __device__ __forceinline__ void load_first_rows(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
+							       const uint32_t voff_warm, std::integer_sequence<int, Ks...>)
+	{
+		(load_one<(Ks / U) * BODY + Ks % U>(raw, base_warm, base_body, voff, voff_warm), ...);
+	}
+	template <int... Bs>
+	static __device__ __forceinline__ void load_second_rows(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body,
+								const uint32_t voff, const uint32_t voff_warm, const uint32_t narrow_warm,
+								const uint32_t narrow_body, std::integer_sequence<int, Bs...>)
+	{
+		(load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, Bs == 0 ? narrow_warm : narrow_body), ...);
+	}
+	/* the warm-up body (the two rows in front of every segment) and the tile's own bodies choose their plane separately: a
+	 * tile whose own rows fit a byte may follow rows that do not (ACM_TILE_NARROW without ACM_TILE_NARROW_FRONT) */
+	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
+						    const uint32_t voff_warm, const uint32_t narrow_warm, const uint32_t narrow_body)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
-		load_seq(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
+		load_first_rows(raw, base_warm, base_body, voff, voff_warm, std::make_integer_sequence<int, NRAW / 2>{});
+		load_second_rows(raw, base_warm, base_body, voff, voff_warm, narrow_warm, narrow_body, std::make_integer_sequence<int, NB + 1>{});
 	}
+};
+
+/* can a narrow tile follow rows that are not narrow?  (see acm_tile2: is_narrow_front) */
+template <class C, int G0>
+struct Tile2Split {
+	static constexpr bool value = FirstPass2<C, G0, 2>::FP::TPS >= 64;
 };
 
 /*
@@ -1268,7 +1340,7 @@ __device__ __forceinline__ void k2_wait()
 
 template <class C, int WPS, int ABL, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
-acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx,
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const uint8_t *__restrict__ idx8,
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
@@ -1330,6 +1402,30 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
+	/* narrow tiles (ACM_TILE_NARROW, set by acm_pack_narrow when the plan was given an int8 plane): the same tile of the
+	 * int8 plane, which has the int16 plane's pitch (FirstPass2::load) */
+	auto is_narrow = [&](const AcmTile2 &r) -> bool { return idx8 != nullptr && (r.flags & ACM_TILE_NARROW) != 0; };
+	/* the warm-up rows are the tile's own, except for segment 0, whose two rows in front belong to the tile before: a narrow
+	 * tile behind rows that do not fit reads those from the int16 arena.  Only where a segment is whole waves (the choice
+	 * must be wave-uniform); at the lower levels such a tile stays wide altogether (acm_pack_narrow marks it so).  (Reading
+	 * EVERY segment's warm-up rows from the int16 arena there was measured: slower than a wide tile, they come from HBM
+	 * a second time instead of from L2) */
+	const bool seg0_wave = Tile2Split<C, G0>::value && (uint32_t)__builtin_amdgcn_readfirstlane(tid) < (uint32_t)FP::TPS;
+	auto is_narrow_front = [&](const AcmTile2 &r) -> bool {
+		return is_narrow(r) && (!seg0_wave || (r.flags & ACM_TILE_NARROW_FRONT) != 0);
+	};
+	auto idx8_base = [&](const AcmTile2 &r) -> const uint8_t * {
+		const uint64_t a = reinterpret_cast<uint64_t>(idx8) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
+	};
+	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r) {
+		const bool body = is_narrow(r), front = is_narrow_front(r);
+		const uint8_t *const wide = idx_base(r), *const narrow = idx8_base(r);
+		FP::load(raw, front ? narrow : wide, body ? narrow : wide, voff, warm_off(r), __builtin_amdgcn_readfirstlane(front ? 1u : 0u),
+			 __builtin_amdgcn_readfirstlane(body ? 1u : 0u));
+	};
+
 
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;      /* 16-byte PCM stores per thread and tile */
 	static_assert(NVEC % NT == 0, "whole rounds");
@@ -1338,7 +1434,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
 	uint32_t raw[FP::NRAW];
 	uint32_t hv = fetch_val(cur);
-	FP::load(raw, idx_base(cur), voff, warm_off(cur));
+	load_tile(raw, cur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1362,7 +1458,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, is_narrow_front(cur), is_narrow(cur));
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -1370,7 +1466,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(2);
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
-		FP::load(raw, idx_base(nxt), voff, warm_off(nxt));
+		load_tile(raw, nxt);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
@@ -1418,18 +1514,24 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 }
 
 struct Tile2Entry {
-	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
 	int threads, tile_rows, wg_per_cu;
+	bool split;             /* Tile2Split of the geometry */
 };
+template <int G0, int...>
+constexpr int first_group() { return G0; }
 template <class C, int... Gs>
-constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT }; }
+constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT, Tile2Split<C, first_group<Gs...>()>::value }; }
 /* bigger tiles: WPC workgroups per CU */
 template <class C, int WPC, int... Gs>
-constexpr Tile2Entry entry_k2w() { return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC }; }
+constexpr Tile2Entry entry_k2w()
+{
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC, Tile2Split<C, first_group<Gs...>()>::value };
+}
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4 }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4, false }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
@@ -1634,7 +1736,7 @@ extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 	return (cus > 0 ? cus : 256) * tile2_entry(level).wg_per_cu;
 }
 
-extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx,
+extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const uint8_t *d_idx8,
 				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
@@ -1653,7 +1755,74 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_idx8, d_hdr, d_pcm, d_sink, fmt);
+	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
+/*
+ * The narrow staged form of a tile table: every tile's indices as int8 in the plane the lean kernel reads narrow tiles from (the
+ * 2 x 2 block of rows 2p, 2p + 1 x columns 2j, 2j + 1 at the byte offset of (row 2p, column 2j) in the int16 plane: same pitch,
+ * every other row's worth of bytes unused), ACM_TILE_NARROW in the record of every tile whose own rows fit a byte, and
+ * ACM_TILE_NARROW_FRONT where the two rows in front of it (which segment 0 re-reads as its warm-up) do too; a geometry that
+ * cannot mix the two (`split` == 0: Tile2Split) gets ACM_TILE_NARROW only together with ACM_TILE_NARROW_FRONT.  One workgroup
+ * per tile; a thread turns 2 rows x 8 columns (two 16-byte reads) into 16 bytes.  count[0] += tiles narrow in both respects,
+ * count[1] += tiles with narrow rows of their own behind rows that are not.
+ */
+namespace {
+__global__ void __launch_bounds__(256)
+acm_pack_narrow(AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint32_t level, const uint32_t tile_rows,
+		const int16_t *__restrict__ idx, uint8_t *__restrict__ idx8, uint32_t *__restrict__ count, const int split)
+{
+	const uint32_t t = blockIdx.x;
+	if (t >= ntiles)
+		return;
+	const AcmTile2 r = tiles[t];
+	const uint32_t cols = 1u << level, per_row = cols / 8, units = (tile_rows / 2) * per_row;
+	const uint4 *src = reinterpret_cast<const uint4 *>(idx + r.idx_off);          /* stream offsets are multiples of 8 indices */
+	uint4 *dst = reinterpret_cast<uint4 *>(idx8 + 2 * r.idx_off);      /* row pair p at the offset of row 2p: the pitch of the int16 plane */
+	uint32_t wide = 0, wide_front = 0;
+	auto look = [&](uint32_t &acc, const uint32_t w) {
+		acc |= (uint32_t)((int32_t)(int16_t)w + 128) | (uint32_t)(((int32_t)w >> 16) + 128);    /* 0..255 <=> fits */
+	};
+	auto pack = [&](const uint32_t w0, const uint32_t w1) -> uint32_t {
+		look(wide, w0);
+		look(wide, w1);
+		return (w0 & 0xFFu) | ((w0 >> 8) & 0xFF00u) | ((w1 & 0xFFu) << 16) | ((w1 << 8) & 0xFF000000u);
+	};
+	for (uint32_t u = threadIdx.x; u < units; u += 256) {
+		const uint32_t p = u / per_row, j = u % per_row;
+		const uint4 a = src[(2 * p) * per_row + j], b = src[(2 * p + 1) * per_row + j];
+		dst[(2 * p) * per_row + j] = make_uint4(pack(a.x, b.x), pack(a.y, b.y), pack(a.z, b.z), pack(a.w, b.w));
+	}
+	if (!(r.flags & ACM_TILE_FRESH))
+		for (uint32_t u = threadIdx.x; u < 2 * per_row; u += 256) {
+			const uint4 a = *(src - 2 * per_row + u);                   /* the two rows in front: the previous tile packs them */
+			look(wide_front, a.x);
+			look(wide_front, a.y);
+			look(wide_front, a.z);
+			look(wide_front, a.w);
+		}
+	const int any_wide_front = __syncthreads_or((wide_front & ~0xFFu) != 0);
+	const int any_wide = __syncthreads_or((wide & ~0xFFu) != 0) || (!split && any_wide_front);
+	if (threadIdx.x == 0) {
+		tiles[t].flags = (r.flags & ~(ACM_TILE_NARROW | ACM_TILE_NARROW_FRONT)) | (any_wide ? 0u : ACM_TILE_NARROW) |
+				 (any_wide_front ? 0u : ACM_TILE_NARROW_FRONT);
+		if (!any_wide)
+			atomicAdd(&count[any_wide_front ? 1 : 0], 1u);
+	}
+}
+}
+
+extern "C" int acmk_launch_pack_narrow(uint32_t level, AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, uint8_t *d_idx8,
+				       uint32_t *d_count, void *stream)
+{
+	if (ntiles == 0)
+		return 0;
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return -1;
+	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, ntiles, level,
+			   (uint32_t)tile2_entry(level).tile_rows, d_idx, d_idx8, d_count, tile2_entry(level).split ? 1 : 0);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

@@ -57,7 +57,7 @@ def basic_blocks(lines):
     blocks, cur, label = [], [], None
     for ln, line in enumerate(lines):
         t = line.split(";")[0].strip()
-        m = re.fullmatch(r"(\.LBB\d+_\d+):", t)
+        m = re.fullmatch(r"(\.L\w+):", t)         # the compiler's blocks and the skip labels inside the second-row load asm
         if m:
             blocks.append([label, cur, None])
             cur, label = [], m.group(1)
