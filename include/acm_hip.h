@@ -136,7 +136,9 @@ int  acmhip_plan_launch(acmhip_plan *plan, const int16_t *d_idx, const acmhip_bl
  * tiles whose indices all fit, and separately whether the two rows in front of the tile (which it re-reads) do.  From
  * then on acmhip_plan_launch WITH THE SAME d_idx reads the marked rows from the int8 plane: half the index bytes and
  * half the load instructions on those tiles, identical PCM.  Call it again after the staged indices change; d_idx = NULL
- * detaches.  Blocks until the pack kernels are done; *narrow_tiles (may be NULL) receives the number of marked tiles
+ * detaches.  Blocks until the pack kernels are done.  The build of the tile kernel that can read both planes costs
+ * the 16-bit tiles up to 3 % at some levels, so per level the plan uses it only when enough tiles are narrow to pay;
+ * *narrow_tiles (may be NULL) receives the number of tiles that WILL be read from the int8 plane
  * (acmhip_plan_stats.tiles counts all).  A plan none of whose streams reaches the lean kernel is left as it is.
  */
 int  acmhip_plan_attach_narrow(acmhip_plan *plan, const int16_t *d_idx, uint64_t *narrow_tiles);

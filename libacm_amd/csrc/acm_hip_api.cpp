@@ -62,6 +62,8 @@ struct LevelGroup {
 	uint32_t ntiles = 0;
 	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
 	AcmTile2 *d_tiles2 = nullptr;   /* whole tiles of streams decoded from row 0: the lean kernel (acm_tile2) */
+	AcmTile2Plane *d_planes2 = nullptr;     /* beside them once an int8 plane is attached (acmhip_plan_attach_narrow) */
+	bool use_narrow = false;        /* ... and enough of the tiles are narrow for the narrow build of the kernel to pay */
 	uint32_t ntiles2 = 0;
 	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
 	uint32_t ntiles_extra = 0;
@@ -377,6 +379,7 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	for (auto &g : plan->fused) {
 		(void)hipFree(g.d_tiles);
 		(void)hipFree(g.d_tiles2);
+		(void)hipFree(g.d_planes2);
 		(void)hipFree(g.d_tiles_extra);
 	}
 	for (auto &g : plan->stagewise)
@@ -828,7 +831,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->fused) {
 		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
 		gi++;
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_idx == pl->narrow_src ? pl->d_idx8 : nullptr,
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, g.use_narrow && d_idx == pl->narrow_src ? g.d_planes2 : nullptr,
 					    d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
@@ -883,26 +886,50 @@ extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, 
 	HIPTRY(hipSetDevice(pl->dev->ordinal));
 	pl->narrow_src = nullptr;
 	pl->stats.narrow_tiles = pl->stats.narrow_front_tiles = 0;
+	for (LevelGroup &g : pl->fused)
+		g.use_narrow = false;
 	if (narrow_tiles)
 		*narrow_tiles = 0;
 	if (!d_idx || pl->narrow_extent == 0)
 		return ACMHIP_OK;                       /* detached / nothing the lean kernel takes */
+	const size_t ngroups = pl->fused.size();
 	if (!pl->d_idx8) {
 		HIPTRY(hipMalloc((void **)&pl->d_idx8, pl->narrow_extent * 2));
-		HIPTRY(hipMalloc((void **)&pl->d_narrow_count, 2 * sizeof(uint32_t)));
+		HIPTRY(hipMalloc((void **)&pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t)));
 	}
 	hipStream_t st = pl->dev->stream;
-	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, 2 * sizeof(uint32_t), st));
-	for (const LevelGroup &g : pl->fused)
-		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count, (void *)st));
-	uint32_t count[2] = { 0, 0 };
-	HIPTRY(hipMemcpyAsync(count, pl->d_narrow_count, sizeof count, hipMemcpyDeviceToHost, st));
+	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, ngroups * 2 * sizeof(uint32_t), st));
+	for (size_t k = 0; k < ngroups; k++) {
+		LevelGroup &g = pl->fused[k];
+		if (g.ntiles2 && !g.d_planes2)
+			HIPTRY(hipMalloc((void **)&g.d_planes2, (size_t)g.ntiles2 * sizeof(AcmTile2Plane)));
+		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.d_planes2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count + 2 * k, (void *)st));
+	}
+	std::vector<uint32_t> count(ngroups * 2, 0);
+	HIPTRY(hipMemcpyAsync(count.data(), pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	HIPTRY(hipStreamSynchronize(st));
+	/* Does the narrow build of the kernel pay for this group?  Where it is as fast as the int16-only build on wide tiles
+	 * (three copies of the first pass: levels 6-9 and 13) as soon as a few tiles are narrow; where it is ~3 % slower on
+	 * them (levels 10-12 and 14, a narrow tile there is ~8 % faster) from a third of the tiles on.  ACM_NARROW=1 / 0
+	 * forces it on for every group with a narrow tile / off (measurements) */
+	const char *force = getenv("ACM_NARROW");
+	for (size_t k = 0; k < ngroups; k++) {
+		LevelGroup &g = pl->fused[k];
+		const uint64_t both = count[2 * k], narrow = both + count[2 * k + 1];
+		if (force)
+			g.use_narrow = atoi(force) != 0 && narrow > 0;
+		else if (acmk_tile2_narrow_form(g.level) == 1)
+			g.use_narrow = narrow * 50 >= g.ntiles2 && narrow > 0;
+		else
+			g.use_narrow = (both + narrow) * 3 >= 2ull * g.ntiles2 && narrow > 0;     /* a tile narrow only in its own rows counts half */
+		if (g.use_narrow) {
+			pl->stats.narrow_tiles += (uint32_t)narrow;
+			pl->stats.narrow_front_tiles += (uint32_t)both;
+		}
+	}
 	pl->narrow_src = d_idx;
-	pl->stats.narrow_tiles = count[0] + count[1];
-	pl->stats.narrow_front_tiles = count[0];
 	if (narrow_tiles)
-		*narrow_tiles = count[0] + count[1];
+		*narrow_tiles = pl->stats.narrow_tiles;
 	return ACMHIP_OK;
 }
 

@@ -699,7 +699,12 @@ struct FirstPass {
 	}
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
-	template <bool CARRY = false>
+	/* NARROW (acm_tile2's narrow tiles): 0 = 16-bit indices, 1 = the row pairs are 2 x 2 byte blocks, 2 = the warm-up body
+	 * is 16-bit, the tile's own bodies are byte blocks, 3 = whatever narrow_warm / narrow_body say at run time.
+	 * acm_tile2 picks one of three compile-time instantiations per tile where that fits the register file: with the unpack
+	 * behind a run-time branch per body the first pass of a WIDE tile is 3 % slower (the scheduler no longer interleaves
+	 * unpack and butterflies) */
+	template <bool CARRY = false, int NARROW = 0>
 	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NREG], uint32_t *tile, const int32_t *rowval,
 						       const int row_first, const int tid, const bool narrow_warm = false, const bool narrow_body = false)
 	{
@@ -730,7 +735,7 @@ struct FirstPass {
 #pragma unroll
 					for (int u = 0; u < BODY; u++)
 						v[w][u] = raw[w * NRAW + (b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
-			} else if (W == 2 && !PLANE && (b < 0 ? narrow_warm : narrow_body)) {
+			} else if (W == 2 && !PLANE && (NARROW == 3 ? (b < 0 ? narrow_warm : narrow_body) : (b < 0 ? NARROW == 1 : NARROW >= 1))) {
 				/* narrow tile (wave-uniform): register (body, q) = int8 indices of this lane's two columns in both rows of the body */
 #pragma unroll
 				for (int q = 0; q < U; q++)
@@ -1225,7 +1230,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
  * waves per SIMD), so the tile loop is written for instruction count: 32 KB tiles at four workgroups per CU, all
  * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
  */
-template <class C, int G, int W, int ABL = 0>
+template <class C, int G, int W, int ABL = 0, int NAR = 0>
 struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segment, the first one included, re-runs the two rows in front of it */
 	using FP = FirstPass<C, G, W, ABL, true>;
 	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
@@ -1262,11 +1267,22 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	 * of a register whose load is in flight copies the old content: tests/test_isa_invariants.py). */
 	template <int B, int Q>
 	static constexpr int off2() { return (((2 * B + 1) * COLS) + Q * SIGMA) * 2; }       /* body B (0 = the warm-up), second row, column group Q */
+	template <int B, int... Qs>
+	static __device__ __forceinline__ void load_second_row_plain(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, std::integer_sequence<int, Qs...>)
+	{
+		(load_one<B * BODY + U + Qs>(raw, base, base, vo, vo), ...);
+	}
+	/* flags: the tile record's; bit: ACM_TILE_NARROW's or ACM_TILE_NARROW_FRONT's number - set = the row pair was one load */
 	template <int B>
-	static __device__ __forceinline__ void load_second_row(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, const uint32_t narrow)
+	static __device__ __forceinline__ void load_second_row(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, const uint32_t flags,
+							       const uint32_t bit)
 	{
 		static_assert(U == 4 || U == 8, "a first pass of two or three stages");
 		constexpr int K = B * BODY + U;
+		if constexpr (!NAR) {            /* the build for plans without an int8 plane: no branch */
+			load_second_row_plain<B>(raw, base, vo, std::make_integer_sequence<int, U>{});
+			return;
+		}
 #define ACM_LD2(N) "global_load_dword %" #N ", %[vo], %[b" #N "] offset:%[i" #N "]\n\t"
 #define ACM_IN2(N) [b##N] "s"(base + (off2<B, N>() - off2<B, N>() % 4096)), [i##N] "n"(off2<B, N>() % 4096)
 		if constexpr (ABL & 1) {
@@ -1274,49 +1290,45 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 			for (int q = 0; q < U; q++)
 				raw[K + q] = vo + q;
 		} else if constexpr (U == 4) {
-			asm volatile("s_cmp_lg_u32 %[nar], 0\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ".Lacm_narrow%=:"
+			asm volatile("s_bitcmp1_b32 %[fl], %[bit]\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ".Lacm_narrow%=:"
 				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3])
-				     : [vo] "v"(vo), [nar] "s"(narrow), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3)
+				     : [vo] "v"(vo), [fl] "s"(flags), [bit] "s"(bit), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3)
 				     : "memory", "scc");
 		} else {
-			asm volatile("s_cmp_lg_u32 %[nar], 0\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ACM_LD2(4)
+			asm volatile("s_bitcmp1_b32 %[fl], %[bit]\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ACM_LD2(4)
 				     ACM_LD2(5) ACM_LD2(6) ACM_LD2(7) ".Lacm_narrow%=:"
 				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3]), "=&v"(raw[K + 4]), "=&v"(raw[K + 5]),
 				       "=&v"(raw[K + 6]), "=&v"(raw[K + 7])
-				     : [vo] "v"(vo), [nar] "s"(narrow), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3), ACM_IN2(4), ACM_IN2(5), ACM_IN2(6), ACM_IN2(7)
+				     : [vo] "v"(vo), [fl] "s"(flags), [bit] "s"(bit), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3), ACM_IN2(4), ACM_IN2(5),
+				       ACM_IN2(6), ACM_IN2(7)
 				     : "memory", "scc");
 		}
 #undef ACM_LD2
 #undef ACM_IN2
 	}
-	template <int... Ks>
-	static __device__ __forceinline__ void load_first_rows(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-							       const uint32_t voff_warm, std::integer_sequence<int, Ks...>)
+	template <int B, int... Qs>
+	static __device__ __forceinline__ void load_first_row(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
+							      const uint32_t voff_warm, std::integer_sequence<int, Qs...>)
 	{
-		(load_one<(Ks / U) * BODY + Ks % U>(raw, base_warm, base_body, voff, voff_warm), ...);
+		(load_one<B * BODY + Qs>(raw, base_warm, base_body, voff, voff_warm), ...);
 	}
 	template <int... Bs>
-	static __device__ __forceinline__ void load_second_rows(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body,
-								const uint32_t voff, const uint32_t voff_warm, const uint32_t narrow_warm,
-								const uint32_t narrow_body, std::integer_sequence<int, Bs...>)
+	static __device__ __forceinline__ void load_bodies(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
+							   const uint32_t voff_warm, const uint32_t flags, const uint32_t warm_bit,
+							   std::integer_sequence<int, Bs...>)
 	{
-		(load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, Bs == 0 ? narrow_warm : narrow_body), ...);
+		((load_first_row<Bs>(raw, base_warm, base_body, voff, voff_warm, std::make_integer_sequence<int, U>{}),
+		  load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, flags, Bs == 0 ? warm_bit : ACM_TILE_NARROW_BIT)), ...);
 	}
 	/* the warm-up body (the two rows in front of every segment) and the tile's own bodies choose their plane separately: a
-	 * tile whose own rows fit a byte may follow rows that do not (ACM_TILE_NARROW without ACM_TILE_NARROW_FRONT) */
+	 * tile whose own rows fit a byte may follow rows that do not (ACM_TILE_NARROW without ACM_TILE_NARROW_FRONT).
+	 * Rows are asked for in address order */
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-						    const uint32_t voff_warm, const uint32_t narrow_warm, const uint32_t narrow_body)
+						    const uint32_t voff_warm, const uint32_t flags, const uint32_t warm_bit)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
-		load_first_rows(raw, base_warm, base_body, voff, voff_warm, std::make_integer_sequence<int, NRAW / 2>{});
-		load_second_rows(raw, base_warm, base_body, voff, voff_warm, narrow_warm, narrow_body, std::make_integer_sequence<int, NB + 1>{});
+		load_bodies(raw, base_warm, base_body, voff, voff_warm, flags, warm_bit, std::make_integer_sequence<int, NB + 1>{});
 	}
-};
-
-/* can a narrow tile follow rows that are not narrow?  (see acm_tile2: is_narrow_front) */
-template <class C, int G0>
-struct Tile2Split {
-	static constexpr bool value = FirstPass2<C, G0, 2>::FP::TPS >= 64;
 };
 
 /*
@@ -1338,14 +1350,16 @@ __device__ __forceinline__ void k2_wait()
 	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
 }
 
-template <class C, int WPS, int ABL, int G0, int... Gs>
+/* NAR: 0 = int16 arena only; 1, 2 = the build for plans with an int8 plane (narrow tiles), with three copies of the first pass /
+ * with one copy that branches per body (FirstPass::compute) */
+template <class C, int WPS, int ABL, int NAR, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
-acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const uint8_t *__restrict__ idx8,
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const AcmTile2Plane *__restrict__ planes,
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
-	using FP = FirstPass2<C, G0, 2, ABL>;
+	using FP = FirstPass2<C, G0, 2, ABL, NAR>;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
 
@@ -1393,39 +1407,43 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		v <<= OutScale<L>::SHIFT;
 		return (NEG_ODD_ROWS && (tid & 1)) ? -(int32_t)v : (int32_t)v;
 	};
-	auto idx_base = [&](const AcmTile2 &r) -> const uint8_t * {
-		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
-		const uint64_t a = reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
-		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
-	};
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
-	/* narrow tiles (ACM_TILE_NARROW, set by acm_pack_narrow when the plan was given an int8 plane): the same tile of the
-	 * int8 plane, which has the int16 plane's pitch (FirstPass2::load) */
-	auto is_narrow = [&](const AcmTile2 &r) -> bool { return idx8 != nullptr && (r.flags & ACM_TILE_NARROW) != 0; };
-	/* the warm-up rows are the tile's own, except for segment 0, whose two rows in front belong to the tile before: a narrow
-	 * tile behind rows that do not fit reads those from the int16 arena.  Only where a segment is whole waves (the choice
-	 * must be wave-uniform); at the lower levels such a tile stays wide altogether (acm_pack_narrow marks it so).  (Reading
-	 * EVERY segment's warm-up rows from the int16 arena there was measured: slower than a wide tile, they come from HBM
-	 * a second time instead of from L2) */
-	const bool seg0_wave = Tile2Split<C, G0>::value && (uint32_t)__builtin_amdgcn_readfirstlane(tid) < (uint32_t)FP::TPS;
-	auto is_narrow_front = [&](const AcmTile2 &r) -> bool {
-		return is_narrow(r) && (!seg0_wave || (r.flags & ACM_TILE_NARROW_FRONT) != 0);
-	};
-	auto idx8_base = [&](const AcmTile2 &r) -> const uint8_t * {
-		const uint64_t a = reinterpret_cast<uint64_t>(idx8) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
+	/* Narrow tiles (the NAR build, launched when the plan has an int8 plane: acm_pack_narrow set ACM_TILE_NARROW in the records
+	 * of the tiles whose own rows fit a byte, ACM_TILE_NARROW_FRONT where the two rows in front fit as well, and wrote next
+	 * to every record where the tile's rows are to be read from: AcmTile2Plane, byte offsets from the int16 arena to
+	 * (tile row -2, column 0) in the plane to use - the int8 plane has the int16 arena's pitch, FirstPass2::load).
+	 * The warm-up rows are the tile's own, except for segment 0, whose two rows in front belong to the tile before: a narrow
+	 * tile behind rows that do not fit reads those from the int16 arena.  The choice must be wave-uniform: the wave(s) that
+	 * hold segment 0 read their warm-up rows wide - where a segment is less than a wave (levels 6..9) that is the first few
+	 * segments, whose own rows then come from HBM a second time, in 16 bits.  (Reading EVERY segment's warm-up rows wide
+	 * was measured: slower than a wide tile.)  All of it is scalar work, and little: every instruction here is an issue slot
+	 * of a kernel that has none to spare (a dozen more per tile cost the wide tiles 3 %) */
+	const bool seg0_wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid) < (uint32_t)(FP::TPS > 64 ? FP::TPS : 64);
+	const uint32_t warm_bit = seg0_wave ? ACM_TILE_NARROW_FRONT_BIT : ACM_TILE_NARROW_BIT;
+	auto body_narrow = [&](const AcmTile2 &r) -> bool { return NAR && (r.flags & ACM_TILE_NARROW) != 0; };
+	auto warm_narrow = [&](const AcmTile2 &r) -> bool { return NAR && ((r.flags >> warm_bit) & 1u) != 0; };
+	auto sgpr_ptr = [&](const uint64_t a) -> const uint8_t * {
+		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
 		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
 		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
 	};
-	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r) {
-		const bool body = is_narrow(r), front = is_narrow_front(r);
-		const uint8_t *const wide = idx_base(r), *const narrow = idx8_base(r);
-		FP::load(raw, front ? narrow : wide, body ? narrow : wide, voff, warm_off(r), __builtin_amdgcn_readfirstlane(front ? 1u : 0u),
-			 __builtin_amdgcn_readfirstlane(body ? 1u : 0u));
+	auto fetch_plane = [&](const uint32_t k) -> AcmTile2Plane {
+		if constexpr (NAR)
+			return planes[__builtin_amdgcn_readfirstlane(k)];
+		else
+			return AcmTile2Plane{ 0, 0 };
 	};
-
+	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r, const AcmTile2Plane &p) {
+		if constexpr (NAR) {
+			const uint64_t a = reinterpret_cast<uint64_t>(idx);
+			FP::load(raw, sgpr_ptr(a + (uint64_t)(seg0_wave ? p.front : p.body)), sgpr_ptr(a + (uint64_t)p.body), voff, warm_off(r), r.flags, warm_bit);
+		} else {
+			const uint8_t *const base = sgpr_ptr(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS));
+			FP::load(raw, base, base, voff, warm_off(r), 0u, 0u);
+		}
+	};
 
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;      /* 16-byte PCM stores per thread and tile */
 	static_assert(NVEC % NT == 0, "whole rounds");
@@ -1434,7 +1452,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
 	uint32_t raw[FP::NRAW];
 	uint32_t hv = fetch_val(cur);
-	load_tile(raw, cur);
+	load_tile(raw, cur, fetch_plane(t));
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1446,6 +1464,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records come through the scalar cache one iteration ahead (asked for behind the PCM stores, used after the
 	 * next first pass); the last tile of a run names itself as its successor */
 	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+	AcmTile2Plane pnxt = fetch_plane(t + 1 < t_end ? t + 1 : t);
 	for (;;) {
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
@@ -1458,7 +1477,14 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, is_narrow_front(cur), is_narrow(cur));
+		if constexpr (NAR == 2)
+			FP::template compute<true, 3>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, warm_narrow(cur), body_narrow(cur));
+		else if (!body_narrow(cur))
+			FP::template compute<true, 0>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		else if (warm_narrow(cur))
+			FP::template compute<true, 1>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		else
+			FP::template compute<true, 2>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -1466,7 +1492,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(2);
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
-		load_tile(raw, nxt);
+		load_tile(raw, nxt, pnxt);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
@@ -1504,6 +1530,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		cur = nxt;
 		t = tn;
 		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+		pnxt = fetch_plane(t + 1 < t_end ? t + 1 : t);
 		buf ^= 1;
 	}
 #ifdef ACM_STAMPS
@@ -1514,24 +1541,25 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 }
 
 struct Tile2Entry {
-	void (*fn)(const AcmTile2 *, uint32_t, const int16_t *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const AcmTile2Plane *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	Fn fn;                  /* int16 arena only */
+	Fn fn_narrow;           /* the build that reads marked tiles from the int8 plane (a dozen more scalar instructions per tile) */
 	int threads, tile_rows, wg_per_cu;
-	bool split;             /* Tile2Split of the geometry */
+	int narrow_form;        /* acm_tile2's NAR of fn_narrow */
 };
-template <int G0, int...>
-constexpr int first_group() { return G0; }
-template <class C, int... Gs>
-constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT, Tile2Split<C, first_group<Gs...>()>::value }; }
+/* NARFORM: which narrow build (acm_tile2's NAR) fits 128 registers at this geometry */
+template <class C, int NARFORM, int... Gs>
+constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, 0, Gs...>, acm_tile2<C, 4, 0, NARFORM, Gs...>, C::NT, C::TR, 1024 / C::NT, NARFORM }; }
 /* bigger tiles: WPC workgroups per CU */
-template <class C, int WPC, int... Gs>
+template <class C, int WPC, int NARFORM, int... Gs>
 constexpr Tile2Entry entry_k2w()
 {
-	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC, Tile2Split<C, first_group<Gs...>()>::value };
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, 0, Gs...>, acm_tile2<C, WPC * C::NT / 256, 0, NARFORM, Gs...>, C::NT, C::TR, WPC, NARFORM };
 }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4, false }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 0, 3, 3, 3>, nullptr, 256, 16, 4, 0 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
@@ -1545,22 +1573,22 @@ const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
  * equal; level 9 as 64 KB tiles of 512 threads -0.4 %; level 10 (2,3,3,2) -1.5 %, (2,2,3,3) -2.5 %, 64 KB tiles -1.5 %;
  * level 11 as 64 KB tiles of 512 threads, two per CU, (2,3,3,3): -2.7 %, which had been the best without priorities) */
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
-	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
-	entry_k2<TileCfg<7, 256, 8192>, 3, 2, 2>(),
-	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
-	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
-	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
-	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
-	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
+	entry_k2<TileCfg<6, 256, 8192>, 1, 2, 2, 2>(),
+	entry_k2<TileCfg<7, 256, 8192>, 1, 3, 2, 2>(),
+	entry_k2<TileCfg<8, 256, 8192>, 1, 3, 3, 2>(),
+	entry_k2<TileCfg<9, 256, 8192>, 1, 3, 3, 3>(),
+	entry_k2<TileCfg<10, 256, 8192>, 2, 3, 3, 2, 2>(),      /* narrow builds of levels 10-12 and 14: three copies of the first pass spill 5-11 registers */
+	entry_k2<TileCfg<11, 256, 8192>, 2, 3, 3, 3, 2>(),
+	entry_k2w<TileCfg<12, 512, 16384>, 2, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
 	/* level 13: four rows are 128 KB - one workgroup of sixteen waves per CU (still four per SIMD), no plane, no prefix sweep:
 	 * 4 B of HBM traffic per sample instead of the 12 B of the prefix + plane pair.  A two-stage first pass makes the
 	 * whole tile ONE segment (1024 threads x two adjacent columns = the 2048 residues of stride 2048): two warm-up rows per
 	 * four rows instead of per two, 24 instead of 32 prefetch registers: +8 % over (3,2,3,3,2) (2.94 against 3.18 ms for
 	 * 2.1 Gsamples; at levels 10 and 11 the same trade loses 3 %: an LDS-pass stage costs more than a first-pass stage) */
-	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),
+	entry_k2w<TileCfg<13, 1024, 32768>, 1, 1, ACM_L13_GROUPS>(),
 	/* level 14: one row pair is the 128 KB tile (the first pass's body is two rows: the least a tile can be), 155 KB of LDS
 	 * with the carries of the first LDS pass (two bodies of stride 256 = 4096 elements) */
-	entry_k2w<TileCfg<14, 1024, 32768>, 1, ACM_L14_GROUPS>(),
+	entry_k2w<TileCfg<14, 1024, 32768>, 1, 2, ACM_L14_GROUPS>(),
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {
@@ -1736,7 +1764,7 @@ extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 	return (cus > 0 ? cus : 256) * tile2_entry(level).wg_per_cu;
 }
 
-extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const uint8_t *d_idx8,
+extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Plane *d_planes,
 				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
@@ -1755,7 +1783,8 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_idx8, d_hdr, d_pcm, d_sink, fmt);
+	hipLaunchKernelGGL(d_planes && e.fn_narrow ? e.fn_narrow : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx,
+			   d_planes, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
@@ -1764,15 +1793,14 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
  * The narrow staged form of a tile table: every tile's indices as int8 in the plane the lean kernel reads narrow tiles from (the
  * 2 x 2 block of rows 2p, 2p + 1 x columns 2j, 2j + 1 at the byte offset of (row 2p, column 2j) in the int16 plane: same pitch,
  * every other row's worth of bytes unused), ACM_TILE_NARROW in the record of every tile whose own rows fit a byte, and
- * ACM_TILE_NARROW_FRONT where the two rows in front of it (which segment 0 re-reads as its warm-up) do too; a geometry that
- * cannot mix the two (`split` == 0: Tile2Split) gets ACM_TILE_NARROW only together with ACM_TILE_NARROW_FRONT.  One workgroup
+ * ACM_TILE_NARROW_FRONT where the two rows in front of it (which segment 0 re-reads as its warm-up) do too.  One workgroup
  * per tile; a thread turns 2 rows x 8 columns (two 16-byte reads) into 16 bytes.  count[0] += tiles narrow in both respects,
  * count[1] += tiles with narrow rows of their own behind rows that are not.
  */
 namespace {
 __global__ void __launch_bounds__(256)
-acm_pack_narrow(AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint32_t level, const uint32_t tile_rows,
-		const int16_t *__restrict__ idx, uint8_t *__restrict__ idx8, uint32_t *__restrict__ count, const int split)
+acm_pack_narrow(AcmTile2 *__restrict__ tiles, AcmTile2Plane *__restrict__ planes, const uint32_t ntiles, const uint32_t level, const uint32_t tile_rows,
+		const int16_t *__restrict__ idx, uint8_t *__restrict__ idx8, uint32_t *__restrict__ count)
 {
 	const uint32_t t = blockIdx.x;
 	if (t >= ntiles)
@@ -1804,25 +1832,35 @@ acm_pack_narrow(AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint3
 			look(wide_front, a.w);
 		}
 	const int any_wide_front = __syncthreads_or((wide_front & ~0xFFu) != 0);
-	const int any_wide = __syncthreads_or((wide & ~0xFFu) != 0) || (!split && any_wide_front);
+	const int any_wide = __syncthreads_or((wide & ~0xFFu) != 0);
 	if (threadIdx.x == 0) {
 		tiles[t].flags = (r.flags & ~(ACM_TILE_NARROW | ACM_TILE_NARROW_FRONT)) | (any_wide ? 0u : ACM_TILE_NARROW) |
-				 (any_wide_front ? 0u : ACM_TILE_NARROW_FRONT);
+				 (any_wide || any_wide_front ? 0u : ACM_TILE_NARROW_FRONT);
 		if (!any_wide)
 			atomicAdd(&count[any_wide_front ? 1 : 0], 1u);
+		const int64_t at = 2 * ((int64_t)r.idx_off - 2 * (int64_t)cols);         /* (tile row -2, column 0), bytes, in either plane */
+		const int64_t to8 = reinterpret_cast<const uint8_t *>(idx8) - reinterpret_cast<const uint8_t *>(idx);
+		planes[t] = AcmTile2Plane{ at + (any_wide ? 0 : to8), at + (any_wide || any_wide_front ? 0 : to8) };
 	}
 }
 }
 
-extern "C" int acmk_launch_pack_narrow(uint32_t level, AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, uint8_t *d_idx8,
-				       uint32_t *d_count, void *stream)
+extern "C" int acmk_tile2_narrow_form(uint32_t level)
+{
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return 0;
+	return tile2_entry(level).narrow_form;
+}
+
+extern "C" int acmk_launch_pack_narrow(uint32_t level, AcmTile2 *d_tiles, AcmTile2Plane *d_planes, uint32_t ntiles, const int16_t *d_idx,
+				       uint8_t *d_idx8, uint32_t *d_count, void *stream)
 {
 	if (ntiles == 0)
 		return 0;
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return -1;
-	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, ntiles, level,
-			   (uint32_t)tile2_entry(level).tile_rows, d_idx, d_idx8, d_count, tile2_entry(level).split ? 1 : 0);
+	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, d_planes, ntiles, level,
+			   (uint32_t)tile2_entry(level).tile_rows, d_idx, d_idx8, d_count);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

@@ -2,8 +2,10 @@
 
   python3 profiles/narrow_probe.py [level streams rows blocks [pwr_max]] ...
 
-Per configuration: tiles found narrow, launch time with the int8 plane detached / attached (HIP events over 20 launches,
-best and median of the rounds), PCM of both forms compared word for word on the device's output (CRC-32 of the arena)."""
+Per configuration: launch time with the int8 plane detached ("wide") / attached ("narrow": the plan decides per level whether the
+narrow build of the kernel pays; "forced": ACM_NARROW=1, the narrow build whenever a tile is narrow) and the tiles read from
+the int8 plane (HIP events over 20 launches, best and median of the rounds); PCM of the forms compared word for word on the
+device's output (CRC-32 of the arena)."""
 import os
 import sys
 import zlib
@@ -15,8 +17,8 @@ sys.path.insert(0, ROOT)
 from libacm_amd import capi, workload  # noqa: E402
 
 
-def run(dev, level, streams, rows, blocks, pwr_max=None):
-    kw = {} if pwr_max is None else {"pwr_min": min(4, pwr_max), "pwr_max": pwr_max}
+def run(dev, level, streams, rows, blocks, pwr_max=None, pwr_min=None):
+    kw = {} if pwr_max is None else {"pwr_min": min(4, pwr_max) if pwr_min is None else pwr_min, "pwr_max": pwr_max}
     b = workload.build_uniform(streams, level, rows, blocks, seed0=0, keep_files=0, **kw)
     bufs = b.upload(dev)
     plan = capi.Plan(dev, b.descs)
@@ -31,11 +33,15 @@ def run(dev, level, streams, rows, blocks, pwr_max=None):
     wide_crc = crc()
     n = plan.attach_narrow(bufs[0])
     narrow_crc = crc()
-    forms = ("wide", "narrow")
+    forms = ("wide", "narrow", "forced")
     times = {f: [] for f in forms}
     counts = {}
     for _ in range(6):
         for form in forms:
+            if form == "forced":
+                os.environ["ACM_NARROW"] = "1"            # the narrow build even where the plan would not choose it
+            else:
+                os.environ.pop("ACM_NARROW", None)
             plan.attach_narrow(None if form == "wide" else bufs[0])
             st = plan.stats()
             counts[form] = (st.narrow_tiles, st.narrow_front_tiles, st.tiles)

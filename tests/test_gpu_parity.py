@@ -87,9 +87,15 @@ def test_lean_tile_kernel_levels_13_14(dev, force_k2, level, rows):
         check_streams(dev, [g], fmt=fmt)
 
 
+@pytest.fixture
+def force_narrow(monkeypatch):
+    """ACM_NARROW=1: the narrow build of the tile kernel runs as soon as one tile is narrow (default: when enough are to pay)"""
+    monkeypatch.setenv("ACM_NARROW", "1")
+
+
 @pytest.mark.parametrize("level", [6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("rows,pwr_max", [(1, 6), (3, 12), (16, 6), (16, 12), (17, 9), (700, 7)])
-def test_narrow_tiles_matrix(dev, force_k2, level, rows, pwr_max):
+def test_narrow_tiles_matrix(dev, force_k2, force_narrow, level, rows, pwr_max):
     """acmhip_plan_attach_narrow: tiles whose indices fit a byte are read from the int8 plane (half the loads), the others from
     the int16 arena, tile by tile in one launch; pwr <= 6 keeps every index inside a byte (linear fillers have at most
     pwr + 1 bits), pwr up to 12 mixes narrow and wide tiles and tiles whose own rows fit but not the two rows in front"""
@@ -103,7 +109,7 @@ def test_narrow_tiles_matrix(dev, force_k2, level, rows, pwr_max):
 
 
 @pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_U16BE])
-def test_narrow_tiles_batch(dev, force_k2, fmt):
+def test_narrow_tiles_batch(dev, force_k2, force_narrow, fmt):
     """many streams of every level, narrow and wide ones interleaved: workgroup runs start inside streams (lead-in tiles,
     narrow or not) and cross from a narrow stream into a wide one"""
     files = []
@@ -115,6 +121,26 @@ def test_narrow_tiles_batch(dev, force_k2, fmt):
                                  channels=1 + i % 2, cut=i % 3, pwr_min=min(4, pm), pwr_max=pm, val_max=65535 if i % 5 == 0 else 255))
     st = check_streams(dev, files, fmt=fmt, narrow=True)
     assert 0 < st.narrow_tiles < st.tiles
+
+
+@pytest.mark.parametrize("level", [9, 11])
+def test_narrow_build_is_used_only_where_it_pays(dev, force_k2, level, monkeypatch):
+    """per level group acmhip_plan_attach_narrow counts the narrow tiles and keeps the int16-only build of the kernel when they
+    are too few: level 9 (narrow build as fast on wide tiles) takes it from 2 % on, level 11 (3 % slower on wide tiles) from a
+    third on; ACM_NARROW=0 / 1 overrides"""
+    blocks = 80
+    quiet = make_stream(9100 + level, level, 16, blocks, pwr_min=3, pwr_max=7)          # every tile narrow
+    mixed = make_stream(9200 + level, level, 16, blocks, pwr_min=7, pwr_max=12)         # about one block in six
+    for f, expect_default in ((quiet, "all"), (mixed, "some" if level == 9 else "none")):
+        for env, expect in ((None, expect_default), ("0", "none"), ("1", "all" if f is quiet else "some")):
+            if env is None:
+                monkeypatch.delenv("ACM_NARROW", raising=False)
+            else:
+                monkeypatch.setenv("ACM_NARROW", env)
+            st = check_streams(dev, [f], narrow=True)
+            lean = (blocks * 16) // ((8192 >> level) if level < 13 else 1)
+            assert {"none": st.narrow_tiles == 0, "some": 0 < st.narrow_tiles < lean, "all": st.narrow_tiles == lean}[expect], (
+                level, env, expect, st.narrow_tiles, lean)
 
 
 def test_narrow_plane_follows_the_arena_it_was_packed_from(dev, force_k2):
