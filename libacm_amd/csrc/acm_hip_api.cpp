@@ -893,10 +893,10 @@ extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, 
 	if (!d_idx || pl->narrow_extent == 0)
 		return ACMHIP_OK;                       /* detached / nothing the lean kernel takes */
 	const size_t ngroups = pl->fused.size();
-	if (!pl->d_idx8) {
-		HIPTRY(hipMalloc((void **)&pl->d_idx8, pl->narrow_extent * 2));
+	if (!pl->d_idx8)
+		HIPTRY(hipMalloc((void **)&pl->d_idx8, pl->narrow_extent * 2));         /* the int16 arena's pitch: every other row pair's worth unused */
+	if (!pl->d_narrow_count)
 		HIPTRY(hipMalloc((void **)&pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t)));
-	}
 	hipStream_t st = pl->dev->stream;
 	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, ngroups * 2 * sizeof(uint32_t), st));
 	for (size_t k = 0; k < ngroups; k++) {
