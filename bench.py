@@ -506,7 +506,7 @@ def main():
     # the same loop on the int16 arena alone, right behind (the int8 plane detached, then attached again)
     if narrow is not None:
         narrow.update(tiles=int(stats.narrow_tiles), tiles_with_rows_in_front=int(stats.narrow_front_tiles))
-        if stats.narrow_tiles:
+        if stats.narrow_tiles and not args.no_extra:        # (profiling runs pass --no-extra: every launch they see is the headline's)
             plan.attach_narrow(None)
             nsteps = max(args.steps, min(SUSTAINED_STEPS, 100))
             _, wev = time_plan(dev, plan, bufs, nsteps, 5, lambda: None)

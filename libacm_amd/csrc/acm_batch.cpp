@@ -21,6 +21,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -391,6 +392,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	hipStream_t st_up = nullptr, st_parse = nullptr;        /* file uploads piece by piece; the walk + column kernels */
 	std::vector<ParseGroup> groups(npg);
 	std::vector<Chunk> rchunks(R > 1 ? R : 0);              /* block ranges: plan, events and read-back state of each */
+	std::vector<hipEvent_t> ev_stripe(R > 1 ? R + 1 : 0, nullptr);  /* [0] = first stripe's upload begins, [s + 1] = stripe s is in place */
+	std::unique_ptr<std::atomic<int>[]> stripe_uncopied(R > 1 ? new std::atomic<int>[R] : nullptr);
 
 	auto cleanup = [&]() {
 		if (pool_busy) {
@@ -412,6 +415,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			for (hipEvent_t e : g.ev)
 				if (e)
 					(void)hipEventDestroy(e);
+		for (hipEvent_t e : ev_stripe)
+			if (e)
+				(void)hipEventDestroy(e);
 		for (std::vector<Chunk> *v : { &chunks, &rchunks })
 			for (Chunk &ch : *v) {
 				acmhip_plan_destroy(ch.plan);
@@ -440,12 +446,20 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PCM, pcm_arena_words * sizeof(int16_t), (void **)&d_pcm));
 	const size_t jobs_bytes = round_up(dev_ids.size() * sizeof(AcmParseJob), 64);
 	const size_t res_bytes = dev_ids.size() * (sizeof(AcmParseResult) + sizeof(uint32_t));  /* results, then flags */
+	/* block ranges: the files go up in R stripes (stripe s of every file back to back: one transfer, then a scatter kernel),
+	 * so that range 0 is walked, synthesised and on its way back while the later stripes are still going up */
+	const size_t nd = dev_ids.size();
+	const size_t stripe_tab_off = jobs_bytes + round_up(res_bytes, 64);
+	const size_t stripe_tab_bytes = R > 1 ? R * nd * sizeof(uint64_t) : 0;
+	uint8_t *d_stage = nullptr;
 	if (!dev_ids.empty()) {
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_FILES, files_total, (void **)&h_files));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_FILES, files_total, (void **)&d_files));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_COLPOS, cols_total * sizeof(uint32_t), (void **)&d_colpos));
-		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, jobs_bytes + res_bytes, (void **)&h_jobs));
-		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, jobs_bytes + res_bytes, (void **)&d_jobs));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_JOBS, stripe_tab_off + stripe_tab_bytes, (void **)&h_jobs));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_JOBS, stripe_tab_off + stripe_tab_bytes, (void **)&d_jobs));
+		if (R > 1)
+			BTRY(acmhip_arena_get(dev, ACM_ARENA_D_STAGE, files_total, (void **)&d_stage));
 	}
 	for (std::vector<Chunk> *v : { &chunks, &rchunks })
 		for (Chunk &ch : *v)
@@ -458,6 +472,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	for (size_t g = 0; g < groups.size(); g++)
 		for (hipEvent_t &e : groups[g].ev)
 			HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
+	for (hipEvent_t &e : ev_stripe)
+		HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
 	const auto t_alloc = clk::now();
 	tm.alloc_s = secs(t_hdr, t_alloc);
 	BNOTE("headers %.3f ms, arenas + events %.3f ms; %zu chunks, %zu parse groups", secs(t0, t_hdr) * 1e3, tm.alloc_s * 1e3, chunks.size(), groups.size());
@@ -527,6 +543,23 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			g.uncopied.fetch_add(1);
 		}
 	}
+	uint64_t *stripe_at = reinterpret_cast<uint64_t *>(h_jobs ? h_jobs + stripe_tab_off : nullptr);  /* [s * nd + k]: stripe s of stream k in the striped arenas */
+	std::vector<uint64_t> stripe_base(R > 1 ? R + 1 : 0, 0);
+	constexpr size_t STRIPE_BATCH = 32;             /* files per copy task */
+	const size_t nbat = (nd + STRIPE_BATCH - 1) / STRIPE_BATCH;
+	if (R > 1) {
+		uint64_t at = 0;
+		for (size_t s = 0; s < R; s++) {
+			stripe_base[s] = at;
+			for (size_t k = 0; k < nd; k++) {
+				const uint32_t len = (uint32_t)items[dev_ids[k]].len;
+				stripe_at[s * nd + k] = at;
+				at += acmk_stripe_bound(len, (uint32_t)s + 1, (uint32_t)R) - acmk_stripe_bound(len, (uint32_t)s, (uint32_t)R);
+			}
+			stripe_uncopied[s].store((int)nbat);
+		}
+		stripe_base[R] = at;            /* == files_total: the stripes tile every slot */
+	}
 	for (size_t i = 0; i < n; i++)
 		if (slots[i].ok && !on_dev[i])
 			host_ids.push_back(i);                  /* ascending, i.e. arena order */
@@ -548,10 +581,29 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			out_ids.push_back(i);
 	std::atomic<size_t> parsed{ 0 };
 	clk::time_point t_parsed = clk::now();
-	const size_t ncopy = groups.empty() ? 0 : dev_ids.size();
+	const size_t ncopy = groups.empty() ? 0 : R > 1 ? R * nbat : dev_ids.size();
 	const size_t nparse = host_ids.size();
 	pool_busy = true;
 	pool.start(ncopy + nparse + out_ids.size() * R, [&](size_t task) {
+		if (task < ncopy && R > 1) {
+			/* stripe-major: stripe 0 of every file first (a task = one stripe of STRIPE_BATCH files) */
+			const size_t s = task / nbat, k0 = task % nbat * STRIPE_BATCH;
+			for (size_t k = k0; k < std::min(nd, k0 + STRIPE_BATCH); k++) {
+				const acm_batch_item &it = items[dev_ids[k]];
+				const uint64_t lo = acmk_stripe_bound((uint32_t)it.len, (uint32_t)s, (uint32_t)R),
+					       hi = acmk_stripe_bound((uint32_t)it.len, (uint32_t)s + 1, (uint32_t)R);
+				uint8_t *dst = h_files + stripe_at[s * nd + k];
+				const uint64_t have = it.len > lo ? std::min<uint64_t>(it.len, hi) - lo : 0;       /* file bytes in this stripe */
+				if (have)
+					memcpy(dst, static_cast<const uint8_t *>(it.data) + lo, have);
+				memset(dst + have, 0, hi - lo - have);                                        /* the slot's zero tail */
+			}
+			if (stripe_uncopied[s].fetch_sub(1) == 1) {
+				std::lock_guard<std::mutex> g(m);
+				cv.notify_all();
+			}
+			return;
+		}
 		if (task < ncopy) {
 			const size_t i = dev_ids[task];
 			const acm_batch_item &it = items[i];
@@ -698,6 +750,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	for (ParseGroup &g : groups) {
 		if (g.k_first == g.k_last)
 			continue;
+		max_columns = std::max(max_columns, g.max_columns);
+		ev_parsed = g.ev[2];
+		if (R > 1)
+			continue;               /* striped upload below */
 		{
 			std::unique_lock<std::mutex> lk(m);
 			cv.wait(lk, [&]() { return g.uncopied.load() == 0; });
@@ -708,42 +764,79 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		HTRY(hipMemcpyAsync(d_jobs + g.k_first * sizeof(AcmParseJob), h_jobs + g.k_first * sizeof(AcmParseJob), nj * sizeof(AcmParseJob),
 				    hipMemcpyHostToDevice, st_up));
 		HTRY(hipEventRecord(g.ev[1], st_up));
-		max_columns = std::max(max_columns, g.max_columns);
-		ev_parsed = g.ev[2];
 		if (&g == &groups.back() || (&g)[1].k_first == (&g)[1].k_last)
 			BNOTE("files up to piece %zu queued for upload", (size_t)(&g - groups.data()));
 	}
 	if (ev_parsed) {
 		AcmParseResult *d_res = reinterpret_cast<AcmParseResult *>(d_jobs + jobs_bytes);
 		uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_res + dev_ids.size());
-		HTRY(hipEventRecord(ev_parsed, st_up));         /* re-recorded below: here it only orders the walk behind the last upload */
-		HTRY(hipStreamWaitEvent(st_parse, ev_parsed, 0));
-		HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_parse));
-		for (size_t r = 0; r < R; r++) {
+		/* one block range: the walk + column kernels, and with R > 1 the synthesis and the read-back of what they staged */
+		auto launch_range = [&](size_t r, size_t stripes_up) -> int {
 			const int e = acmk_launch_parse_range(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx,
-							      d_hdr, d_res, d_flags, max_columns, (uint32_t)r, (uint32_t)R, st_parse);
-			HTRY((hipError_t)e);
+							      d_hdr, d_res, d_flags, max_columns, (uint32_t)r, (uint32_t)R, (uint32_t)stripes_up, st_parse);
+			if (e != 0)
+				return acmhip_report_hip(e, "acmk_launch_parse_range");
 			if (R == 1)
-				break;
+				return ACMHIP_OK;
 			/* range r is staged: synthesise it and read it back while the walk goes on */
 			Chunk &rg = rchunks[r];
-			HTRY(hipEventRecord(rg.ev[1], st_parse));
-			HTRY(hipStreamWaitEvent(st_main, rg.ev[1], 0));
-			HTRY(hipEventRecord(rg.ev[0], st_main));
-			if (rg.plan)
-				BTRY(acmhip_plan_launch(rg.plan, d_idx, d_hdr, d_pcm, opts.fmt));
-			HTRY(hipEventRecord(rg.ev[2], st_main));
-			HTRY(hipStreamWaitEvent(st_copy, rg.ev[2], 0));
-			HTRY(hipEventRecord(rg.ev[3], st_copy));
+#define RTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return acmhip_report_hip((int)e_, #call); } while (0)
+			RTRY(hipEventRecord(rg.ev[1], st_parse));
+			RTRY(hipStreamWaitEvent(st_main, rg.ev[1], 0));
+			RTRY(hipEventRecord(rg.ev[0], st_main));
+			if (rg.plan) {
+				const int pr = acmhip_plan_launch(rg.plan, d_idx, d_hdr, d_pcm, opts.fmt);
+				if (pr != ACMHIP_OK)
+					return pr;
+			}
+			RTRY(hipEventRecord(rg.ev[2], st_main));
+			RTRY(hipStreamWaitEvent(st_copy, rg.ev[2], 0));
+			RTRY(hipEventRecord(rg.ev[3], st_copy));
 			if (rbase[r + 1] > rbase[r])
-				HTRY(hipMemcpyAsync(h_pcm + rbase[r], d_pcm + rbase[r], (rbase[r + 1] - rbase[r]) * sizeof(int16_t), hipMemcpyDeviceToHost, st_copy));
-			HTRY(hipEventRecord(rg.ev[4], st_copy));
+				RTRY(hipMemcpyAsync(h_pcm + rbase[r], d_pcm + rbase[r], (rbase[r + 1] - rbase[r]) * sizeof(int16_t), hipMemcpyDeviceToHost, st_copy));
+			RTRY(hipEventRecord(rg.ev[4], st_copy));
+#undef RTRY
 			BNOTE("range %zu: walk, synthesis and read-back queued", r);
 			{
 				std::lock_guard<std::mutex> g(m);
 				issued.store(r + 1, std::memory_order_release);
 			}
 			cv.notify_all();
+			return ACMHIP_OK;
+		};
+		HTRY(hipMemsetAsync(d_flags, 0, dev_ids.size() * sizeof(uint32_t), st_parse));
+		if (R == 1) {
+			HTRY(hipEventRecord(ev_parsed, st_up));         /* re-recorded below: here it only orders the walk behind the last upload */
+			HTRY(hipStreamWaitEvent(st_parse, ev_parsed, 0));
+			BTRY(launch_range(0, 0));
+		} else {
+			/* striped upload: stripe s of every file as one transfer + a scatter kernel; the walk of range r may start once
+			 * stripe r + 1 is in place (a range of blocks ends near the end of its stripe of the bits; one stripe of margin -
+			 * a stream whose bit rate is so uneven that it needs more is stopped there and taken by the host reader) */
+			HTRY(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, st_up));
+			HTRY(hipMemcpyAsync(d_jobs + stripe_tab_off, h_jobs + stripe_tab_off, stripe_tab_bytes, hipMemcpyHostToDevice, st_up));
+			HTRY(hipEventRecord(ev_stripe[0], st_up));
+			for (size_t sp = 0; sp < R; sp++) {
+				{
+					std::unique_lock<std::mutex> lk(m);
+					cv.wait(lk, [&]() { return stripe_uncopied[sp].load() == 0; });
+				}
+				if (stripe_base[sp + 1] > stripe_base[sp])
+					HTRY(hipMemcpyAsync(d_stage + stripe_base[sp], h_files + stripe_base[sp], stripe_base[sp + 1] - stripe_base[sp],
+							    hipMemcpyHostToDevice, st_up));
+				HTRY((hipError_t)acmk_launch_scatter_stripe(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)nd,
+									   reinterpret_cast<const uint64_t *>(d_jobs + stripe_tab_off), d_stage, d_files,
+									   (uint32_t)sp, (uint32_t)R, st_up));
+				HTRY(hipEventRecord(ev_stripe[sp + 1], st_up));
+				if (sp >= 1) {
+					HTRY(hipStreamWaitEvent(st_parse, ev_stripe[sp + 1], 0));
+					BTRY(launch_range(sp - 1, sp + 1 < R ? sp + 1 : 0));
+				}
+				if (sp + 1 == R) {
+					BNOTE("last stripe of the files queued for upload");
+					BTRY(launch_range(R - 1, 0));
+				}
+			}
 		}
 		HTRY(hipMemcpyAsync(results, d_jobs + jobs_bytes, res_bytes, hipMemcpyDeviceToHost, st_parse));
 		HTRY(hipEventRecord(ev_parsed, st_parse));
@@ -944,8 +1037,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	double h2d_files_s = 0;
 	for (ParseGroup &g : groups) {
 		float ms = 0;
-		if (g.k_first != g.k_last && hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess)
+		if (R == 1 && g.k_first != g.k_last && hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess)
 			h2d_files_s += ms * 1e-3;
+	}
+	if (R > 1) {            /* striped upload: first stripe queued .. last stripe in place (the stripes wait for the pool's copies in between) */
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, ev_stripe[0], ev_stripe[R]) == hipSuccess)
+			h2d_files_s = ms * 1e-3;
 	}
 	tm.h2d_s += h2d_files_s;
 	/* host-side staging: headers, then until the last stream was parsed - by the pool, or by the device (whose walks

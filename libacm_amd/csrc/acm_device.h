@@ -102,7 +102,7 @@ extern "C" {
  * calls.  A device handle serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
 enum {
 	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS,
-	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_COLPOS, ACM_ARENA_D_JOBS,
+	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_COLPOS, ACM_ARENA_D_JOBS, ACM_ARENA_D_STAGE,
 	ACM_ARENA_SLOTS
 };
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
@@ -152,7 +152,15 @@ int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *
 #define ACM_PARSE_RANGE_MAX_STREAMS 32768
 int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 			    acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,
-			    void *stream);
+			    uint32_t stripes_up, void *stream);
+/* Striped upload of a block-range batch: every file's arena slot (the file padded to 16 bytes + 16 zero bytes) is cut into R
+ * stripes at acmk_stripe_bound(len, s, R); stripe s of all files travels as ONE transfer into a staging arena and a scatter
+ * kernel puts the pieces in place, so the first ranges are walked, synthesised and read back while the later stripes are
+ * still on their way up (PCIe runs both directions at once).  stripes_up (0 = the whole file is there) tells the walk of a
+ * range how many stripes it may read: a stream that needs more stops with a status and goes to the host reader. */
+uint32_t acmk_stripe_bound(uint32_t file_len, uint32_t s, uint32_t S);
+int acmk_launch_scatter_stripe(const AcmParseJob *d_jobs, uint32_t njobs, const uint64_t *d_stripe_at, const uint8_t *d_stage,
+			       uint8_t *d_files, uint32_t s, uint32_t S, void *stream);
 int acmk_launch_small(uint32_t level, const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,
 		      const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm, unsigned fmt, void *stream);
 int acmk_launch_emit(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,

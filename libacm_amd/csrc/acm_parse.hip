@@ -150,6 +150,13 @@ __device__ __forceinline__ uint32_t k_table_for(uint32_t code)
 
 /* ---- kernel 1: walk the streams ---- */
 
+/* striped upload: stripe s of S of a file's arena slot (the file, padded to 16 bytes, + 16 zero bytes) starts here */
+__host__ __device__ __forceinline__ uint32_t acm_stripe_bound(uint32_t file_len, uint32_t s, uint32_t S)
+{
+	const uint32_t slot = ((file_len + 15u) & ~15u) + 16u;
+	return s >= S ? slot : (uint32_t)(((uint64_t)slot * s / S) & ~15ull);
+}
+
 /* payload bits of a column by filler code for `rows` rows; K_WALK = step through it, BAD_CODE = stop */
 __device__ __forceinline__ uint32_t column_bits(uint32_t code, uint32_t rows)
 {
@@ -366,7 +373,7 @@ constexpr int WAVE_SCAN_WAVES = 4;      /* streams per workgroup: one per SIMD o
 __global__ void __launch_bounds__(64 * WAVE_SCAN_WAVES)
 acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
 		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res,
-		    const uint32_t range, const uint32_t nranges)
+		    const uint32_t range, const uint32_t nranges, const uint32_t stripes_up)
 {
 	const uint32_t jobno = blockIdx.x * WAVE_SCAN_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (jobno >= njobs)
@@ -374,7 +381,10 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	const uint32_t lane = threadIdx.x & 63u;
 	const AcmParseJob job = jobs[jobno];
 	const uint32_t rows = job.rows, cols = 1u << job.level;
-	const uint32_t safe = job.file_len * 8u;
+	/* striped upload (acm_batch.cpp): only the first stripes_up of nranges stripes of every file are on the device yet; a
+	 * stream whose range reaches beyond them stops as if its data had run out, and the host reader takes it */
+	const uint32_t safe = 8u * (stripes_up && stripes_up < nranges ? min(job.file_len, acm_stripe_bound(job.file_len, stripes_up, nranges))
+								      : job.file_len);
 	/* per-lane tables, looked up with v_readlane: lane = filler code */
 	const uint32_t code_len = column_bits(lane & 31u, rows);
 	const uint32_t code_tab = k_table_for(lane & 31u);
@@ -597,10 +607,43 @@ extern "C" int acmk_parse_supported(uint32_t level, uint32_t rows, uint64_t file
  * d_flags[njobs] must be zero on entry; after the kernels a stream is clean iff
  * d_res[j].status == 0 && d_res[j].blocks_done == jobs[j].blocks && d_flags[j] == 0.
  */
+/* striped upload: stripe s of every file, uploaded back to back into the staging arena, goes to its place in the file arena */
+namespace {
+__global__ void __launch_bounds__(256)
+acm_scatter_stripe(const AcmParseJob *__restrict__ jobs, const uint32_t njobs, const uint64_t *__restrict__ stripe_at,
+		   const uint8_t *__restrict__ stage, uint8_t *__restrict__ files, const uint32_t s, const uint32_t S)
+{
+	const uint32_t k = blockIdx.x;
+	if (k >= njobs)
+		return;
+	const AcmParseJob job = jobs[k];
+	const uint32_t lo = acm_stripe_bound(job.file_len, s, S), hi = acm_stripe_bound(job.file_len, s + 1, S);
+	const uint4 *src = reinterpret_cast<const uint4 *>(stage + stripe_at[(uint64_t)s * njobs + k]);
+	uint4 *dst = reinterpret_cast<uint4 *>(files + job.file_off + lo);
+	for (uint32_t v = threadIdx.x; v < (hi - lo) / 16u; v += 256u)
+		dst[v] = src[v];
+}
+}
+
+extern "C" uint32_t acmk_stripe_bound(uint32_t file_len, uint32_t s, uint32_t S)
+{
+	return acm_stripe_bound(file_len, s, S);
+}
+
+extern "C" int acmk_launch_scatter_stripe(const AcmParseJob *d_jobs, uint32_t njobs, const uint64_t *d_stripe_at, const uint8_t *d_stage,
+					  uint8_t *d_files, uint32_t s, uint32_t S, void *stream)
+{
+	if (njobs == 0)
+		return 0;
+	hipLaunchKernelGGL(acm_scatter_stripe, dim3(njobs), dim3(256), 0, (hipStream_t)stream, d_jobs, njobs, d_stripe_at, d_stage, d_files, s, S);
+	ACMP_CHECK();
+	return 0;
+}
+
 extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files,
 				       uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
 				       AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t range, uint32_t nranges,
-				       void *stream)
+				       uint32_t stripes_up, void *stream)
 {
 	if (njobs == 0)
 		return 0;
@@ -630,7 +673,7 @@ extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs
 #endif
 	if (njobs <= wave_max)
 		hipLaunchKernelGGL(acm_parse_scan_wave, dim3((njobs + WAVE_SCAN_WAVES - 1) / WAVE_SCAN_WAVES), dim3(64 * WAVE_SCAN_WAVES), 0, st,
-				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res, range, nranges);
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res, range, nranges, stripes_up);
 	else
 		hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
 				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
@@ -653,5 +696,5 @@ extern "C" int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, cons
 				 uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
 				 AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, void *stream)
 {
-	return acmk_launch_parse_range(d_jobs, njobs, d_files, d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, 0, 1, stream);
+	return acmk_launch_parse_range(d_jobs, njobs, d_files, d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, 0, 1, 0, stream);
 }
