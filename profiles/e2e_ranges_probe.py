@@ -1,5 +1,5 @@
 """End-to-end device-parse batch (file bytes in host memory -> PCM in host memory) by block-range count, same box, interleaved.
-usage: python3 profiles/e2e_ranges_probe.py [streams level rows blocks]   (GPU box)"""
+usage: python3 profiles/e2e_ranges_probe.py [streams level rows blocks]   (GPU box; E2E_RANGES=1,8,16,32 picks the counts)"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -11,7 +11,7 @@ with ThreadPoolExecutor(32) as ex:
     files = list(ex.map(lambda i: synth.generate(seed=synth.BASE_SEED + i, level=level, rows=rows, nblocks=blocks), range(n)))
 ref = None
 for rep in range(3):
-    for R in ("1", "4", "8", "16"):
+    for R in os.environ.get("E2E_RANGES", "1,4,8,16").split(","):
         os.environ["ACM_BATCH_RANGES"] = R
         for pinned in (False, True):
             res, tm = capi.batch_decode(dev, files, parse=capi.PARSE_DEVICE, pinned=pinned)
