@@ -467,7 +467,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				HTRY(hipEventCreateWithFlags(&e, hipEventBlockingSync));
 	if (!groups.empty()) {
 		BTRY(acmhip_aux_stream(dev, ACM_AUX_STREAMS - 1, (void **)&st_up));
-		BTRY(acmhip_aux_stream(dev, 0, (void **)&st_parse));
+		/* block ranges: walk r, its columns and its synthesis (0.2 ms) follow each other anyway - one stream; what must never
+		 * share a hardware queue is the upload, the read-back and the kernels (the runtime maps streams onto a handful of
+		 * queues: an upload queued behind a 5 ms read-back on the same one arrives 5 ms late, every stripe of it) */
+		if (R > 1)
+			st_parse = st_main;
+		else
+			BTRY(acmhip_aux_stream(dev, 0, (void **)&st_parse));
 	}
 	for (size_t g = 0; g < groups.size(); g++)
 		for (hipEvent_t &e : groups[g].ev)

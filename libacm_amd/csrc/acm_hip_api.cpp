@@ -148,6 +148,15 @@ extern "C" int acmhip_device_open(int ordinal, void *hip_stream, acmhip_device *
 			return hip_fail(e, "hipStreamCreateWithFlags");
 		}
 	}
+	/* the streams of the batch pipeline that run concurrently - kernels (above), read-back, upload - are created here, one
+	 * after the other: the runtime hands out its few hardware queues in creation order, so these three get one each as long
+	 * as queues are left (created later, between whatever else the process creates, two of them may share one, and an
+	 * upload then waits behind every read-back).  Failing here is not fatal: they are created on first use otherwise */
+	if (hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking) != hipSuccess)
+		d->copy_stream = nullptr;
+	if (hipStreamCreateWithFlags(&d->aux[ACM_AUX_STREAMS - 1], hipStreamNonBlocking) != hipSuccess)
+		d->aux[ACM_AUX_STREAMS - 1] = nullptr;
+	(void)hipGetLastError();
 	*out = d;
 	return ACMHIP_OK;
 }
