@@ -206,6 +206,53 @@ def copy_ceiling():
     return (round(gbs, 1), name.value.decode()) if gbs > 0 else None
 
 
+def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):
+    """HBM bytes per launch of the tile kernel, measured on THIS box in THIS run: two child runs of this command under
+    rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else enabled - MI355X_MICROARCH.md "HBM"),
+    a handful of launches each with the same staged input.  FETCH_SIZE is doubled (gfx950 tallies its 128-byte requests at
+    64 B), both are KiB.  None when rocprofv3 is not there or a pass fails (the line then falls back to the committed profile)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu", "--no-extra", "--no-verify",
+             "--streams", str(args.streams), "--level", str(args.level), "--rows", str(args.rows), "--blocks", str(args.blocks),
+             "--channels", str(args.channels)] + (["--no-narrow"] if args.no_narrow else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="acm_pmc_", dir="/tmp")
+        try:
+            # the program itself stands right behind "--": the profiler's library is in the process before it starts
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            total, dispatches = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and any(w in row.get("Kernel_Name", "") for w in kernel_words):
+                            total += float(row["Counter_Value"])
+                            dispatches.add(row["Dispatch_Id"])
+            if not dispatches:
+                return None
+            got[counter] = (total / len(dispatches), len(dispatches))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return {"hbm_bytes_per_launch": int((2 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024),
+            "fetch_size_kib_raw": round(got["FETCH_SIZE"][0], 1), "write_size_kib": round(got["WRITE_SIZE"][0], 1),
+            "dispatches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]], "seconds": round(time.perf_counter() - t0, 1)}
+
+
 def kernel_source_sha():
     """sha256 of the kernel source with comments and white space stripped (what the compiler sees, line numbers aside): a
     comment edit does not orphan the committed PMC traffic figures, a code edit does"""
@@ -595,6 +642,15 @@ def main():
     except Exception:
         traffic = None
 
+    # ... and, on rank 0 of a one-GPU default run, measured now: two short child runs of this command under rocprofv3 --pmc
+    traffic_committed = traffic
+    if rank == 0 and world == 1 and not args.no_extra and not args.stagewise and args.workload == "uniform" and 6 <= args.level <= 14:
+        lt = live_traffic(args)
+        if lt:
+            traffic = lt["hbm_bytes_per_launch"]
+            traffic_src = ("measured in this run on this box: two child runs of this command under rocprofv3 --pmc (FETCH_SIZE x2, WRITE_SIZE; "
+                           "%d / %d dispatches of the tile kernel, %.0f s)" % (lt["dispatches"][0], lt["dispatches"][1], lt["seconds"]))
+
     lv_txt = "7-9" if args.workload == "corpus" else args.level
     shape = (args.streams, args.level, args.rows, args.blocks, args.channels)
     out = {
@@ -622,6 +678,7 @@ def main():
                    "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_committed_profile": traffic_committed,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
                      "kernel": ("acm_tile2<TileCfg<%s,%d,%d>> (+ acm_fused_tile on ragged tails)" % ((lv_txt,) + K2_GEOMETRY.get(args.level, (256, 8192)))
                                 if args.workload == "corpus" or 6 <= args.level <= 14 else "see DESIGN.md section 2 for level %s" % lv_txt),
