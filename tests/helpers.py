@@ -74,3 +74,37 @@ def decode_record(stream_cls_factory, data, force_chans=0, be=0, sgned=1, step=8
            "info": s.info(), "raw_tell_end": s.getter("raw_tell")}
     s.close()
     return rec
+
+
+def handmade_stream(level, rows, blocks, channels=1, rate=22050, seed=1):
+    """An ACM file written by hand (bits LSB first, as libacm_amd/csrc/acm_synth.c writes them; reader: decode.c:586-589 block
+    header, :491-502 column loop, :712-752 stream header): `blocks` = [(pwr, val, code)], every column of a block uses the one
+    filler `code` - 0 (no payload) or a linear width 3..16 (rows x code bits, random; keep code <= pwr + 1).  For files whose
+    bit rate is as uneven as one likes (the striped upload of acm_batch.cpp has to notice)."""
+    rng = np.random.default_rng([0xACE5, seed, level, rows])
+    acc, nbits, out = 0, 0, bytearray()
+
+    def put(v, n):
+        nonlocal acc, nbits
+        acc |= (int(v) & ((1 << n) - 1)) << nbits
+        nbits += n
+        while nbits >= 8:
+            out.append(acc & 0xFF)
+            acc >>= 8
+            nbits -= 8
+
+    cols = 1 << level
+    total = len(blocks) * rows * cols
+    for v, n in ((0x032897, 24), (1, 8), (total & 0xFFFF, 16), (total >> 16, 16), (channels, 16), (rate, 16), (level, 4), (rows, 12)):
+        put(v, n)
+    for pwr, val, code in blocks:
+        assert code == 0 or 3 <= code <= min(16, pwr + 1)
+        put(pwr, 4)
+        put(val, 16)
+        for _ in range(cols):
+            put(code, 5)
+            for v in rng.integers(0, 1 << code, size=rows) if code else ():
+                put(v, code)
+    if nbits:
+        put(0, 8 - nbits)
+    return bytes(out)
