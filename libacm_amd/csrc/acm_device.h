@@ -35,10 +35,6 @@ struct AcmTile {
  * of recomputing two halo rows; a workgroup walks a contiguous run of the tile table */
 #define ACM_TILE_FRESH   1u    /* nothing in front of this tile: the carries start from zero (stream row 0, or a lead-in) */
 #define ACM_TILE_DISCARD 2u    /* lead-in: run the passes to build the carries, store no PCM */
-#define ACM_TILE_NARROW_BIT 2
-#define ACM_TILE_NARROW_FRONT_BIT 3
-#define ACM_TILE_NARROW  (1u << ACM_TILE_NARROW_BIT)          /* acm_tile2 only: the tile's own rows can be read from the int8 plane */
-#define ACM_TILE_NARROW_FRONT (1u << ACM_TILE_NARROW_FRONT_BIT)   /* ... and so can the two rows in front of it (the warm-up of its first segment) */
 
 /* one tile of the lean kernel (acm_tile2): tile_rows consecutive rows of a stream decoded from its row 0, all of them
  * present and emitted.  Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH. */
@@ -48,15 +44,12 @@ struct AcmTile2 {
 	uint32_t hdr_blk;      /* blkhdr index of the block that holds tile row -2 (tile row 0 in a stream's first tile) */
 	uint32_t rowpos;       /* position of that row inside its block */
 	uint32_t magic;        /* ceil(2^32 / acm_rows); 0 for acm_rows == 1 */
-	uint32_t flags;        /* ACM_TILE_FRESH, ACM_TILE_NARROW, ACM_TILE_NARROW_FRONT */
+	uint32_t flags;        /* ACM_TILE_FRESH */
 };
 
-/* beside every AcmTile2 of a plan with an int8 plane (acm_pack_narrow): where the tile's rows are read from - byte offsets from
- * the int16 arena to (tile row -2, column 0) in the arena itself or in the int8 plane (same pitch) */
-struct AcmTile2Plane {
-	int64_t body;          /* the tile's own rows, and the warm-up rows of every segment but the first */
-	int64_t front;         /* the two rows in front of the tile, as the wave(s) holding segment 0 read them */
-};
+/* beside every AcmTile2 of a plan with an int8 plane (acm_pack_narrow): two bits per wave of the tile kernel's workgroup -
+ * bit 2w: the rows wave w owns are read from the int8 plane, bit 2w + 1: so are the two rows in front of them */
+typedef uint32_t AcmTile2Modes;
 
 /* resolved H1 patch for the stage-wise path: scratch[dst] = value */
 struct AcmDevPatch {
@@ -124,14 +117,15 @@ int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const Acm
 int acmk_tile2_rows(uint32_t level);                            /* rows per acm_tile2 tile, 0 if the level is not covered */
 int acmk_tile2_grid(uint32_t level, int cus);
 #define ACM_K2_SINK_BYTES 65536                               /* >= one tile of PCM: where lead-in tiles put theirs */
-int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Plane *d_planes,
+int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Modes *d_modes, const uint8_t *d_idx8,
 		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 /* which narrow build acm_tile2 has at this level: 1 = as fast on wide tiles as the int16-only build, 2 = about 3 % slower on them
  * (one copy of the first pass with a branch per row pair: three copies do not fit the register file), 0 = none */
 int acmk_tile2_narrow_form(uint32_t level);
-/* fills the int8 plane for every tile of the table and marks the tiles that may be read from it; d_count[0] += tiles narrow with
- * the two rows in front of them, d_count[1] += tiles narrow behind rows that are not */
-int acmk_launch_pack_narrow(uint32_t level, AcmTile2 *d_tiles, AcmTile2Plane *d_planes, uint32_t ntiles, const int16_t *d_idx, uint8_t *d_idx8,
+int acmk_tile2_waves(uint32_t level);                           /* waves per workgroup of the level's acm_tile2 build */
+/* fills the int8 plane for every tile of the table and writes the mode words; d_count[0] += waves narrow with the two rows in
+ * front of them, d_count[1] += waves narrow behind rows that are not (acmk_tile2_waves(level) waves per tile) */
+int acmk_launch_pack_narrow(uint32_t level, const AcmTile2 *d_tiles, AcmTile2Modes *d_modes, uint32_t ntiles, const int16_t *d_idx, uint8_t *d_idx8,
 			    uint32_t *d_count, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);

@@ -62,7 +62,7 @@ struct LevelGroup {
 	uint32_t ntiles = 0;
 	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
 	AcmTile2 *d_tiles2 = nullptr;   /* whole tiles of streams decoded from row 0: the lean kernel (acm_tile2) */
-	AcmTile2Plane *d_planes2 = nullptr;     /* beside them once an int8 plane is attached (acmhip_plan_attach_narrow) */
+	AcmTile2Modes *d_modes2 = nullptr;      /* beside them once an int8 plane is attached (acmhip_plan_attach_narrow) */
 	bool use_narrow = false;        /* ... and enough of the tiles are narrow for the narrow build of the kernel to pay */
 	uint32_t ntiles2 = 0;
 	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
@@ -388,7 +388,7 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	for (auto &g : plan->fused) {
 		(void)hipFree(g.d_tiles);
 		(void)hipFree(g.d_tiles2);
-		(void)hipFree(g.d_planes2);
+		(void)hipFree(g.d_modes2);
 		(void)hipFree(g.d_tiles_extra);
 	}
 	for (auto &g : plan->stagewise)
@@ -840,7 +840,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->fused) {
 		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
 		gi++;
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, g.use_narrow && d_idx == pl->narrow_src ? g.d_planes2 : nullptr,
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, g.use_narrow && d_idx == pl->narrow_src ? g.d_modes2 : nullptr, pl->d_idx8,
 					    d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
@@ -910,9 +910,9 @@ extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, 
 	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, ngroups * 2 * sizeof(uint32_t), st));
 	for (size_t k = 0; k < ngroups; k++) {
 		LevelGroup &g = pl->fused[k];
-		if (g.ntiles2 && !g.d_planes2)
-			HIPTRY(hipMalloc((void **)&g.d_planes2, (size_t)g.ntiles2 * sizeof(AcmTile2Plane)));
-		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.d_planes2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count + 2 * k, (void *)st));
+		if (g.ntiles2 && !g.d_modes2)
+			HIPTRY(hipMalloc((void **)&g.d_modes2, (size_t)g.ntiles2 * sizeof(AcmTile2Modes)));
+		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.d_modes2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count + 2 * k, (void *)st));
 	}
 	std::vector<uint32_t> count(ngroups * 2, 0);
 	HIPTRY(hipMemcpyAsync(count.data(), pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -924,16 +924,18 @@ extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, 
 	const char *force = getenv("ACM_NARROW");
 	for (size_t k = 0; k < ngroups; k++) {
 		LevelGroup &g = pl->fused[k];
+		/* the kernel decides wave by wave (acm_tile2): counted in waves, reported in tiles' worth of them */
+		const uint64_t nw = (uint64_t)std::max(1, acmk_tile2_waves(g.level)), waves = nw * g.ntiles2;
 		const uint64_t both = count[2 * k], narrow = both + count[2 * k + 1];
 		if (force)
 			g.use_narrow = atoi(force) != 0 && narrow > 0;
 		else if (acmk_tile2_narrow_form(g.level) == 1)
-			g.use_narrow = narrow * 50 >= g.ntiles2 && narrow > 0;
+			g.use_narrow = narrow * 50 >= waves && narrow > 0;
 		else
-			g.use_narrow = (both + narrow) * 3 >= 2ull * g.ntiles2 && narrow > 0;     /* a tile narrow only in its own rows counts half */
+			g.use_narrow = (both + narrow) * 3 >= 2ull * waves && narrow > 0;       /* a wave narrow only in its own rows counts half */
 		if (g.use_narrow) {
-			pl->stats.narrow_tiles += (uint32_t)narrow;
-			pl->stats.narrow_front_tiles += (uint32_t)both;
+			pl->stats.narrow_tiles += (uint32_t)(narrow / nw);
+			pl->stats.narrow_front_tiles += (uint32_t)(both / nw);
 		}
 	}
 	pl->narrow_src = d_idx;

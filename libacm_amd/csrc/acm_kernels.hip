@@ -1272,7 +1272,7 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	{
 		(load_one<B * BODY + U + Qs>(raw, base, base, vo, vo), ...);
 	}
-	/* flags: the tile record's; bit: ACM_TILE_NARROW's or ACM_TILE_NARROW_FRONT's number - set = the row pair was one load */
+	/* flags: the tile's mode word (AcmTile2Modes); bit: this wave's body / warm-up bit in it - set = the row pair is one load */
 	template <int B>
 	static __device__ __forceinline__ void load_second_row(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, const uint32_t flags,
 							       const uint32_t bit)
@@ -1314,20 +1314,20 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	}
 	template <int... Bs>
 	static __device__ __forceinline__ void load_bodies(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-							   const uint32_t voff_warm, const uint32_t flags, const uint32_t warm_bit,
+							   const uint32_t voff_warm, const uint32_t modes, const uint32_t warm_bit, const uint32_t body_bit,
 							   std::integer_sequence<int, Bs...>)
 	{
 		((load_first_row<Bs>(raw, base_warm, base_body, voff, voff_warm, std::make_integer_sequence<int, U>{}),
-		  load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, flags, Bs == 0 ? warm_bit : ACM_TILE_NARROW_BIT)), ...);
+		  load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, modes, Bs == 0 ? warm_bit : body_bit)), ...);
 	}
-	/* the warm-up body (the two rows in front of every segment) and the tile's own bodies choose their plane separately: a
-	 * tile whose own rows fit a byte may follow rows that do not (ACM_TILE_NARROW without ACM_TILE_NARROW_FRONT).
+	/* the warm-up body (the two rows in front of every segment) and the wave's own bodies choose their plane separately: rows
+	 * that fit a byte may follow rows that do not (bits warm_bit / body_bit of the tile's mode word).
 	 * Rows are asked for in address order */
 	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-						    const uint32_t voff_warm, const uint32_t flags, const uint32_t warm_bit)
+						    const uint32_t voff_warm, const uint32_t modes, const uint32_t warm_bit, const uint32_t body_bit)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
-		load_bodies(raw, base_warm, base_body, voff, voff_warm, flags, warm_bit, std::make_integer_sequence<int, NB + 1>{});
+		load_bodies(raw, base_warm, base_body, voff, voff_warm, modes, warm_bit, body_bit, std::make_integer_sequence<int, NB + 1>{});
 	}
 };
 
@@ -1354,8 +1354,8 @@ __device__ __forceinline__ void k2_wait()
  * with one copy that branches per body (FirstPass::compute) */
 template <class C, int WPS, int ABL, int NAR, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
-acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const AcmTile2Plane *__restrict__ planes,
-	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const AcmTile2Modes *__restrict__ modes,
+	  const uint8_t *__restrict__ idx8, const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
@@ -1410,38 +1410,40 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
-	/* Narrow tiles (the NAR build, launched when the plan has an int8 plane: acm_pack_narrow set ACM_TILE_NARROW in the records
-	 * of the tiles whose own rows fit a byte, ACM_TILE_NARROW_FRONT where the two rows in front fit as well, and wrote next
-	 * to every record where the tile's rows are to be read from: AcmTile2Plane, byte offsets from the int16 arena to
-	 * (tile row -2, column 0) in the plane to use - the int8 plane has the int16 arena's pitch, FirstPass2::load).
-	 * The warm-up rows are the tile's own, except for segment 0, whose two rows in front belong to the tile before: a narrow
-	 * tile behind rows that do not fit reads those from the int16 arena.  The choice must be wave-uniform: the wave(s) that
-	 * hold segment 0 read their warm-up rows wide - where a segment is less than a wave (levels 6..9) that is the first few
-	 * segments, whose own rows then come from HBM a second time, in 16 bits.  (Reading EVERY segment's warm-up rows wide
-	 * was measured: slower than a wide tile.)  All of it is scalar work, and little: every instruction here is an issue slot
-	 * of a kernel that has none to spare (a dozen more per tile cost the wide tiles 3 %) */
-	const bool seg0_wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid) < (uint32_t)(FP::TPS > 64 ? FP::TPS : 64);
-	const uint32_t warm_bit = seg0_wave ? ACM_TILE_NARROW_FRONT_BIT : ACM_TILE_NARROW_BIT;
-	auto body_narrow = [&](const AcmTile2 &r) -> bool { return NAR && (r.flags & ACM_TILE_NARROW) != 0; };
-	auto warm_narrow = [&](const AcmTile2 &r) -> bool { return NAR && ((r.flags >> warm_bit) & 1u) != 0; };
+	/* Narrow rows (the NAR build, launched when the plan has an int8 plane: acm_pack_narrow wrote a mode word beside every
+	 * record, two bits per WAVE of this workgroup - bit 2w: the rows wave w owns fit a byte and are read from the int8 plane,
+	 * bit 2w + 1: so are the two rows in front of them, which the wave's first segment re-reads as its warm-up (the last two
+	 * of the wave before, or of the tile before).  The int8 plane has the int16 arena's pitch: a tile's place in it is its
+	 * place in the arena + (idx8 - idx), FirstPass2::load).  A wave is the unit because the choice must be wave-uniform;
+	 * per wave rather than per tile, because at the lower levels a tile is several blocks of the stream (level 7, 16 rows
+	 * per block: a wave's rows are exactly one block) and a block's indices are narrow or not as a whole.
+	 * Narrow rows behind rows that are not: the wave reads its warm-up rows from the int16 arena - every segment's, so
+	 * those of its later segments come from HBM a second time, in 16 bits; acm_pack_narrow allows that for waves of at most
+	 * two segments (level 9 on; with more the wave stays wide).  Reading EVERY warm-up row of a tile wide was measured:
+	 * slower than a wide tile.  All of it is scalar work, and little: every instruction here is an issue slot of a kernel
+	 * that has none to spare (a dozen more per tile cost the wide tiles 3 %) */
+	const uint32_t body_bit = 2u * (((uint32_t)__builtin_amdgcn_readfirstlane(tid) >> 6) & 15u), warm_bit = body_bit + 1u;
+	auto body_narrow = [&](const uint32_t m) -> bool { return NAR && ((m >> body_bit) & 1u) != 0; };
+	auto warm_narrow = [&](const uint32_t m) -> bool { return NAR && ((m >> warm_bit) & 1u) != 0; };
 	auto sgpr_ptr = [&](const uint64_t a) -> const uint8_t * {
 		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
 		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
 		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
 	};
-	auto fetch_plane = [&](const uint32_t k) -> AcmTile2Plane {
+	auto fetch_modes = [&](const uint32_t k) -> uint32_t {
 		if constexpr (NAR)
-			return planes[__builtin_amdgcn_readfirstlane(k)];
+			return modes[__builtin_amdgcn_readfirstlane(k)];
 		else
-			return AcmTile2Plane{ 0, 0 };
+			return 0u;
 	};
-	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r, const AcmTile2Plane &p) {
+	const uint64_t to8 = NAR ? reinterpret_cast<uint64_t>(idx8) - reinterpret_cast<uint64_t>(idx) : 0;
+	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r, const uint32_t m) {
+		const uint64_t a = reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
 		if constexpr (NAR) {
-			const uint64_t a = reinterpret_cast<uint64_t>(idx);
-			FP::load(raw, sgpr_ptr(a + (uint64_t)(seg0_wave ? p.front : p.body)), sgpr_ptr(a + (uint64_t)p.body), voff, warm_off(r), r.flags, warm_bit);
+			FP::load(raw, sgpr_ptr(a + (warm_narrow(m) ? to8 : 0)), sgpr_ptr(a + (body_narrow(m) ? to8 : 0)), voff, warm_off(r), m, warm_bit, body_bit);
 		} else {
-			const uint8_t *const base = sgpr_ptr(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS));
-			FP::load(raw, base, base, voff, warm_off(r), 0u, 0u);
+			const uint8_t *const base = sgpr_ptr(a);
+			FP::load(raw, base, base, voff, warm_off(r), 0u, 0u, 0u);
 		}
 	};
 
@@ -1452,7 +1454,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
 	uint32_t raw[FP::NRAW];
 	uint32_t hv = fetch_val(cur);
-	load_tile(raw, cur, fetch_plane(t));
+	uint32_t mcur = fetch_modes(t);
+	load_tile(raw, cur, mcur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1464,7 +1467,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records come through the scalar cache one iteration ahead (asked for behind the PCM stores, used after the
 	 * next first pass); the last tile of a run names itself as its successor */
 	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
-	AcmTile2Plane pnxt = fetch_plane(t + 1 < t_end ? t + 1 : t);
+	uint32_t mnxt = fetch_modes(t + 1 < t_end ? t + 1 : t);
 	for (;;) {
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
@@ -1478,10 +1481,10 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
 		if constexpr (NAR == 2)
-			FP::template compute<true, 3>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, warm_narrow(cur), body_narrow(cur));
-		else if (!body_narrow(cur))
+			FP::template compute<true, 3>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, warm_narrow(mcur), body_narrow(mcur));
+		else if (!body_narrow(mcur))
 			FP::template compute<true, 0>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
-		else if (warm_narrow(cur))
+		else if (warm_narrow(mcur))
 			FP::template compute<true, 1>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
 		else
 			FP::template compute<true, 2>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
@@ -1492,7 +1495,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(2);
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
-		load_tile(raw, nxt, pnxt);
+		load_tile(raw, nxt, mnxt);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
@@ -1530,7 +1533,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		cur = nxt;
 		t = tn;
 		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
-		pnxt = fetch_plane(t + 1 < t_end ? t + 1 : t);
+		mcur = mnxt;
+		mnxt = fetch_modes(t + 1 < t_end ? t + 1 : t);
 		buf ^= 1;
 	}
 #ifdef ACM_STAMPS
@@ -1541,25 +1545,34 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 }
 
 struct Tile2Entry {
-	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const AcmTile2Plane *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const AcmTile2Modes *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *,
+			   unsigned);
 	Fn fn;                  /* int16 arena only */
 	Fn fn_narrow;           /* the build that reads marked tiles from the int8 plane (a dozen more scalar instructions per tile) */
 	int threads, tile_rows, wg_per_cu;
 	int narrow_form;        /* acm_tile2's NAR of fn_narrow */
+	int tps, rps;           /* first pass: threads and rows per segment (acm_pack_narrow works out which rows a wave owns) */
 };
+template <int G0, int...>
+constexpr int first_group() { return G0; }
 /* NARFORM: which narrow build (acm_tile2's NAR) fits 128 registers at this geometry */
 template <class C, int NARFORM, int... Gs>
-constexpr Tile2Entry entry_k2() { return Tile2Entry{ acm_tile2<C, 4, 0, 0, Gs...>, acm_tile2<C, 4, 0, NARFORM, Gs...>, C::NT, C::TR, 1024 / C::NT, NARFORM }; }
+constexpr Tile2Entry entry_k2()
+{
+	return Tile2Entry{ acm_tile2<C, 4, 0, 0, Gs...>, acm_tile2<C, 4, 0, NARFORM, Gs...>, C::NT, C::TR, 1024 / C::NT, NARFORM,
+			   FirstPass2<C, first_group<Gs...>(), 2>::FP::TPS, FirstPass2<C, first_group<Gs...>(), 2>::FP::RPS };
+}
 /* bigger tiles: WPC workgroups per CU */
 template <class C, int WPC, int NARFORM, int... Gs>
 constexpr Tile2Entry entry_k2w()
 {
-	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, 0, Gs...>, acm_tile2<C, WPC * C::NT / 256, 0, NARFORM, Gs...>, C::NT, C::TR, WPC, NARFORM };
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, 0, Gs...>, acm_tile2<C, WPC * C::NT / 256, 0, NARFORM, Gs...>, C::NT, C::TR, WPC, NARFORM,
+			   FirstPass2<C, first_group<Gs...>(), 2>::FP::TPS, FirstPass2<C, first_group<Gs...>(), 2>::FP::RPS };
 }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 0, 3, 3, 3>, nullptr, 256, 16, 4, 0 }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 0, 3, 3, 3>, nullptr, 256, 16, 4, 0, 32, 2 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
@@ -1764,7 +1777,7 @@ extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 	return (cus > 0 ? cus : 256) * tile2_entry(level).wg_per_cu;
 }
 
-extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Plane *d_planes,
+extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Modes *d_modes, const uint8_t *d_idx8,
 				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
@@ -1783,64 +1796,91 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(d_planes && e.fn_narrow ? e.fn_narrow : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx,
-			   d_planes, d_hdr, d_pcm, d_sink, fmt);
+	const bool narrow = d_modes && d_idx8 && e.fn_narrow;
+	hipLaunchKernelGGL(narrow ? e.fn_narrow : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx,
+			   narrow ? d_modes : nullptr, narrow ? d_idx8 : nullptr, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
 
 /*
- * The narrow staged form of a tile table: every tile's indices as int8 in the plane the lean kernel reads narrow tiles from (the
+ * The narrow staged form of a tile table: every tile's indices as int8 in the plane the lean kernel reads narrow rows from (the
  * 2 x 2 block of rows 2p, 2p + 1 x columns 2j, 2j + 1 at the byte offset of (row 2p, column 2j) in the int16 plane: same pitch,
- * every other row's worth of bytes unused), ACM_TILE_NARROW in the record of every tile whose own rows fit a byte, and
- * ACM_TILE_NARROW_FRONT where the two rows in front of it (which segment 0 re-reads as its warm-up) do too.  One workgroup
- * per tile; a thread turns 2 rows x 8 columns (two 16-byte reads) into 16 bytes.  count[0] += tiles narrow in both respects,
- * count[1] += tiles with narrow rows of their own behind rows that are not.
+ * every other row's worth of bytes unused), and beside every record its mode word (AcmTile2Modes: per wave of the tile
+ * kernel's workgroup, do the rows it owns fit a byte, and do the two rows in front of them).  One workgroup per tile; a thread
+ * turns 2 rows x 8 columns (two 16-byte reads) into 16 bytes.  count[0] += waves narrow in both respects, count[1] += waves
+ * with narrow rows of their own behind rows that are not (over all tiles).
  */
 namespace {
 __global__ void __launch_bounds__(256)
-acm_pack_narrow(AcmTile2 *__restrict__ tiles, AcmTile2Plane *__restrict__ planes, const uint32_t ntiles, const uint32_t level, const uint32_t tile_rows,
-		const int16_t *__restrict__ idx, uint8_t *__restrict__ idx8, uint32_t *__restrict__ count)
+acm_pack_narrow(const AcmTile2 *__restrict__ tiles, AcmTile2Modes *__restrict__ modes, const uint32_t ntiles, const uint32_t level,
+		const uint32_t tile_rows, const uint32_t nwaves, const uint32_t tps, const uint32_t rps, const int16_t *__restrict__ idx,
+		uint8_t *__restrict__ idx8, uint32_t *__restrict__ count)
 {
+	__shared__ uint32_t wide_pair[65];              /* [p + 1]: row pair p of the tile has an index that needs 16 bits; [0]: the pair in front */
+	__shared__ uint32_t mode_word;
 	const uint32_t t = blockIdx.x;
 	if (t >= ntiles)
 		return;
 	const AcmTile2 r = tiles[t];
-	const uint32_t cols = 1u << level, per_row = cols / 8, units = (tile_rows / 2) * per_row;
+	const uint32_t cols = 1u << level, per_row = cols / 8, npairs = tile_rows / 2, units = npairs * per_row;
 	const uint4 *src = reinterpret_cast<const uint4 *>(idx + r.idx_off);          /* stream offsets are multiples of 8 indices */
 	uint4 *dst = reinterpret_cast<uint4 *>(idx8 + 2 * r.idx_off);      /* row pair p at the offset of row 2p: the pitch of the int16 plane */
-	uint32_t wide = 0, wide_front = 0;
+	if (threadIdx.x <= npairs)
+		wide_pair[threadIdx.x] = 0u;
+	if (threadIdx.x == 0)
+		mode_word = 0u;
+	__syncthreads();
 	auto look = [&](uint32_t &acc, const uint32_t w) {
 		acc |= (uint32_t)((int32_t)(int16_t)w + 128) | (uint32_t)(((int32_t)w >> 16) + 128);    /* 0..255 <=> fits */
-	};
-	auto pack = [&](const uint32_t w0, const uint32_t w1) -> uint32_t {
-		look(wide, w0);
-		look(wide, w1);
-		return (w0 & 0xFFu) | ((w0 >> 8) & 0xFF00u) | ((w1 & 0xFFu) << 16) | ((w1 << 8) & 0xFF000000u);
 	};
 	for (uint32_t u = threadIdx.x; u < units; u += 256) {
 		const uint32_t p = u / per_row, j = u % per_row;
 		const uint4 a = src[(2 * p) * per_row + j], b = src[(2 * p + 1) * per_row + j];
+		uint32_t wide = 0;
+		auto pack = [&](const uint32_t w0, const uint32_t w1) -> uint32_t {
+			look(wide, w0);
+			look(wide, w1);
+			return (w0 & 0xFFu) | ((w0 >> 8) & 0xFF00u) | ((w1 & 0xFFu) << 16) | ((w1 << 8) & 0xFF000000u);
+		};
 		dst[(2 * p) * per_row + j] = make_uint4(pack(a.x, b.x), pack(a.y, b.y), pack(a.z, b.z), pack(a.w, b.w));
+		if (wide & ~0xFFu)
+			atomicOr(&wide_pair[p + 1], 1u);
 	}
 	if (!(r.flags & ACM_TILE_FRESH))
 		for (uint32_t u = threadIdx.x; u < 2 * per_row; u += 256) {
 			const uint4 a = *(src - 2 * per_row + u);                   /* the two rows in front: the previous tile packs them */
-			look(wide_front, a.x);
-			look(wide_front, a.y);
-			look(wide_front, a.z);
-			look(wide_front, a.w);
+			uint32_t wide = 0;
+			look(wide, a.x);
+			look(wide, a.y);
+			look(wide, a.z);
+			look(wide, a.w);
+			if (wide & ~0xFFu)
+				atomicOr(&wide_pair[0], 1u);
 		}
-	const int any_wide_front = __syncthreads_or((wide_front & ~0xFFu) != 0);
-	const int any_wide = __syncthreads_or((wide & ~0xFFu) != 0);
+	__syncthreads();
+	if (threadIdx.x < nwaves) {
+		/* the rows wave w of the tile kernel owns: those of the first-pass segments its lanes belong to */
+		const uint32_t w = threadIdx.x, first_seg = w * 64u / tps, last_seg = ((w + 1u) * 64u - 1u) / tps;
+		const uint32_t p_lo = first_seg * rps / 2u, p_hi = (last_seg + 1u) * rps / 2u;
+		bool body = true;
+		for (uint32_t p = p_lo; p < p_hi; p++)
+			body = body && wide_pair[p + 1] == 0u;
+		const bool front = wide_pair[p_lo] == 0u;               /* the pair in front of the wave's rows ([0]: in front of the tile) */
+		/* narrow rows behind wide ones: the wave reads ALL its warm-up rows wide - worth it for at most two segments per wave */
+		const bool narrow = body && (front || last_seg - first_seg < 2u);
+		if (narrow)
+			atomicOr(&mode_word, (front ? 3u : 1u) << (2u * (w & 15u)));
+	}
+	__syncthreads();
 	if (threadIdx.x == 0) {
-		tiles[t].flags = (r.flags & ~(ACM_TILE_NARROW | ACM_TILE_NARROW_FRONT)) | (any_wide ? 0u : ACM_TILE_NARROW) |
-				 (any_wide || any_wide_front ? 0u : ACM_TILE_NARROW_FRONT);
-		if (!any_wide)
-			atomicAdd(&count[any_wide_front ? 1 : 0], 1u);
-		const int64_t at = 2 * ((int64_t)r.idx_off - 2 * (int64_t)cols);         /* (tile row -2, column 0), bytes, in either plane */
-		const int64_t to8 = reinterpret_cast<const uint8_t *>(idx8) - reinterpret_cast<const uint8_t *>(idx);
-		planes[t] = AcmTile2Plane{ at + (any_wide ? 0 : to8), at + (any_wide || any_wide_front ? 0 : to8) };
+		const uint32_t m = mode_word;
+		modes[t] = m;
+		const uint32_t both = (uint32_t)__popc(m & 0xAAAAAAAAu), body = (uint32_t)__popc(m & 0x55555555u);
+		if (both)
+			atomicAdd(&count[0], both);
+		if (body - both)
+			atomicAdd(&count[1], body - both);
 	}
 }
 }
@@ -1852,15 +1892,25 @@ extern "C" int acmk_tile2_narrow_form(uint32_t level)
 	return tile2_entry(level).narrow_form;
 }
 
-extern "C" int acmk_launch_pack_narrow(uint32_t level, AcmTile2 *d_tiles, AcmTile2Plane *d_planes, uint32_t ntiles, const int16_t *d_idx,
+extern "C" int acmk_tile2_waves(uint32_t level)
+{
+	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
+		return 0;
+	return tile2_entry(level).threads / 64;
+}
+
+extern "C" int acmk_launch_pack_narrow(uint32_t level, const AcmTile2 *d_tiles, AcmTile2Modes *d_modes, uint32_t ntiles, const int16_t *d_idx,
 				       uint8_t *d_idx8, uint32_t *d_count, void *stream)
 {
 	if (ntiles == 0)
 		return 0;
 	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
 		return -1;
-	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, d_planes, ntiles, level,
-			   (uint32_t)tile2_entry(level).tile_rows, d_idx, d_idx8, d_count);
+	const Tile2Entry &e = tile2_entry(level);
+	if (e.tile_rows > 128 || e.threads > 1024)
+		return -1;
+	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, d_modes, ntiles, level,
+			   (uint32_t)e.tile_rows, (uint32_t)e.threads / 64u, (uint32_t)e.tps, (uint32_t)e.rps, d_idx, d_idx8, d_count);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
