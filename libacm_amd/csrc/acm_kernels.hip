@@ -1341,7 +1341,13 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
  * The loaded registers are first read in the NEXT iteration, behind that wait and a barrier.  What the compiler must
  * not do is copy or spill such a register between its load and the wait (it would copy the old content);
  * tests/test_isa_invariants.py checks the generated code for that.
+ * The counted wait relies on what gfx9 / CDNA guarantee: the vector memory operations of a wave return (and decrement vmcnt)
+ * in the order they were issued, loads and stores alike.  Targets with separate load and store counters or out-of-order
+ * returns (gfx10 on) need another wait; this file is written for gfx950 and refuses anything else.
  */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "acm_kernels.hip: gfx950 (MI355X) only - the hand-counted s_waitcnt vmcnt(N) of acm_tile2 assumes in-order vector memory returns"
+#endif
 
 template <int YOUNGER>
 __device__ __forceinline__ void k2_wait()
