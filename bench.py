@@ -763,6 +763,12 @@ def main():
                 out["cpu_baseline"] = {"error": str(e)[:200]}
 
     if rank == 0:
+        # RCCL announces its version through C stdio when the first communicator comes up; that text sits in libc's buffer until
+        # the process ends and would land BEHIND the line below - push it out first, so that the JSON line is the last line
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
     plan.destroy()
