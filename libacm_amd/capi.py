@@ -262,7 +262,7 @@ class Plan:
         _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
 
     def attach_narrow(self, d_idx):
-        """int8 copy of the lean kernel's tiles of the staged arena d_idx (None detaches) -> number of narrow tiles"""
+        """int8 copy of the lean kernel's tiles of the staged arena d_idx (None detaches) -> tiles' worth of rows that will be read from it"""
         n = C.c_uint64()
         _check(lib().acmhip_plan_attach_narrow(self.h, d_idx, C.byref(n)), "acmhip_plan_attach_narrow")
         return n.value

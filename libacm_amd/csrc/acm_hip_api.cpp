@@ -919,8 +919,8 @@ extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, 
 	HIPTRY(hipStreamSynchronize(st));
 	/* Does the narrow build of the kernel pay for this group?  Where it is as fast as the int16-only build on wide tiles
 	 * (three copies of the first pass: levels 6-9 and 13) as soon as a few tiles are narrow; where it is ~3 % slower on
-	 * them (levels 10-12 and 14, a narrow tile there is ~8 % faster) from a third of the tiles on.  ACM_NARROW=1 / 0
-	 * forces it on for every group with a narrow tile / off (measurements) */
+	 * them (levels 10-12 and 14, narrow rows there are ~8 % faster) from a third of the waves on.  ACM_NARROW=1 / 0
+	 * forces it on for every group with a narrow wave / off (measurements) */
 	const char *force = getenv("ACM_NARROW");
 	for (size_t k = 0; k < ngroups; k++) {
 		LevelGroup &g = pl->fused[k];

@@ -419,7 +419,7 @@ __device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t
 #undef ACM_SDWA_MUL
 }
 
-/* narrow tiles: one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1), (row + 1, col),
+/* narrow rows (acm_tile2's int8 plane): one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1), (row + 1, col),
  * (row + 1, col + 1) - and SDWA picks and sign-extends the byte inside the multiply, as it does with the 16-bit words */
 __device__ __forceinline__ void mul_idx8_val(const uint32_t r, const int32_t val0, const int32_t val1, uint32_t &r0c0, uint32_t &r0c1,
 					     uint32_t &r1c0, uint32_t &r1c1)
@@ -699,9 +699,9 @@ struct FirstPass {
 	}
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
-	/* NARROW (acm_tile2's narrow tiles): 0 = 16-bit indices, 1 = the row pairs are 2 x 2 byte blocks, 2 = the warm-up body
+	/* NARROW (acm_tile2's narrow rows): 0 = 16-bit indices, 1 = the row pairs are 2 x 2 byte blocks, 2 = the warm-up body
 	 * is 16-bit, the tile's own bodies are byte blocks, 3 = whatever narrow_warm / narrow_body say at run time.
-	 * acm_tile2 picks one of three compile-time instantiations per tile where that fits the register file: with the unpack
+	 * acm_tile2 picks one of three compile-time instantiations per tile and wave where that fits the register file: with the unpack
 	 * behind a run-time branch per body the first pass of a WIDE tile is 3 % slower (the scheduler no longer interleaves
 	 * unpack and butterflies) */
 	template <bool CARRY = false, int NARROW = 0>
@@ -736,7 +736,7 @@ struct FirstPass {
 					for (int u = 0; u < BODY; u++)
 						v[w][u] = raw[w * NRAW + (b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
 			} else if (W == 2 && !PLANE && (NARROW == 3 ? (b < 0 ? narrow_warm : narrow_body) : (b < 0 ? NARROW == 1 : NARROW >= 1))) {
-				/* narrow tile (wave-uniform): register (body, q) = int8 indices of this lane's two columns in both rows of the body */
+				/* narrow rows (wave-uniform): register (body, q) = int8 indices of this lane's two columns in both rows of the body */
 #pragma unroll
 				for (int q = 0; q < U; q++)
 					mul_idx8_val(raw[(b + (WARM ? 1 : 0)) * BODY + q], v0, v1, v[0][q], v[W - 1][q], v[0][U + q], v[W - 1][U + q]);
@@ -1258,7 +1258,7 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 		else
 			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
-	/* Narrow tiles (ACM_TILE_NARROW): the indices of the tile and of the two rows in front of it fit a byte and sit in the
+	/* Narrow rows (acm_tile2's mode word says which, wave by wave): their indices fit a byte and sit in the
 	 * int8 plane in 2 x 2 blocks - the dword at the byte offset the int16 plane has for (row 2p, columns 2j, 2j + 1) holds
 	 * rows 2p, 2p + 1 x columns 2j, 2j + 1 - so the load of a body's FIRST row, from the other base, brings both rows, and
 	 * the loads of its second row are skipped: half the loads, half the bytes, the same instructions.
@@ -1356,7 +1356,7 @@ __device__ __forceinline__ void k2_wait()
 	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
 }
 
-/* NAR: 0 = int16 arena only; 1, 2 = the build for plans with an int8 plane (narrow tiles), with three copies of the first pass /
+/* NAR: 0 = int16 arena only; 1, 2 = the build for plans with an int8 plane (narrow rows), with three copies of the first pass /
  * with one copy that branches per body (FirstPass::compute) */
 template <class C, int WPS, int ABL, int NAR, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
@@ -1554,7 +1554,7 @@ struct Tile2Entry {
 	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const AcmTile2Modes *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *,
 			   unsigned);
 	Fn fn;                  /* int16 arena only */
-	Fn fn_narrow;           /* the build that reads marked tiles from the int8 plane (a dozen more scalar instructions per tile) */
+	Fn fn_narrow;           /* the build that reads the rows the mode words mark from the int8 plane (a dozen more scalar instructions per tile) */
 	int threads, tile_rows, wg_per_cu;
 	int narrow_form;        /* acm_tile2's NAR of fn_narrow */
 	int tps, rps;           /* first pass: threads and rows per segment (acm_pack_narrow works out which rows a wave owns) */
