@@ -228,6 +228,8 @@ typedef struct acm_batch_opts {
 	                            d_pcm_words 16-bit words (>= acm_batch_pcm_words()): PCM stays in HBM, stream i at
 	                            d_pcm + items[i].dev_off, nothing is copied back (items[i].pcm is ignored) */
 	uint64_t d_pcm_words;
+	const struct acm_batch_prestaged *prestaged;    /* NULL, or what acm_batch_prestage made of these very items: the bit
+	                                                   parsing is done already (forces ACM_BATCH_PARSE_HOST semantics) */
 } acm_batch_opts;
 
 /* opts->flags */
@@ -257,6 +259,17 @@ typedef struct acm_batch_timing {
 
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,
 		      const acm_batch_opts *opts, acm_batch_timing *timing);
+
+/*
+ * The host half of acm_batch_decode ahead of time, WITHOUT a device: bit-parses the items' files into staged form
+ * (host thread pool, opts->threads / force_chans as above) kept in memory this call allocates.  A later
+ * acm_batch_decode on the same items with opts->prestaged = *out copies that into its upload arenas instead of
+ * parsing - a front end can parse the next groups of files while the device works on the current one, or while the
+ * HIP runtime is still coming up (libacm_amd/csrc/acmtool.c -B).  *seconds (may be NULL): wall clock of the parsing.
+ */
+typedef struct acm_batch_prestaged acm_batch_prestaged;
+int  acm_batch_prestage(const acm_batch_item *items, size_t n, const acm_batch_opts *opts, acm_batch_prestaged **out, double *seconds);
+void acm_batch_prestage_free(acm_batch_prestaged *p);
 
 /* Optional, for applications that know they are about to decode through the libacm.h calls (acmtool -d): start opening
  * the process-wide default device - HIP runtime, device handle, the kernels' code object - on a thread of the library's

@@ -53,7 +53,8 @@ class BatchItem(C.Structure):
 
 class BatchOpts(C.Structure):
     _fields_ = [("force_chans", C.c_int), ("fmt", C.c_uint), ("threads", C.c_int), ("plan_flags", C.c_uint),
-                ("parse", C.c_uint), ("flags", C.c_uint), ("d_pcm", C.c_void_p), ("d_pcm_words", C.c_uint64)]
+                ("parse", C.c_uint), ("flags", C.c_uint), ("d_pcm", C.c_void_p), ("d_pcm_words", C.c_uint64),
+                ("prestaged", C.c_void_p)]
 
 
 class BatchTiming(C.Structure):
@@ -68,7 +69,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_attach_narrow", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
-    "acm_batch_decode", "acm_batch_pcm_words", "acmhip_prewarm",
+    "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -124,6 +125,9 @@ def lib():
     L.acm_batch_decode.argtypes = [vp, C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(BatchTiming)]
     L.acm_batch_pcm_words.argtypes = [C.POINTER(BatchItem), sz, C.c_int]
     L.acm_batch_pcm_words.restype = C.c_uint64
+    L.acm_batch_prestage.argtypes = [C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(vp), C.POINTER(C.c_double)]
+    L.acm_batch_prestage_free.argtypes = [vp]
+    L.acm_batch_prestage_free.restype = None
     _lib = L
     return L
 
@@ -362,11 +366,12 @@ PARSE_HOST, PARSE_DEVICE, PARSE_AUTO = 0, 1, 2
 BATCH_PCM_PINNED = 1
 
 
-def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST, pinned=False):
+def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST, pinned=False, prestage=False):
     """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming).
 
     pinned=True: the output buffers are carved from one pinned arena (acmhip_host_alloc) and the call is told so
-    (ACM_BATCH_PCM_PINNED: the read-back engine writes them directly); the arrays returned are copies."""
+    (ACM_BATCH_PCM_PINNED: the read-back engine writes them directly); the arrays returned are copies.
+    prestage=True: the bit parsing runs first, on its own (acm_batch_prestage: no device involved), and the decode gets its result."""
     n = len(files)
     bufs = [_as_u8(f) for f in files]
     infos = [probe(b, force_chans) for b in bufs]
@@ -395,10 +400,16 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
         items[k].pcm_cap = outs[k].size
     opts = BatchOpts(force_chans, fmt, threads, flags, parse, BATCH_PCM_PINNED if pinned else 0)
     tm = BatchTiming()
+    pre = C.c_void_p()
     try:
+        if prestage:
+            _check(lib().acm_batch_prestage(items, n, C.byref(opts), C.byref(pre), None), "acm_batch_prestage")
+            opts.prestaged = pre
         _check(lib().acm_batch_decode(dev.h, items, n, C.byref(opts), C.byref(tm)), "acm_batch_decode")
         res = [(items[k].status, outs[k][:items[k].words].copy() if pinned else outs[k][:items[k].words]) for k in range(n)]
     finally:
+        if pre:
+            lib().acm_batch_prestage_free(pre)
         if pinned:
             del outs, whole
             lib().acmhip_host_free(arena)

@@ -199,6 +199,150 @@ struct ParseGroup {
 
 } // namespace
 
+/* what acm_batch_prestage keeps: per item the header, the status, the staged blocks (one allocation for all items, laid out
+ * like the batch's own arenas) and the H1 patches */
+struct acm_batch_prestaged {
+	struct Item {
+		acm_stage_info info{};
+		uint64_t need_blocks = 0, idx_off = 0, hdr_off = 0;
+		std::vector<acmhip_patch> patches;
+		int status = 0;
+		bool ok = false;
+	};
+	std::vector<Item> items;
+	std::vector<const uint8_t *> data;      /* the file images the items pointed at (identity check in acm_batch_decode) */
+	int16_t *idx = nullptr;
+	acmhip_blkhdr *hdr = nullptr;
+	size_t idx_cap = 0, hdr_cap = 0;        /* bytes */
+	int force_chans = 0;
+};
+
+namespace {
+/* Staging buffers of prestaged groups are a hundred megabytes each and live for milliseconds: handing them back to the C
+ * library means an munmap (10 ms for 200 MB of touched pages, on the thread that feeds the device) and a fresh set of page
+ * faults for the next group.  A few of them are kept here instead and handed out again, best fit. */
+struct StageCache {
+	struct Buf {
+		void *mem;
+		size_t cap;
+	};
+	std::mutex m;
+	std::vector<Buf> bufs;
+	size_t bytes = 0;
+	static constexpr size_t MAX_BUFS = 8, MAX_BYTES = (size_t)1 << 30;
+
+	void *get(size_t want, size_t *cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(m);
+			size_t best = bufs.size();
+			for (size_t k = 0; k < bufs.size(); k++)
+				if (bufs[k].cap >= want && (best == bufs.size() || bufs[k].cap < bufs[best].cap))
+					best = k;
+			if (best != bufs.size() && bufs[best].cap <= 2 * want + (1u << 20)) {
+				const Buf b = bufs[best];
+				bufs.erase(bufs.begin() + (long)best);
+				bytes -= b.cap;
+				*cap = b.cap;
+				return b.mem;
+			}
+		}
+		*cap = want;
+		return malloc(want);
+	}
+	void put(void *mem, size_t cap)
+	{
+		if (!mem)
+			return;
+		{
+			std::lock_guard<std::mutex> g(m);
+			if (bufs.size() < MAX_BUFS && bytes + cap <= MAX_BYTES) {
+				bufs.push_back(Buf{ mem, cap });
+				bytes += cap;
+				return;
+			}
+		}
+		free(mem);
+	}
+};
+StageCache g_stage_cache;
+}
+
+extern "C" void acm_batch_prestage_free(acm_batch_prestaged *p)
+{
+	if (!p)
+		return;
+	g_stage_cache.put(p->idx, p->idx_cap);
+	g_stage_cache.put(p->hdr, p->hdr_cap);
+	delete p;
+}
+
+extern "C" int acm_batch_prestage(const acm_batch_item *items, size_t n, const acm_batch_opts *opts_in, acm_batch_prestaged **out, double *seconds)
+{
+	if (!out || (n && !items))
+		return ACMHIP_ERR_ARG;
+	*out = nullptr;
+	const auto t0 = clk::now();
+	acm_batch_opts opts{};
+	if (opts_in)
+		opts = *opts_in;
+	acm_batch_prestaged *p = new (std::nothrow) acm_batch_prestaged;
+	if (!p)
+		return ACMHIP_ERR_NOMEM;
+	p->items.resize(n);
+	p->data.resize(n);
+	p->force_chans = opts.force_chans;
+	const int threads_wanted = opts.threads > 0 ? opts.threads : default_threads();
+	Pool pool((int)std::min<size_t>((size_t)threads_wanted, std::max<size_t>(1, n)));
+	pool.run(n, [&](size_t i) {
+		acm_batch_prestaged::Item &s = p->items[i];
+		p->data[i] = items[i].data;
+		s.status = acm_stage_probe(items[i].data, items[i].len, opts.force_chans, &s.info);
+		s.ok = s.status == ACM_OK;
+		if (s.ok)
+			s.need_blocks = blocks_possible(s.info, items[i].len);
+	});
+	uint64_t idx_total = 0, hdr_total = 0;
+	for (acm_batch_prestaged::Item &s : p->items) {
+		if (!s.ok)
+			continue;
+		s.idx_off = idx_total;
+		s.hdr_off = hdr_total;
+		idx_total += round_up(s.need_blocks * (uint64_t)s.info.rows * s.info.cols, 64);
+		hdr_total += s.need_blocks;
+	}
+	p->idx = static_cast<int16_t *>(g_stage_cache.get(std::max<uint64_t>(idx_total, 1) * sizeof(int16_t), &p->idx_cap));
+	p->hdr = static_cast<acmhip_blkhdr *>(g_stage_cache.get(std::max<uint64_t>(hdr_total, 1) * sizeof(acmhip_blkhdr), &p->hdr_cap));
+	if (!p->idx || !p->hdr) {
+		acm_batch_prestage_free(p);
+		return ACMHIP_ERR_NOMEM;
+	}
+	pool.run(n, [&](size_t i) {
+		acm_batch_prestaged::Item &s = p->items[i];
+		if (!s.ok)
+			return;
+		acm_stage_info info{};
+		/* first pass counts patches (normally zero), second only if there are any */
+		int r = acm_stage_file(items[i].data, items[i].len, opts.force_chans, p->idx + s.idx_off, p->hdr + s.hdr_off, s.need_blocks, nullptr, 0, &info);
+		if (r == ACM_OK && info.npatches) {
+			s.patches.resize(info.npatches);
+			r = acm_stage_file(items[i].data, items[i].len, opts.force_chans, p->idx + s.idx_off, p->hdr + s.hdr_off, s.need_blocks,
+					   s.patches.data(), s.patches.size(), &info);
+		}
+		if (r != ACM_OK) {
+			s.status = r;
+			s.ok = false;
+			return;
+		}
+		s.info = info;
+		s.status = info.end_status;
+	});
+	if (seconds)
+		*seconds = secs(t0, clk::now());
+	*out = p;
+	return ACMHIP_OK;
+}
+
 extern "C" uint64_t acm_batch_pcm_words(const acm_batch_item *items, size_t n, int force_chans)
 {
 	uint64_t total = 0;
@@ -222,6 +366,16 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		opts = *opts_in;
 	if (opts.fmt > 3 || opts.parse > ACM_BATCH_PARSE_AUTO)
 		return ACMHIP_ERR_ARG;
+	/* parsed ahead of time (acm_batch_prestage): must be these very items */
+	const acm_batch_prestaged *pre = opts.prestaged;
+	if (pre) {
+		if (pre->items.size() != n || pre->force_chans != opts.force_chans)
+			return ACMHIP_ERR_ARG;
+		for (size_t i = 0; i < n; i++)
+			if (pre->data[i] != items[i].data)
+				return ACMHIP_ERR_ARG;
+		opts.parse = ACM_BATCH_PARSE_HOST;
+	}
 	acm_batch_timing tm{};
 	const auto t0 = clk::now();
 	static const bool trace = getenv("ACM_BATCH_TRACE") != nullptr;         /* host-side timeline on stderr */
@@ -489,6 +643,24 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		Slot &s = slots[i];
 		acm_batch_item &it = items[i];
 		acm_stage_info info{};
+		if (pre) {
+			/* parsed already: the staged blocks only have to move into the upload arenas */
+			const acm_batch_prestaged::Item &ps = pre->items[i];
+			if (!ps.ok) {
+				it.status = ps.status;
+				s.ok = false;
+				return;
+			}
+			const uint64_t bl = (uint64_t)ps.info.rows * ps.info.cols;
+			memcpy(h_idx + s.idx_off, pre->idx + ps.idx_off, ps.info.blocks * bl * sizeof(int16_t));
+			memcpy(h_hdr + s.hdr_off, pre->hdr + ps.hdr_off, ps.info.blocks * sizeof(acmhip_blkhdr));
+			s.patches = ps.patches;
+			s.info = ps.info;
+			s.host_staged = true;
+			it.status = ps.info.end_status;
+			it.words = deliverable_words(ps.info.total_values, bl, ps.info.channels, ps.info.blocks);
+			return;
+		}
 		/* first pass counts patches (normally zero), second only if there are any */
 		int r = acm_stage_file(it.data, it.len, opts.force_chans, h_idx + s.idx_off, h_hdr + s.hdr_off,
 				       s.need_blocks, nullptr, 0, &info);

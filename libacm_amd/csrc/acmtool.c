@@ -9,11 +9,14 @@
  * Extension (no reference counterpart): -B decodes all listed files as ONE
  * batch on the GPU (acm_batch_decode) instead of one after the other.
  */
+#include <errno.h>
 #include <getopt.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -115,11 +118,63 @@ static int pad_output(const char *name, FILE *out, char *buf, int done, int tota
 	return done;
 }
 
-/* all outputs written and closed: end the process without the HIP runtime's teardown (profiles/startup_probe.sh: ~0.08 s
- * of a 0.3 s run) */
+/*
+ * Leaving costs as much as arriving: when a process that used the GPU ends, the kernel gives back its device memory and
+ * unpins its pinned arenas before the parent's wait() returns - 0.16-0.27 s behind the last output byte of a 0.8 s batch run
+ * (profiles/r3_cli_probe.txt), 0.08 s even for a program that only initialised the runtime.  So the decode runs in a CHILD
+ * (forked before anything touches HIP); when every output is written and closed the child sends its exit code through a
+ * pipe and goes on to die at its own pace, and the process the caller waits for returns that code at once.  A child that
+ * ends any other way closes the pipe without a byte: the parent then waits for it and passes its status on.
+ * ACMTOOL_NO_DETACH=1 keeps everything in one process.
+ */
+static int done_fd = -1;
+
+static void detach_teardown(void)
+{
+	int fds[2];
+	pid_t pid;
+	const char *no = getenv("ACMTOOL_NO_DETACH");
+	if ((no && atoi(no)) || pipe(fds) != 0)
+		return;
+	fflush(NULL);
+	pid = fork();
+	if (pid < 0) {
+		close(fds[0]);
+		close(fds[1]);
+		return;
+	}
+	if (pid == 0) {
+		close(fds[0]);
+		done_fd = fds[1];
+		return;                 /* the child does the work */
+	}
+	close(fds[1]);
+	{
+		unsigned char code = 0;
+		ssize_t n;
+		int st = 0;
+		do
+			n = read(fds[0], &code, 1);
+		while (n < 0 && errno == EINTR);
+		if (n == 1)
+			_exit(code);
+		while (waitpid(pid, &st, 0) < 0 && errno == EINTR)
+			;
+		_exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+	}
+}
+
+/* all outputs written and closed: end the process without the HIP runtime's teardown, and tell the waiting parent first */
 static void fast_exit(int code)
 {
 	fflush(NULL);
+	if (done_fd >= 0) {
+		unsigned char c = (unsigned char)code;
+		ssize_t n;
+		do
+			n = write(done_fd, &c, 1);
+		while (n < 0 && errno == EINTR);
+	}
 	_exit(code);
 }
 
@@ -246,12 +301,16 @@ static int slurp(const char *name, unsigned char **data, size_t *len)
 
 /*
  * -B: batch mode (no reference counterpart; the files it leaves behind are the ones acmtool.c:231-316 writes one by one).
- * Three stages run beside each other on groups of files that fit a memory budget:
- *   reader   slurps the files of group g+1, reads their headers and carves one pinned PCM arena per group
- *   decoder  (this thread) runs acm_batch_decode on group g
- *   writers  write the WAV / raw files of group g-1 from a small thread pool, then release the group
- * At most three groups exist at a time, whatever the length of the file list; their PCM arenas are pinned once and reused,
- * and the read-back engine writes every file's PCM straight into them (ACM_BATCH_PCM_PINNED).
+ * Four stages run beside each other on groups of files that fit a memory budget:
+ *   reader   slurps the files of a group and reads their headers
+ *   stager   bit-parses the group on the host pool (acm_batch_prestage: needs no device, so it runs from the first
+ *            millisecond on, while the HIP runtime is still coming up - a third of the run on the 4000-file corpus)
+ *   decoder  (this thread) gives the group one of three pinned PCM arenas and runs acm_batch_decode on it: what is left of
+ *            that call is upload, synthesis and read-back
+ *   writers  write the WAV / raw files from a small thread pool, then release the group and its arena
+ * At most batch_groups_ahead groups exist at a time (read or parsed, waiting for the device), three of them with a PCM
+ * arena, whatever the length of the file list; the arenas are pinned once and reused, and the read-back engine writes
+ * every file's PCM straight into them (ACM_BATCH_PCM_PINNED).
  */
 typedef struct barena {                 /* PCM of one group; pinned when the device hands it out, else malloc */
 	void *mem;
@@ -263,6 +322,9 @@ typedef struct bgroup {
 	int first, n;                   /* names[first .. first + n) */
 	acm_batch_item *items;
 	barena *arena;
+	size_t pcm_words;               /* arena words this group needs */
+	acm_batch_prestaged *pre;       /* the group's files, bit-parsed (stager) */
+	double pre_s;
 	acm_batch_timing tm;
 	int rc;
 	struct bgroup *next;
@@ -320,7 +382,7 @@ static struct {
 	int nfiles;
 	char **names;
 	size_t budget;                  /* bytes of file images + PCM per group */
-	bqueue to_decode, to_write;
+	bqueue to_stage, to_decode, to_write;
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
 	int groups_alive;               /* read but not yet written out and freed */
@@ -329,7 +391,9 @@ static struct {
 } bt;
 
 #define BATCH_GROUPS_IN_FLIGHT 3        /* == number of bt.arenas */
-#define BATCH_WRITERS 4
+static int batch_groups_ahead = 6;      /* groups read / parsed ahead of the device: file images + staged indices, ~1.3 x the budget each
+					 * (ACMTOOL_GROUPS_AHEAD; what is touched here has to be given back at exit, 0.1 s per gigabyte) */
+#define BATCH_WRITERS 8
 
 /* ACMTOOL_BATCH_TRACE=1: wall-clock notes of the three stages on stderr (diagnostics; profiles/cli_batch_probe.sh) */
 static int bt_trace;
@@ -348,10 +412,9 @@ static void *batch_reader(void *unused)
 	(void)unused;
 	while (i < bt.nfiles) {
 		bgroup *g = calloc(1, sizeof(*g));
-		size_t bytes = 0, pcm_words = 0, at = 0;
-		int k;
+		size_t bytes = 0, pcm_words = 0;
 		pthread_mutex_lock(&bt.mu);
-		while (bt.groups_alive >= BATCH_GROUPS_IN_FLIGHT)
+		while (bt.groups_alive >= batch_groups_ahead)
 			pthread_cond_wait(&bt.cv, &bt.mu);
 		bt.groups_alive++;
 		pthread_mutex_unlock(&bt.mu);
@@ -377,49 +440,77 @@ static void *batch_reader(void *unused)
 			g->n++;
 			i++;
 		}
-		/* one arena per group, every file's PCM on a 128-byte boundary inside it; pinned memory lets the
-		 * read-back copy engine write it without a bounce buffer */
 		BT_NOTE("reader: %d files read, %zu MB of PCM to come", g->n, pcm_words * 2 >> 20);
-		if (pcm_words) {
-			/* groups_alive bounds the groups in flight to the number of arenas: one is free.  It is kept when big
-			 * enough; a new one is sized for a whole budget unless this is the only group */
-			barena *a = NULL;
-			pthread_mutex_lock(&bt.mu);
-			for (k = 0; k < BATCH_GROUPS_IN_FLIGHT && !a; k++)
-				if (!bt.arenas[k].busy)
-					a = &bt.arenas[k];
-			a->busy = 1;
-			pthread_mutex_unlock(&bt.mu);
-			if (a->cap < pcm_words * 2) {
-				size_t want = pcm_words * 2;
-				if (!(g->first == 0 && i == bt.nfiles) && want < bt.budget)
-					want = bt.budget;
-				if (a->mem) {
-					if (a->pinned)
-						acmhip_host_free(a->mem);
-					else
-						free(a->mem);
-				}
-				a->pinned = acmhip_host_alloc(want, &a->mem) == ACMHIP_OK;
-				if (!a->pinned)
-					a->mem = malloc(want);
-				a->cap = a->mem ? want : 0;
-				if (!a->mem)
-					fprintf(stderr, "acmtool: cannot allocate %zu MB for the PCM of %d files\n", want >> 20, g->n);
-			}
-			g->arena = a;
-		}
-		for (k = 0; k < g->n; k++) {
-			if (g->items[k].pcm_cap && g->arena && g->arena->mem) {
-				g->items[k].pcm = (int16_t *)g->arena->mem + at;
-				at += (g->items[k].pcm_cap + 63) & ~(size_t)63;
-			}
-		}
-		BT_NOTE("reader: arena ready");
+		g->pcm_words = pcm_words;
+		bq_push(&bt.to_stage, g);
+	}
+	bq_push(&bt.to_stage, NULL);
+	return NULL;
+}
+
+/* the host half of the decode, group by group, as soon as the files are in memory */
+static void *batch_stager(void *unused)
+{
+	bgroup *g;
+	acm_batch_opts opts;
+	(void)unused;
+	memset(&opts, 0, sizeof(opts));
+	opts.force_chans = cfg.force_chans;
+	while ((g = bq_pop(&bt.to_stage)) != NULL) {
+		if (acm_batch_prestage(g->items, (size_t)g->n, &opts, &g->pre, &g->pre_s) != ACMHIP_OK)
+			g->pre = NULL;          /* out of memory: acm_batch_decode parses the group itself */
+		BT_NOTE("stager: group of %d files parsed in %.3f s", g->n, g->pre_s);
 		bq_push(&bt.to_decode, g);
 	}
 	bq_push(&bt.to_decode, NULL);
 	return NULL;
+}
+
+/* one arena per group, every file's PCM on a 128-byte boundary inside it; pinned memory lets the read-back copy engine
+ * write it without a bounce buffer.  Called by the decoder (the device is up by then: pinning needs the runtime) */
+static void batch_give_arena(bgroup *g, int only_group)
+{
+	size_t at = 0;
+	int k;
+	if (g->pcm_words) {
+		barena *a = NULL;
+		pthread_mutex_lock(&bt.mu);
+		for (;;) {
+			for (k = 0; k < BATCH_GROUPS_IN_FLIGHT && !a; k++)
+				if (!bt.arenas[k].busy)
+					a = &bt.arenas[k];
+			if (a)
+				break;
+			pthread_cond_wait(&bt.cv, &bt.mu);      /* the writers release them */
+		}
+		a->busy = 1;
+		pthread_mutex_unlock(&bt.mu);
+		if (a->cap < g->pcm_words * 2) {
+			/* kept when big enough; a new one is sized for a whole budget unless this is the only group */
+			size_t want = g->pcm_words * 2;
+			if (!only_group && want < bt.budget)
+				want = bt.budget;
+			if (a->mem) {
+				if (a->pinned)
+					acmhip_host_free(a->mem);
+				else
+					free(a->mem);
+			}
+			a->pinned = acmhip_host_alloc(want, &a->mem) == ACMHIP_OK;
+			if (!a->pinned)
+				a->mem = malloc(want);
+			a->cap = a->mem ? want : 0;
+			if (!a->mem)
+				fprintf(stderr, "acmtool: cannot allocate %zu MB for the PCM of %d files\n", want >> 20, g->n);
+		}
+		g->arena = a;
+	}
+	for (k = 0; k < g->n; k++) {
+		if (g->items[k].pcm_cap && g->arena && g->arena->mem) {
+			g->items[k].pcm = (int16_t *)g->arena->mem + at;
+			at += (g->items[k].pcm_cap + 63) & ~(size_t)63;
+		}
+	}
 }
 
 typedef struct bwrite_job {
@@ -549,7 +640,7 @@ static int decode_batch(int nfiles, char **names)
 {
 	acm_batch_opts opts;
 	acmhip_device *dev = NULL;
-	pthread_t reader, writer;
+	pthread_t reader, stager, writer;
 	bgroup *g;
 	int rc, failed = 0;
 	const char *mb = getenv("ACMTOOL_BATCH_MB"), *bb = getenv("ACMTOOL_BATCH_BYTES");
@@ -564,15 +655,19 @@ static int decode_batch(int nfiles, char **names)
 											 * footprint (0.2 s per gigabyte to pin, as much to unpin) low */
 	if (bb && atol(bb) > 0)
 		bt.budget = (size_t)atol(bb);
+	bq_init(&bt.to_stage);
 	bq_init(&bt.to_decode);
 	bq_init(&bt.to_write);
 	pthread_mutex_init(&bt.mu, NULL);
 	pthread_cond_init(&bt.cv, NULL);
 
+	if (getenv("ACMTOOL_GROUPS_AHEAD") && atoi(getenv("ACMTOOL_GROUPS_AHEAD")) >= BATCH_GROUPS_IN_FLIGHT)
+		batch_groups_ahead = atoi(getenv("ACMTOOL_GROUPS_AHEAD"));
 	bt_trace = getenv("ACMTOOL_BATCH_TRACE") != NULL;
 	bt_t0 = bt_now();
 	/* the reader starts first: it reads the first group's files while this thread brings the HIP runtime up (~0.2 s) */
 	pthread_create(&reader, NULL, batch_reader, NULL);
+	pthread_create(&stager, NULL, batch_stager, NULL);
 	pthread_create(&writer, NULL, batch_writer, NULL);
 	rc = acmhip_device_open(0, NULL, &dev);
 	if (rc != ACMHIP_OK) {
@@ -582,8 +677,15 @@ static int decode_batch(int nfiles, char **names)
 	BT_NOTE("device open");
 	while ((g = bq_pop(&bt.to_decode)) != NULL) {
 		BT_NOTE("decoder: group of %d files", g->n);
+		batch_give_arena(g, g->first == 0 && g->n == nfiles);
+		BT_NOTE("decoder: arena ready");
 		opts.flags = (g->arena && g->arena->pinned) ? ACM_BATCH_PCM_PINNED : 0;
+		opts.prestaged = g->pre;
 		g->rc = failed ? ACMHIP_ERR_ARG : acm_batch_decode(dev, g->items, (size_t)g->n, &opts, &g->tm);
+		BT_NOTE("decoder: call returned");
+		acm_batch_prestage_free(g->pre);
+		g->pre = NULL;
+		g->tm.stage_s += g->pre_s;      /* the parsing happened in the stager */
 		BT_NOTE("decoder: done (parse %.3f h2d %.3f kernel %.3f d2h %.3f total %.3f, device-parsed %llu)", g->tm.stage_s, g->tm.h2d_s,
 			g->tm.kernel_s, g->tm.d2h_s, g->tm.total_s, (unsigned long long)g->tm.device_parsed);
 		if (g->rc != ACMHIP_OK && !failed) {
@@ -603,6 +705,7 @@ static int decode_batch(int nfiles, char **names)
 	}
 	bq_push(&bt.to_write, NULL);
 	pthread_join(reader, NULL);
+	pthread_join(stager, NULL);
 	pthread_join(writer, NULL);
 	if (!cfg.quiet && !failed)
 		printf("batch: %llu samples, alloc %.3fs parse %.3fs h2d %.3fs kernel %.3fs d2h %.3fs total %.3fs\n",
@@ -611,6 +714,11 @@ static int decode_batch(int nfiles, char **names)
 	/* every output file is closed: leave without unpinning the arenas (as slow as pinning them) or taking the HIP
 	 * runtime down (~0.08 s) - the process ends here anyway */
 	BT_NOTE("done");
+	if (bt_trace) {
+		struct timespec ts;
+		clock_gettime(CLOCK_REALTIME, &ts);
+		fprintf(stderr, "[batch] wall clock at exit %.3f, the batch started %.3f s before\n", ts.tv_sec + ts.tv_nsec * 1e-9, bt_now() - bt_t0);
+	}
 	fast_exit(failed);
 	return failed;
 }
@@ -694,6 +802,7 @@ int main(int argc, char *argv[])
 	/* decode */
 	if (optind == argc)
 		usage(1);
+	detach_teardown();              /* from here on this is the child: nothing has touched the GPU yet */
 	if (batch)
 		return decode_batch(argc - optind, argv + optind);
 	/* decoding for sure: the GPU comes up on a thread of the library's own while this one opens and parses */

@@ -631,6 +631,40 @@ def test_batch_block_ranges(dev, ranges, monkeypatch):
             assert res[k][0] == wst and np.array_equal(res[k][1], want), (k, ranges)
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_batch_prestaged(dev, pinned):
+    """acm_batch_prestage (the host half of a batch ahead of time, no device) + acm_batch_decode on its result: same PCM and
+    statuses as the oracle for clean, ragged, stereo, truncated, H1-patched and non-ACM files; items that are not the
+    prestaged ones are refused"""
+    files = [make_stream(9900 + i, [7, 9, 5, 3, 11, 0, 13, 8][i % 8], [16, 3, 1, 33][i % 4], 1 + (i * 7) % 19, channels=1 + i % 2, cut=i % 5)
+             for i in range(29)]
+    files[5] = files[5][:len(files[5]) * 2 // 3]
+    files[11] = b"RIFFnope"
+    files[17] = make_stream(9990, 7, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    res, tm = capi.batch_decode(dev, files, threads=4, pinned=pinned, prestage=True)
+    import oracle_api as O
+    for k, f in enumerate(files):
+        o = O.Oracle(f)
+        if o.err < 0:
+            assert res[k][0] == o.err and res[k][1].size == 0, k
+            continue
+        want, wst = oracle_pcm(f)
+        assert res[k][0] == wst and np.array_equal(res[k][1], want), k
+    # the handle belongs to the items it was made from
+    import ctypes as C
+    bufs, items = capi._batch_items(files)
+    pre = C.c_void_p()
+    opts = capi.BatchOpts(0, capi.FMT_S16LE, 2, capi.PLAN_AUTO, capi.PARSE_HOST, 0)
+    assert capi.lib().acm_batch_prestage(items, len(files), C.byref(opts), C.byref(pre), None) == 0
+    try:
+        opts.prestaged = pre
+        assert capi.lib().acm_batch_decode(dev.h, items, len(files) - 1, C.byref(opts), None) != 0
+        bufs2, items2 = capi._batch_items(files[::-1])
+        assert capi.lib().acm_batch_decode(dev.h, items2, len(files), C.byref(opts), None) != 0
+    finally:
+        capi.lib().acm_batch_prestage_free(pre)
+
+
 @pytest.mark.parametrize("ranges", ["2", "4", "16"])
 def test_batch_striped_upload_uneven_bit_rate(dev, ranges, monkeypatch):
     """block ranges upload the files in stripes and walk range r once stripe r + 1 is on the device: a stream that spends nearly
