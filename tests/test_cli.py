@@ -71,6 +71,38 @@ def test_cli_decoding(dev, rec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("detach", ["0", "1"], ids=["detached", "one_process"])
+def test_cli_returns_when_the_outputs_are_closed(dev, detach):
+    """acmtool decodes in a child that reports its exit code once every output is written and closed (the kernel's teardown of
+    the GPU process is not the caller's to wait for); ACMTOOL_NO_DETACH=1 keeps one process.  Either way: the same files, the
+    same messages, the same exit code - and the files are complete the moment the tool returns (stdout / stderr go to files
+    here: a pipe would be held open by the child and make the caller wait for it anyway)."""
+    env = dict(os.environ, ACMTOOL_NO_DETACH=detach)
+    with tempfile.TemporaryDirectory() as td:
+        from helpers import make_stream
+        files = {"a.acm": make_stream(7700, 7, 16, 40), "b.acm": make_stream(7701, 9, 4, 11, channels=2), "c.acm": b"not an acm file"}
+        for n, d in files.items():
+            open(os.path.join(td, n), "wb").write(d)
+        for flags in (["-d", "-q", "-r"], ["-d", "-q", "-B"]):
+            with open(os.path.join(td, "out.txt"), "wb") as so, open(os.path.join(td, "err.txt"), "wb") as se:
+                rc = subprocess.call([tool()] + flags + sorted(files), cwd=td, env=env, stdout=so, stderr=se)
+            ext = ".raw" if "-r" in flags else ".wav"
+            import oracle_api as O
+            for n in ("a", "b"):
+                got = open(os.path.join(td, n + ext), "rb").read()          # complete right now
+                want = O.Oracle.decode_all(files[n + ".acm"])[0].tobytes()
+                assert got[-len(want):] == want and len(got) == len(want) + (0 if ext == ".raw" else 44), (flags, n)
+                os.remove(os.path.join(td, n + ext))
+            assert not os.path.exists(os.path.join(td, "c" + ext))
+            assert rc == 0 and b"c.acm" in open(os.path.join(td, "err.txt"), "rb").read(), flags
+        # a child that does not get as far as reporting: the parent passes its status on
+        rc = subprocess.call([tool(), "-d", "-q", "-o", os.path.join(td, "nodir", "x.wav"), "a.acm"], cwd=td, env=env,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert rc == subprocess.call([tool(), "-d", "-q", "-o", os.path.join(td, "nodir", "x.wav"), "a.acm"], cwd=td,
+                                     env=dict(env, ACMTOOL_NO_DETACH="1"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("budget", [None, "20000"], ids=["one_group", "many_groups"])
 def test_cli_batch_mode(dev, budget):
     """-B: groups of files through acm_batch_decode with reading / decoding / writing overlapped.  The files it leaves
