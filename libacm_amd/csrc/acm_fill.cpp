@@ -231,6 +231,39 @@ struct SymbolTable {
 	}
 };
 
+/*
+ * The k-fillers' symbols are one to five bits long, so the next 8 bits usually hold several of them: one entry per
+ * (k-filler, next 8 bits) = every symbol that lies wholly inside those bits, up to 8 rows' worth - bits 0-3 the bits they
+ * take, 4-7 the rows they produce, then eight nibbles (index + 8; rows not produced hold 8 = index 0).  A look-up and eight
+ * unconditional stores replace three to eight single-symbol steps; used while at least eight rows of the column are left
+ * (the stores stay inside the column, and the "two zeros" symbol cannot reach past its end), the rest goes symbol by symbol.
+ */
+struct MultiSymbolTable {
+	uint64_t e[8][256];
+	static int slot(unsigned code) { return code <= 18 ? (int)code - 17 : code <= 21 ? (int)code - 18 : code <= 24 ? (int)code - 19 : (int)code - 20; }
+	static bool has(unsigned code) { return code == 17 || code == 18 || code == 20 || code == 21 || code == 23 || code == 24 || code == 26 || code == 27; }
+	MultiSymbolTable()
+	{
+		static const unsigned codes[8] = { 17, 18, 20, 21, 23, 24, 26, 27 };
+		for (int k = 0; k < 8; k++)
+			for (unsigned bits = 0; bits < 256; bits++) {
+				unsigned used = 0, rows = 0;
+				uint64_t vals = 0x88888888u;
+				for (;;) {
+					const uint32_t one = SymbolTable::entry(codes[k], (bits >> used) & 127u);
+					const unsigned len = one & 7u, cnt = (one >> 3) & 3u;
+					if (used + len > 8 || rows + cnt > 8)
+						break;
+					vals = (vals & ~((uint64_t)0xF << (4 * rows))) | (uint64_t)((one >> 5) & 15u) << (4 * rows);
+					if (cnt == 2)           /* "0" of the x3 / x4 / x5 families: two zeros */
+						vals = (vals & ~((uint64_t)0xF << (4 * (rows + 1)))) | (uint64_t)((one >> 9) & 15u) << (4 * (rows + 1));
+					used += len;
+					rows += cnt;
+				}
+				e[k][bits] = used | rows << 4 | vals << 8;
+			}
+	}
+};
 
 /*
  * One column.  `col` points at idx[0*cols + c]; consecutive rows are `pitch`
@@ -261,6 +294,24 @@ __attribute__((always_inline)) inline int parse_column(Cursor &bc, unsigned code
 		static const SymbolTable table;
 		const uint32_t *const tab = table.e[SymbolTable::slot(code)];
 		int16_t sink;                                           /* rows past the column's end land here */
+		if (MultiSymbolTable::has(code)) {
+			static const MultiSymbolTable multi;
+			const uint64_t *const mt = multi.e[MultiSymbolTable::slot(code)];
+			while (rows - r >= 8) {
+				if (bc.have < 8)
+					bc.refill();
+				const uint64_t e = mt[(uint32_t)bc.win & 255u];
+				const unsigned len = (unsigned)e & 15u, cnt = (unsigned)(e >> 4) & 15u;
+				const uint32_t v = (uint32_t)(e >> 8);
+				bc.win >>= len;
+				bc.have -= len;
+				bc.bit += len;
+				for (unsigned k = 0; k < 8; k++)
+					col[k * pitch] = (int16_t)((int)((v >> (4 * k)) & 15u) - 8);
+				col += cnt * pitch;
+				r += cnt;
+			}
+		}
 		while (r < rows) {
 			if (bc.have < 7)
 				bc.refill();
