@@ -989,8 +989,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			BTRY(launch_range(0, 0));
 		} else {
 			/* striped upload: stripe s of every file as one transfer + a scatter kernel; the walk of range r may start once
-			 * stripe r + 1 is in place (a range of blocks ends near the end of its stripe of the bits; one stripe of margin -
-			 * a stream whose bit rate is so uneven that it needs more is stopped there and taken by the host reader) */
+			 * stripe r + MARGIN is in place (a range of blocks ends near the end of its stripe of the bits; a stream whose bit
+			 * rate is so uneven that it needs more than the margin is stopped there and taken by the host reader) */
 			HTRY(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, st_up));
 			HTRY(hipMemcpyAsync(d_jobs + stripe_tab_off, h_jobs + stripe_tab_off, stripe_tab_bytes, hipMemcpyHostToDevice, st_up));
 			HTRY(hipEventRecord(ev_stripe[0], st_up));
@@ -1006,13 +1006,20 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 									   reinterpret_cast<const uint64_t *>(d_jobs + stripe_tab_off), d_stage, d_files,
 									   (uint32_t)sp, (uint32_t)R, st_up));
 				HTRY(hipEventRecord(ev_stripe[sp + 1], st_up));
-				if (sp >= 1) {
-					HTRY(hipStreamWaitEvent(st_parse, ev_stripe[sp + 1], 0));
-					BTRY(launch_range(sp - 1, sp + 1 < R ? sp + 1 : 0));
-				}
-				if (sp + 1 == R) {
+				/* range r is walked behind stripe r + MARGIN: its blocks end near the end of stripe r of the bits, and how
+				 * near depends on how evenly the stream spends them (a corpus of short files: a range is a block or two) */
+				constexpr size_t MARGIN = 2;
+				if (sp + 1 < R) {
+					if (sp >= MARGIN) {
+						HTRY(hipStreamWaitEvent(st_parse, ev_stripe[sp + 1], 0));
+						BTRY(launch_range(sp - MARGIN, sp + 1));
+					}
+				} else {
 					BNOTE("last stripe of the files queued for upload");
-					BTRY(launch_range(R - 1, 0));
+					HTRY(hipStreamWaitEvent(st_parse, ev_stripe[R], 0));
+					for (size_t r = R > MARGIN ? R - MARGIN - 1 : 0; r < R; r++)
+						if (r + MARGIN + 1 >= R)            /* the ranges no earlier stripe has released */
+							BTRY(launch_range(r, 0));
 				}
 			}
 		}
