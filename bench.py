@@ -231,7 +231,7 @@ def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):
         try:
             # the program itself stands right behind "--": the profiler's library is in the process before it starts
             r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return None
             total, dispatches = 0.0, set()
