@@ -144,6 +144,72 @@ int  acmhip_plan_launch(acmhip_plan *plan, const int16_t *d_idx, const acmhip_bl
  */
 int  acmhip_plan_attach_narrow(acmhip_plan *plan, const int16_t *d_idx, uint64_t *narrow_tiles);
 
+/* ------------------------------------------------------------------------
+ * Packed staged form: filler class per column pair + fixed-width packed residuals
+ * (BASELINE.json north_star: "per-block filler indices plus packed residuals").
+ *
+ * What set_pos() would store (decode.c:174-177) is an index whose range the column's filler fixes: 0 for the zero filler,
+ * |idx| <= 5 for every k / t filler, `ind` bits for a linear one (decode.c:181-476).  Instead of one int16 per sample the
+ * host stager ships, for the whole tiles of a stream (acmhip_packed_tile_rows(level) rows x cols, the unit the lean tile
+ * kernel works on), per GROUP of rows (acmhip_packed_group_rows) and per PAIR of adjacent columns a width class - 0, 4, 8
+ * or 16 bits per index, the narrowest that holds every index of the pair in those rows - and the indices at that width.
+ * Column pairs of one class are stored together, so that a wavefront of the kernel unpacks with one code path:
+ *
+ *   tile  -> acmhip_packed_slots(level) consecutive chunk descriptors, wave-major: the kernel's wave
+ *            w owns entries [w * S, (w + 1) * S) of them (S = slots / waves); unused entries have kind 0;
+ *   chunk -> 64 UNITS of one group and one class: 64 / NQ column pairs x NQ row quads (NQ = group rows / 4), a unit being
+ *            2 columns x the 4 rows row0 + q, row0 + q + NQ, row0 + q + 2 NQ, row0 + q + 3 NQ of its group.  Its blob, at
+ *            blob_off16 * 16 bytes: 64 / NQ uint16 (entries >= count unused) that name the column pairs by where their
+ *            first column sits in the kernel's padded LDS row (dwords: 2 p + p / 16), then the units, pair-major (pair r,
+ *            quad q at index r * NQ + q): kind 4: four dwords, dword k = the unit's k-th row, (int16) column 2p |
+ *            (int16) column 2p + 1 << 16;  kind 3: two dwords of int8 (row 0, col 2p), (row 0, 2p + 1), (row 1, 2p),
+ *            (row 1, 2p + 1) | rows 2, 3;  kind 2: one dword of eight int4 in the same order;  kind 1: nothing (all zeros).
+ *
+ * The int16 form stays what every other kernel reads (ragged tails, windows, streams with H1 patches, levels the lean
+ * kernel does not take), and what a plan falls back to while no packed arenas are bound.
+ * ---------------------------------------------------------------------- */
+typedef struct acmhip_packed_chunk {
+	uint32_t blob_off16;     /* 16-byte units from the blob arena's base */
+	uint16_t count;          /* column pairs in this chunk, 1 .. 64 / NQ */
+	uint8_t  kind;           /* ACMHIP_PK_*; 0 = unused entry */
+	uint8_t  row0;           /* first row of the chunk's group inside its tile */
+} acmhip_packed_chunk;
+#define ACMHIP_PK_ZERO   1u
+#define ACMHIP_PK_NIBBLE 2u
+#define ACMHIP_PK_BYTE   3u
+#define ACMHIP_PK_WORD   4u
+
+/* beside acmhip_stream_desc i: rows [0, ntiles * tile_rows) of the stream are staged in packed form as well */
+typedef struct acmhip_packed_stream {
+	uint64_t chunk_off;      /* the chunk-table entry the stream's first tile starts at (tile k: chunk_off + k * slots of its level) */
+	uint32_t ntiles;         /* 0: this stream has no packed form */
+	uint32_t reserved;
+} acmhip_packed_stream;
+
+int  acmhip_packed_tile_rows(uint32_t level);     /* rows per packed tile, 0 if the level has no packed form */
+int  acmhip_packed_group_rows(uint32_t level);    /* rows that share one width class per column pair */
+int  acmhip_packed_slots(uint32_t level);         /* chunk descriptors per tile */
+/* upper bound of the blob bytes `ntiles` tiles of `level` can take (incl. the slack the kernel may read past the last unit) */
+int  acmhip_pack_bound(uint32_t level, uint64_t ntiles, uint64_t *max_blob_bytes);
+/*
+ * Host stager, packed half (no device involved): packs `ntiles` consecutive tiles of ONE stream from staged indices
+ * idx[row * cols + col] (as acm_stage_file writes them; row 0 = the first row of the first tile) into
+ * chunks[0 .. ntiles * slots) and blob[0 .. *blob_bytes).  blob_base: where blob[0] will sit in the batch's blob arena
+ * (bytes, multiple of 16); the offsets written are absolute.  Replaces nothing in the reference by itself: it is the
+ * storage side of set_pos (decode.c:174-177).
+ */
+int  acmhip_pack_tiles(uint32_t level, const int16_t *idx, uint64_t ntiles, acmhip_packed_chunk *chunks, uint8_t *blob,
+		       uint64_t blob_base, uint64_t *blob_bytes);
+/* the inverse, for tests and tools: one tile's descriptors -> idx[tile_rows * cols] (blob = the arena's base) */
+int  acmhip_unpack_tile(uint32_t level, const acmhip_packed_chunk *tile_chunks, const uint8_t *blob, int16_t *idx);
+
+/* acmhip_plan_create with the packed form of (some of) the streams: packed[i].ntiles whole tiles of stream i, from its
+ * row 0 on, go to the packed build of the lean tile kernel once arenas are bound.  packed may be NULL. */
+int  acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream_desc *streams, size_t n, const acmhip_packed_stream *packed,
+			       const acmhip_patch *patches, size_t npatches, unsigned flags, acmhip_plan **out);
+/* device tables the packed tiles of this plan are read from by every later launch (both NULL: back to the int16 form) */
+int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob);
+
 /* introspection for benchmarks/tests */
 typedef struct acmhip_plan_stats {
 	uint64_t samples;        /* total n_emit */
@@ -153,7 +219,7 @@ typedef struct acmhip_plan_stats {
 	uint32_t launches;       /* kernel launches per acmhip_plan_launch */
 	uint32_t narrow_tiles;   /* tiles' worth of rows the launches read from the int8 plane (acmhip_plan_attach_narrow; 0 while nothing is attached) */
 	uint32_t narrow_front_tiles;     /* ... of which the two rows in front are narrow too (no 16-bit load left for them) */
-	uint32_t reserved;
+	uint32_t packed_tiles;   /* tiles that have records of the packed build too (read in packed form while arenas are bound: acmhip_plan_bind_packed) */
 } acmhip_plan_stats;
 int  acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out);
 

@@ -50,7 +50,7 @@ def build_synth(force=False):
     return out
 
 
-HIP_SOURCES = ["acm_kernels.hip", "acm_parse.hip", "acm_hip_api.cpp", "acm_fill.cpp", "acm_stream.cpp", "acm_batch.cpp"]
+HIP_SOURCES = ["acm_kernels.hip", "acm_parse.hip", "acm_hip_api.cpp", "acm_fill.cpp", "acm_pack.cpp", "acm_stream.cpp", "acm_batch.cpp"]
 
 
 def build_hip(force=False):

@@ -34,7 +34,18 @@ class StreamDesc(C.Structure):
 class PlanStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("tiles", C.c_uint64), ("fused_streams", C.c_uint32),
                 ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("narrow_tiles", C.c_uint32),
-                ("narrow_front_tiles", C.c_uint32), ("reserved", C.c_uint32)]
+                ("narrow_front_tiles", C.c_uint32), ("packed_tiles", C.c_uint32)]
+
+
+class PackedChunk(C.Structure):
+    _fields_ = [("blob_off16", C.c_uint32), ("count", C.c_uint16), ("kind", C.c_uint8), ("row0", C.c_uint8)]
+
+
+class PackedStream(C.Structure):
+    _fields_ = [("chunk_off", C.c_uint64), ("ntiles", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+PACKED_CHUNK_DT = np.dtype([("blob_off16", "<u4"), ("count", "<u2"), ("kind", "u1"), ("row0", "u1")])
 
 
 class StageInfo(C.Structure):
@@ -70,6 +81,8 @@ ACMHIP_SYMBOLS = [
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_attach_narrow", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
+    "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
+    "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -128,6 +141,14 @@ def lib():
     L.acm_batch_prestage.argtypes = [C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(vp), C.POINTER(C.c_double)]
     L.acm_batch_prestage_free.argtypes = [vp]
     L.acm_batch_prestage_free.restype = None
+    L.acmhip_packed_tile_rows.argtypes = [C.c_uint32]
+    L.acmhip_packed_group_rows.argtypes = [C.c_uint32]
+    L.acmhip_packed_slots.argtypes = [C.c_uint32]
+    L.acmhip_pack_bound.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.acmhip_pack_tiles.argtypes = [C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.acmhip_unpack_tile.argtypes = [C.c_uint32, vp, vp, vp]
+    L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(PackedStream), C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
+    L.acmhip_plan_bind_packed.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -209,6 +230,93 @@ def stage_file(data, force_chans=0, idx_out=None, hdr_out=None):
     return Staged(idx[:info2.blocks * bl], hdr[:info2.blocks], patches, info2)
 
 
+# --------------------------------------------------------------------------- host staging, packed half
+def packed_tile_rows(level):
+    return lib().acmhip_packed_tile_rows(level)
+
+
+class PackedArena:
+    """Host tables of the packed staged form of several streams: .chunks (acmhip_packed_slots(level) entries per tile), .blob,
+    and .streams (PackedStream beside each stream descriptor)."""
+
+    def __init__(self, chunks, blob, streams):
+        self.chunks, self.blob, self.streams = chunks, blob, streams
+
+    def upload(self, dev):
+        ptrs = []
+        for a in (self.chunks, self.blob):
+            p = dev.malloc(max(a.nbytes, 16))
+            flat = a.view(np.uint8).reshape(-1)
+            for o in range(0, flat.size, 1 << 28):
+                dev.upload(p + o, flat[o:o + (1 << 28)])
+            ptrs.append(p)
+        return tuple(ptrs)
+
+    @property
+    def nbytes(self):
+        return self.chunks.nbytes + self.blob.nbytes
+
+
+def pack_streams(idx, descs, threads=1):
+    """The packed staged form of every stream of a staged arena that can have one (whole tiles from row 0 of the levels
+    acmhip_packed_tile_rows() covers): returns a PackedArena whose .streams is a list of PackedStream beside descs."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    n = len(descs)
+    ntiles, chunk_off, blob_cap, slots = [0] * n, [0] * n, [0] * n, [0] * n
+    c_at = 0
+    for i, d in enumerate(descs):
+        tr = L.acmhip_packed_tile_rows(d.level)
+        if tr > 0 and d.row_begin == 0:
+            ntiles[i] = min(d.nrows, d.n_emit >> d.level) // tr
+            slots[i] = L.acmhip_packed_slots(d.level)
+        chunk_off[i] = c_at
+        c_at += ntiles[i] * slots[i]
+        if ntiles[i]:
+            mb = C.c_uint64()
+            _check(L.acmhip_pack_bound(d.level, ntiles[i], C.byref(mb)), "acmhip_pack_bound")
+            blob_cap[i] = (mb.value + 15) // 16 * 16
+    chunks = np.zeros(max(c_at, 1), dtype=PACKED_CHUNK_DT)
+    parts = [None] * n
+
+    def one(i):
+        if not ntiles[i]:
+            return
+        d = descs[i]
+        bl = np.zeros(blob_cap[i], dtype=np.uint8)
+        nb = C.c_uint64()
+        _check(L.acmhip_pack_tiles(d.level, idx[d.idx_off:].ctypes.data, ntiles[i], chunks[chunk_off[i]:].ctypes.data,
+                                   bl.ctypes.data, 0, C.byref(nb)), "acmhip_pack_tiles")
+        parts[i] = bl[:nb.value].copy()
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(one, range(n)))
+    b_at = 0
+    lay = []
+    for i in range(n):
+        lay.append(b_at)
+        if parts[i] is not None:
+            b_at += (parts[i].size + 15) // 16 * 16
+    blob = np.zeros(max(b_at, 16), dtype=np.uint8)
+    for i in range(n):
+        if parts[i] is None:
+            continue
+        b0 = lay[i]
+        c = chunks[chunk_off[i]:chunk_off[i] + ntiles[i] * slots[i]]
+        c["blob_off16"][c["kind"] != 0] += b0 // 16
+        blob[b0:b0 + parts[i].size] = parts[i]
+        parts[i] = None
+    streams = [PackedStream(chunk_off[i], ntiles[i], 0) for i in range(n)]
+    return PackedArena(chunks, blob, streams)
+
+
+def unpack_tile(level, chunks, blob, entry):
+    """inverse of the packer for the tile whose descriptors start at chunk-table entry `entry` (tests): int16 [tile_rows, cols]"""
+    tr = lib().acmhip_packed_tile_rows(level)
+    out = np.zeros((tr, 1 << level), dtype=np.int16)
+    _check(lib().acmhip_unpack_tile(level, chunks[entry:].ctypes.data, blob.ctypes.data, out.ctypes.data), "acmhip_unpack_tile")
+    return out
+
+
 # --------------------------------------------------------------------------- device
 class Device:
     def __init__(self, ordinal=0, hip_stream=None):
@@ -253,14 +361,25 @@ class Device:
 
 
 class Plan:
-    def __init__(self, dev, descs, patches=None, flags=PLAN_AUTO):
+    def __init__(self, dev, descs, patches=None, flags=PLAN_AUTO, packed=None):
+        """packed: optional list of PackedStream, one per desc (ntiles 0 = that stream has no packed form)"""
         self.dev = dev
         n = len(descs)
         arr = (StreamDesc * max(n, 1))(*descs)
         np_ = len(patches) if patches is not None else 0
         self.h = C.c_void_p()
-        _check(lib().acmhip_plan_create(dev.h, arr, n, patches if np_ else None, np_, flags, C.byref(self.h)),
-               "acmhip_plan_create")
+        if packed is not None:
+            assert len(packed) == n
+            pk = (PackedStream * max(n, 1))(*packed)
+            _check(lib().acmhip_plan_create_packed(dev.h, arr, n, pk, patches if np_ else None, np_, flags, C.byref(self.h)),
+                   "acmhip_plan_create_packed")
+        else:
+            _check(lib().acmhip_plan_create(dev.h, arr, n, patches if np_ else None, np_, flags, C.byref(self.h)),
+                   "acmhip_plan_create")
+
+    def bind_packed(self, d_chunks, d_blob):
+        """device tables of the packed staged form for every later launch (both None: back to the int16 arena)"""
+        _check(lib().acmhip_plan_bind_packed(self.h, d_chunks, d_blob), "acmhip_plan_bind_packed")
 
     def launch(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE):
         _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
@@ -330,10 +449,11 @@ class Arena:
         self.patches = (Patch * len(self.patch_list))(*self.patch_list) if self.patch_list else None
 
 
-def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, narrow=False):
+def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, narrow=False, packed=False):
     """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream.
     patch_subset (tests): keep only these entries of the batch's H1 patch list.
-    narrow: attach the int8 form of the staged indices first (acmhip_plan_attach_narrow)."""
+    narrow: attach the int8 form of the staged indices first (acmhip_plan_attach_narrow).
+    packed: stage the packed form too (acmhip_pack_tiles) and bind it: whole tiles from row 0 are read from it."""
     ar = Arena(staged_list, windows)
     if patch_subset is not None and ar.patch_list:
         ar.patch_list = [ar.patch_list[k] for k in patch_subset]
@@ -344,7 +464,16 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
     try:
         dev.upload(d_idx, ar.idx)
         dev.upload(d_hdr, ar.hdr)
-        plan = Plan(dev, ar.descs, ar.patches, flags)
+        pk, pk_ptrs = None, ()
+        if packed:
+            patched = {p.stream for p in ar.patch_list}
+            pk = pack_streams(ar.idx, ar.descs)
+            for i in patched:
+                pk.streams[i].ntiles = 0
+            pk_ptrs = pk.upload(dev)
+        plan = Plan(dev, ar.descs, ar.patches, flags, packed=pk.streams if pk else None)
+        if pk:
+            plan.bind_packed(*pk_ptrs)
         if narrow:
             plan.attach_narrow(d_idx)
         plan.launch(d_idx, d_hdr, d_pcm, fmt)
@@ -352,6 +481,8 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
         dev.download(out, d_pcm)
         st = plan.stats()
         plan.destroy()
+        for p in pk_ptrs:
+            dev.free(p)
     finally:
         dev.free(d_idx)
         dev.free(d_hdr)

@@ -84,6 +84,10 @@ struct AcmParseResult {
 /* levels the lean tile kernel (acm_tile2) covers (measured: 32 KB tiles lose to the 64-128 KB tiles of acm_fused_tile from level 10 on) */
 #define ACM_K2_MIN_LEVEL 6
 #define ACM_K2_MAX_LEVEL 14
+/* levels whose acm_tile2 tiles have a packed staged form and a kernel build that reads it (acm_tile2p): the 32 KB tiles of four
+ * workgroups per CU whose two-row stage-0 history fits LDS beside the tile */
+#define ACM_K2P_MIN_LEVEL 6
+#define ACM_K2P_MAX_LEVEL 9
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 
@@ -119,6 +123,15 @@ int acmk_tile2_grid(uint32_t level, int cus);
 #define ACM_K2_SINK_BYTES 65536                               /* >= one tile of PCM: where lead-in tiles put theirs */
 int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Modes *d_modes, const uint8_t *d_idx8,
 		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
+/* the packed staged form (include/acm_hip.h): same tiles as acm_tile2 (records with idx_off = the tile's first entry in the chunk table and
+ * hdr_blk / rowpos naming the block of tile row 0), stage-0 inputs unpacked from chunks of one width class each */
+int acmk_tile2p_rows(uint32_t level);                           /* rows per packed tile (= acmk_tile2_rows), 0 if the level has no packed build */
+int acmk_tile2p_group_rows(uint32_t level);                     /* rows that share a width class per column pair */
+int acmk_tile2p_slots(uint32_t level);                          /* chunk descriptors per tile: waves x descriptors per wave */
+int acmk_tile2p_waves(uint32_t level);
+int acmk_tile2p_pad_shift(uint32_t level);                      /* the tile's LDS rows carry one pad dword per 2^shift elements */
+int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob,
+		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 /* which narrow build acm_tile2 has at this level: 1 = as fast on wide tiles as the int16-only build, 2 = about 3 % slower on them
  * (one copy of the first pass with a branch per row pair: three copies do not fit the register file), 0 = none */
 int acmk_tile2_narrow_form(uint32_t level);

@@ -65,6 +65,10 @@ struct LevelGroup {
 	AcmTile2Modes *d_modes2 = nullptr;      /* beside them once an int8 plane is attached (acmhip_plan_attach_narrow) */
 	bool use_narrow = false;        /* ... and enough of the tiles are narrow for the narrow build of the kernel to pay */
 	uint32_t ntiles2 = 0;
+	/* the whole tiles of the streams that came with a packed form: as records of the packed build (acm_tile2p; idx_off = packed tile
+	 * number) and as plain acm_tile2 records over the int16 arena, which a launch uses while no packed arenas are bound */
+	AcmTile2 *d_tiles2p = nullptr, *d_tiles2p_plain = nullptr;
+	uint32_t ntiles2p = 0;
 	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
 	uint32_t ntiles_extra = 0;
 	uint32_t *d_list = nullptr;
@@ -94,6 +98,8 @@ struct acmhip_plan {
 	int32_t *d_plane[2] = { nullptr, nullptr };
 	uint64_t plane_elems = 0;
 	acmhip_plan_stats stats{};
+	const acmhip_packed_chunk *pk_chunks = nullptr; /* acmhip_plan_bind_packed: device tables of the packed staged form */
+	const uint8_t *pk_blob = nullptr;
 	int variant = 0;                        /* fused-kernel variant the tile tables were cut for */
 	/* several tile-kernel groups (a corpus of mixed levels): their launches are independent, so they go round robin
 	 * over the device stream and two side streams - the ramp-up and the tail of one launch overlap the next one's
@@ -389,6 +395,8 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		(void)hipFree(g.d_tiles);
 		(void)hipFree(g.d_tiles2);
 		(void)hipFree(g.d_modes2);
+		(void)hipFree(g.d_tiles2p);
+		(void)hipFree(g.d_tiles2p_plain);
 		(void)hipFree(g.d_tiles_extra);
 	}
 	for (auto &g : plan->stagewise)
@@ -418,6 +426,12 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 				  const acmhip_patch *patches, size_t npatches, unsigned flags,
 				  acmhip_plan **out)
 {
+	return acmhip_plan_create_packed(dev, streams, n, nullptr, patches, npatches, flags, out);
+}
+
+extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream_desc *streams, size_t n, const acmhip_packed_stream *packed,
+					 const acmhip_patch *patches, size_t npatches, unsigned flags, acmhip_plan **out)
+{
 	if (!dev || !out || (n && !streams) || (npatches && !patches) || n > 0xFFFFFFFFull)
 		return ACMHIP_ERR_ARG;
 	HIPTRY(hipSetDevice(dev->ordinal));
@@ -442,7 +456,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 		patch_rows[patches[p].stream].push_back(patches[p].sample >> streams[patches[p].stream].level);
 	for (auto &v : patch_rows)
 		std::sort(v.begin(), v.end());
-	std::vector<std::vector<AcmTile2>> tiles2(16);
+	std::vector<std::vector<AcmTile2>> tiles2(16), tiles2p(16), tiles2p_plain(16);
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
 	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
@@ -546,11 +560,22 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 				const uint64_t full_rows = std::min<uint64_t>(s.nrows, s.n_emit >> s.level);
 				rows2 = full_rows / T2 * T2;
 				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
+				/* a stream that came with its packed form: the same tiles once more as records of the packed build */
+				const bool pk = packed && packed[i].ntiles && acmk_tile2p_rows(s.level) == (int)T2;
+				if (pk && packed[i].ntiles < rows2 / T2) {
+					set_err("stream %zu: %u packed tiles, %llu whole tiles to decode", i, packed[i].ntiles, (unsigned long long)(rows2 / T2));
+					return ACMHIP_ERR_ARG;
+				}
+				std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : tiles2[s.level];
 				for (uint64_t r = 0; r < rows2; r += T2) {
 					const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
-					tiles2[s.level].push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
-									    (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-									    r == 0 ? ACM_TILE_FRESH : 0u });
+					plain.push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
+								  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
+								  r == 0 ? ACM_TILE_FRESH : 0u });
+					if (pk)
+						tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
+										     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
+										     r == 0 ? ACM_TILE_FRESH : 0u });
 				}
 			}
 			for (uint64_t r = rows2; r < emit_rows; r += T)
@@ -692,7 +717,7 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 	pl->variant = variant;
 	int rc = to_device(dev, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
-		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty()) {
+		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty() || !tiles2p[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
 			if (!tiles_extra[lv].empty()) {
@@ -706,8 +731,9 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
-			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? !tiles2[lv].empty()         /* levels 13, 14: decided before the cut */
-						  : getenv("ACM_K2") ? !tiles2[lv].empty() : tiles2[lv].size() >= 8 * grid2);
+			const size_t n2 = tiles2[lv].size() + tiles2p[lv].size();
+			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? n2 > 0         /* levels 13, 14: decided before the cut */
+						  : getenv("ACM_K2") ? n2 > 0 : n2 >= 8 * grid2);
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
@@ -723,7 +749,16 @@ extern "C" int acmhip_plan_create(acmhip_device *dev, const acmhip_stream_desc *
 					pl->narrow_extent = std::max<uint64_t>(pl->narrow_extent, t2.idx_off + ((uint64_t)acmk_tile2_rows(lv) << lv));
 				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
 				st.tiles += g.ntiles2;
-				st.launches += 1;
+				st.launches += g.ntiles2 ? 1 : 0;
+				if (rc == ACMHIP_OK && !tiles2p[lv].empty()) {
+					g.ntiles2p = (uint32_t)tiles2p[lv].size();
+					rc = to_device(dev, tiles2p[lv], &g.d_tiles2p);
+					if (rc == ACMHIP_OK)
+						rc = to_device(dev, tiles2p_plain[lv], &g.d_tiles2p_plain);
+					st.tiles += g.ntiles2p;
+					st.packed_tiles += g.ntiles2p;
+					st.launches += 1;
+				}
 				if (g.ntiles == 0)
 					st.launches -= 1;
 			}
@@ -842,6 +877,10 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		gi++;
 		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, g.use_narrow && d_idx == pl->narrow_src ? g.d_modes2 : nullptr, pl->d_idx8,
 					    d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		if (pl->pk_chunks)
+			LAUNCHTRY(acmk_launch_tile2p(g.level, pl->dev->cus, g.d_tiles2p, g.ntiles2p, pl->pk_chunks, pl->pk_blob, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		else
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, nullptr, nullptr, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}
@@ -885,6 +924,19 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 			LAUNCHTRY(acmk_launch_fused_plane(pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, pl->d_plane[cur], d_pcm, fmt, st));
 		}
 	}
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_bind_packed(acmhip_plan *pl, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob)
+{
+	if (!pl)
+		return ACMHIP_ERR_ARG;
+	if ((d_chunks == nullptr) != (d_blob == nullptr)) {
+		set_err("acmhip_plan_bind_packed: both tables, or none");
+		return ACMHIP_ERR_ARG;
+	}
+	pl->pk_chunks = d_chunks;
+	pl->pk_blob = d_blob;
 	return ACMHIP_OK;
 }
 

@@ -786,8 +786,11 @@ struct FirstPass {
 /* padded size of a carry buffer holding the BS elements in front of a tile (same pad rule as P::off) */
 constexpr int carry_words(int bs, int ps = 6) { return bs + (bs >> ps) + 2; }
 
+/* bias / bias_warm (a pass that starts at stage 0 only: acm_tile2p runs ALL its stages in LDS): the "+1" of decode.c:561-564 for
+ * the thread that owns residue 0 - in the bodies of its walk / in the warm-up body in front of it (0 where those rows do not exist) */
 template <class C, int K0, int G, bool LAST, int ABL = 0, bool FLIP = true, bool BIGEND = true, bool CARRY = false>
-__device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt, uint32_t *carry = nullptr)
+__device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const unsigned fmt, uint32_t *carry = nullptr, const uint32_t bias = 0u,
+					 const uint32_t bias_warm = 0u)
 {
 	using P = PassGeo<C, K0, G>;
 	constexpr int L = C::L;
@@ -859,7 +862,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			nxt[u] = base[P::off(u)];
 	}
 	if (!(ABL & 2))
-		pass_body<L, K0, G>(w, h, 0u, 0u);
+		pass_body<L, K0, G>(w, h, K0 == 0 ? bias_warm : 0u, K0 == 0 ? bias_warm : 0u);
 
 #pragma unroll
 	for (int it = 0; it < NBODY; it++) {
@@ -875,7 +878,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 				nxt[u] = pn[P::off(u)];
 		}
 		if (!(ABL & 2))
-			pass_body<L, K0, G>(v, h, 0u, 0u);
+			pass_body<L, K0, G>(v, h, K0 == 0 ? bias : 0u, K0 == 0 ? bias : 0u);
 		if constexpr (!LAST) {
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
@@ -919,13 +922,14 @@ constexpr int carry_total()
 }
 
 template <class C, int ABL, bool CARRY, int K0, int G, int... Rest>
-__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt, uint32_t *carry = nullptr)
+__device__ __forceinline__ void run_lds_passes(uint32_t *tile, int tid, unsigned fmt, uint32_t *carry = nullptr, const uint32_t bias = 0u,
+					       const uint32_t bias_warm = 0u)
 {
 	constexpr bool last = sizeof...(Rest) == 0;
 	static_assert(!last || K0 + G == C::L, "stage groups must add up to the level");
 	uint32_t *cb = CARRY ? carry : nullptr;
 	if constexpr (!last) {
-		lds_pass<C, K0, G, false, ABL, true, true, CARRY>(tile, tid, fmt, cb);
+		lds_pass<C, K0, G, false, ABL, true, true, CARRY>(tile, tid, fmt, cb, bias, bias_warm);
 		run_lds_passes<C, ABL, CARRY, K0 + G, Rest...>(tile, tid, fmt,
 							       CARRY ? carry + carry_words(PassGeo<C, K0, G>::BODY * PassGeo<C, K0, G>::SIGMA, C::PS) : nullptr);
 	} else if (fmt == ACMHIP_FMT_S16LE) {
@@ -1614,6 +1618,316 @@ inline const Tile2Entry &tile2_entry(uint32_t level)
 	return g_tile2[level - ACM_K2_MIN_LEVEL];
 }
 
+// ---------------------------------------------------------------------------
+// K2P: the lean tile kernel on the packed staged form
+// ---------------------------------------------------------------------------
+/*
+ * Same tiles, same LDS passes, same write-out as acm_tile2; what differs is where the stage-0 inputs come from.  acm_tile2
+ * owns a residue class per thread in its first pass, so its lanes stand for COLUMNS, and a column's index width is what varies
+ * in the packed form (include/acm_hip.h): per lane the field width, the register a field sits in and the address would all
+ * differ.  Here the unpack is a phase of its own in STORAGE order: the host stager has sorted the column pairs of a row group
+ * by width class, a wavefront takes a chunk of 64 units (2 columns x 4 rows each) of ONE class - one scalar branch, then
+ * SDWA multiplies (words, bytes) or v_bfe_i32 + multiply (nibbles) with compile-time field positions - and scatters
+ * value = idx * val (decode.c:592-600, :174-177) into the LDS tile at (row, column pair) of the chunk's column-pair list.
+ * All `level` stages then run as LDS passes in place (the pass that starts at stage 0 applies the "+1" of decode.c:561-564),
+ * their histories carried from tile to tile like every other pass's: no warm-up rows are re-read or re-computed.
+ * Per tile and thread: ~6 coalesced dword loads instead of 33, 0.6-0.9 B per index instead of 2 (4 on the rows acm_tile2 reads
+ * twice), one more LDS round trip per element.
+ * The chunk loads of the next tile are issued by hand before the LDS passes of this one and waited for with the tile's PCM
+ * stores in flight (k2_wait); which slot holds what is scalar state (the chunk descriptors' second word).
+ */
+template <class C, int GR_>
+struct PackGeo {
+	static constexpr int GR = GR_;                          /* rows per group: one width class per column pair */
+	static constexpr int NQ = GR / 4;                       /* row quads per group */
+	static constexpr int RPC = 64 / NQ;                     /* column pairs (ranks) per chunk */
+	static constexpr int PERMB = RPC * 2;                   /* bytes of a chunk's column-pair list */
+	static constexpr int NG = C::TR / GR;
+	static constexpr int P = C::COLS / 2;
+	static constexpr int MAXCHUNKS = NG * (P * NQ / 64 + 3);   /* four classes per group, each rounded up to whole chunks */
+	static constexpr int NW = C::NT / 64;
+	static constexpr int NSLOT = (MAXCHUNKS + NW - 1) / NW; /* chunk descriptors per wave and tile */
+	static constexpr int RS = C::COLS + (C::COLS >> C::PS); /* dwords between (row, c) and (row + 1, c) in the padded tile */
+	static_assert(GR % 4 == 0 && 64 % NQ == 0 && C::TR % GR == 0 && (P * NQ) % 64 == 0 && PERMB % 16 == 0, "packed geometry");
+	static_assert(C::COLS % (1 << C::PS) == 0, "rows are whole pad groups");
+	/* where the row value of tile row `row` sits in LDS: a unit's four rows (q, q + NQ, q + 2 NQ, q + 3 NQ of their group)
+	 * side by side, one 16-byte read per lane */
+	static __device__ __forceinline__ int rowval_pos(const int row)
+	{
+		const int g = row / GR, rr = row % GR;
+		return g * GR + 4 * (rr % NQ) + rr / NQ;
+	}
+};
+
+template <class C, class PG>
+struct PhaseU {
+	static constexpr int L = C::L, NQ = PG::NQ, RPC = PG::RPC, PERMB = PG::PERMB, RS = PG::RS;
+	struct Lane {
+		uint32_t unit;          /* index of this lane's unit among the chunk's 64: rank * NQ + quad */
+		uint32_t rank;          /* column pair of the chunk this lane works on */
+		uint32_t perm_voff;     /* byte offset of the dword that holds its column-pair entry ... */
+		uint32_t perm_sh;       /* ... and which half */
+		uint32_t row_dw;        /* dwords from the group's first row to this lane's first row */
+		uint32_t quad4;         /* 4 * quad: where its four row values start */
+	};
+	static __device__ __forceinline__ Lane lane_consts(const int tid)
+	{
+		/* adjacent lanes take adjacent column pairs of the same quad; the quads of a chunk start one row apart (their rows
+		 * interleave), which puts the stores of one instruction on different banks */
+		const uint32_t l = (uint32_t)tid & 63u, q = l / RPC, r = l % RPC;
+		return Lane{ r * NQ + q, r, (r >> 1) * 4u, (r & 1u) * 16u, q * (uint32_t)RS, q * 4u };
+	}
+	/* one chunk: its column-pair entries and 1 / 2 / 4 dwords of units per lane, by kind.  ONE asm statement with the
+	 * branches inside: every register has one definition on every path (tests/test_isa_invariants.py).  A chunk of zeros
+	 * (kind 1) loads a dword of whatever follows its list: cheaper than a branch around it for all the others */
+	static __device__ __forceinline__ void load(uint32_t (&d)[4], uint32_t &pm, const uint8_t *base, const uint32_t kind, const Lane &ln)
+	{
+		const uint32_t vd = ln.unit << kind;            /* 4, 8 or 16 bytes per unit */
+		asm volatile("s_cmp_eq_u32 %[k], 0\n\ts_cbranch_scc1 .Lacm_pk%=\n\t"
+			     "global_load_dword %[pm], %[vp], %[b]\n\t"
+			     "global_load_dword %[d0], %[vd], %[b] offset:%[o0]\n\t"
+			     "s_cmp_lt_u32 %[k], 3\n\ts_cbranch_scc1 .Lacm_pk%=\n\t"
+			     "global_load_dword %[d1], %[vd], %[b] offset:%[o1]\n\t"
+			     "s_cmp_lt_u32 %[k], 4\n\ts_cbranch_scc1 .Lacm_pk%=\n\t"
+			     "global_load_dword %[d2], %[vd], %[b] offset:%[o2]\n\t"
+			     "global_load_dword %[d3], %[vd], %[b] offset:%[o3]\n\t"
+			     ".Lacm_pk%=:"
+			     : [pm] "=&v"(pm), [d0] "=&v"(d[0]), [d1] "=&v"(d[1]), [d2] "=&v"(d[2]), [d3] "=&v"(d[3])
+			     : [vp] "v"(ln.perm_voff), [vd] "v"(vd), [b] "s"(base), [k] "s"(kind), [o0] "n"(PERMB), [o1] "n"(PERMB + 4),
+			       [o2] "n"(PERMB + 8), [o3] "n"(PERMB + 12)
+			     : "memory", "scc");
+	}
+	/* a unit's eight indices times the values of its four rows (decode.c:592-600: midbuf[idx] == idx * val), by kind - one
+	 * statement with scalar branches inside, the most frequent kind first: left to the compiler the three forms come out as a
+	 * web of flag registers and zero fills on every path */
+	static __device__ __forceinline__ void unpack(const uint32_t (&d)[4], const int32_t (&rv)[4], const uint32_t kind, uint32_t (&x)[4][2])
+	{
+#define ACM_PK_NIB(D, POS, V) "v_bfe_i32 " D ", %[d0], " POS ", 4\n\tv_mul_i32_i24 " D ", " D ", " V "\n\t"
+#define ACM_PK_SDWA(D, S, SEL, V) "v_mul_i32_i24_sdwa " D ", sext(" S "), " V " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"
+		asm("s_cmp_eq_u32 %[k], 2\n\ts_cbranch_scc0 .Lacm_un_b%=\n\t"
+		    ACM_PK_NIB("%[x0]", "0", "%[r0]") ACM_PK_NIB("%[x1]", "4", "%[r0]") ACM_PK_NIB("%[x2]", "8", "%[r1]") ACM_PK_NIB("%[x3]", "12", "%[r1]")
+		    ACM_PK_NIB("%[x4]", "16", "%[r2]") ACM_PK_NIB("%[x5]", "20", "%[r2]") ACM_PK_NIB("%[x6]", "24", "%[r3]") ACM_PK_NIB("%[x7]", "28", "%[r3]")
+		    "s_branch .Lacm_un_e%=\n"
+		    ".Lacm_un_b%=:\n\ts_cmp_eq_u32 %[k], 3\n\ts_cbranch_scc0 .Lacm_un_w%=\n\t"
+		    ACM_PK_SDWA("%[x0]", "%[d0]", "BYTE_0", "%[r0]") ACM_PK_SDWA("%[x1]", "%[d0]", "BYTE_1", "%[r0]")
+		    ACM_PK_SDWA("%[x2]", "%[d0]", "BYTE_2", "%[r1]") ACM_PK_SDWA("%[x3]", "%[d0]", "BYTE_3", "%[r1]")
+		    ACM_PK_SDWA("%[x4]", "%[d1]", "BYTE_0", "%[r2]") ACM_PK_SDWA("%[x5]", "%[d1]", "BYTE_1", "%[r2]")
+		    ACM_PK_SDWA("%[x6]", "%[d1]", "BYTE_2", "%[r3]") ACM_PK_SDWA("%[x7]", "%[d1]", "BYTE_3", "%[r3]")
+		    "s_branch .Lacm_un_e%=\n"
+		    ".Lacm_un_w%=:\n\ts_cmp_eq_u32 %[k], 4\n\ts_cbranch_scc0 .Lacm_un_z%=\n\t"
+		    ACM_PK_SDWA("%[x0]", "%[d0]", "WORD_0", "%[r0]") ACM_PK_SDWA("%[x1]", "%[d0]", "WORD_1", "%[r0]")
+		    ACM_PK_SDWA("%[x2]", "%[d1]", "WORD_0", "%[r1]") ACM_PK_SDWA("%[x3]", "%[d1]", "WORD_1", "%[r1]")
+		    ACM_PK_SDWA("%[x4]", "%[d2]", "WORD_0", "%[r2]") ACM_PK_SDWA("%[x5]", "%[d2]", "WORD_1", "%[r2]")
+		    ACM_PK_SDWA("%[x6]", "%[d3]", "WORD_0", "%[r3]") ACM_PK_SDWA("%[x7]", "%[d3]", "WORD_1", "%[r3]")
+		    "s_branch .Lacm_un_e%=\n"
+		    ".Lacm_un_z%=:\n\t"
+		    "v_mov_b32 %[x0], 0\n\tv_mov_b32 %[x1], 0\n\tv_mov_b32 %[x2], 0\n\tv_mov_b32 %[x3], 0\n\t"
+		    "v_mov_b32 %[x4], 0\n\tv_mov_b32 %[x5], 0\n\tv_mov_b32 %[x6], 0\n\tv_mov_b32 %[x7], 0\n"
+		    ".Lacm_un_e%=:"
+		    : [x0] "=&v"(x[0][0]), [x1] "=&v"(x[0][1]), [x2] "=&v"(x[1][0]), [x3] "=&v"(x[1][1]), [x4] "=&v"(x[2][0]), [x5] "=&v"(x[2][1]),
+		      [x6] "=&v"(x[3][0]), [x7] "=&v"(x[3][1])
+		    : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [d3] "v"(d[3]), [r0] "v"(rv[0]), [r1] "v"(rv[1]), [r2] "v"(rv[2]), [r3] "v"(rv[3]),
+		      [k] "s"(kind)
+		    : "scc");
+#undef ACM_PK_NIB
+#undef ACM_PK_SDWA
+	}
+	/* meta = the chunk descriptor's second word: count | kind << 16 | row0 << 24 (0: the slot is empty) */
+	typedef int32_t v4i __attribute__((ext_vector_type(4)));
+	/* +-val of a unit's four rows (decode.c:589): one 16-byte read */
+	static __device__ __forceinline__ v4i row_values(const int32_t *rowval, const uint32_t row0, const Lane &ln)
+	{
+		return *reinterpret_cast<const v4i *>(rowval + row0 + ln.quad4);
+	}
+	/* r4: the lane's row values when the tile is a single group (they are the same for every chunk then), else read per chunk */
+	static __device__ __forceinline__ void compute(const uint32_t (&d)[4], const uint32_t pm, const uint32_t meta, uint32_t *tile,
+						       const int32_t *rowval, const Lane &ln, const v4i r4_tile)
+	{
+		const uint32_t kind = (meta >> 16) & 0xFFu, count = meta & 0xFFFFu, row0 = meta >> 24;
+		if (kind == 0u)
+			return;
+		if (ln.rank < count) {
+			const uint32_t at = (pm >> ln.perm_sh) & 0xFFFFu;                       /* 2 p + p / 16: the pair's place in a padded row */
+			uint32_t *o = tile + row0 * (uint32_t)RS + ln.row_dw + at;
+			const v4i r4 = PG::NG == 1 ? r4_tile : row_values(rowval, row0, ln);
+			const int32_t rv[4] = { r4.x, r4.y, r4.z, r4.w };
+			uint32_t x[4][2];
+			unpack(d, rv, kind, x);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				o[k * NQ * RS] = x[k][0];
+				o[k * NQ * RS + 1] = x[k][1];
+			}
+		}
+	}
+};
+
+template <class C, int WPS, int GR, int G0, int... Gs>
+__global__ void __launch_bounds__(C::NT, WPS)
+acm_tile2p(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint2 *__restrict__ chunks /* acmhip_packed_chunk as two words */,
+	   const uint8_t *__restrict__ blob, const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink,
+	   const unsigned fmt)
+{
+	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
+	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
+	using PG = PackGeo<C, GR>;
+	using PU = PhaseU<C, PG>;
+	constexpr int NSLOT = PG::NSLOT, NW = PG::NW;
+	static_assert(TR <= NT, "one row value per thread");
+	constexpr bool PRIO = WPS * 256 / NT > 1;
+
+	__shared__ uint32_t tile_mem[8 + NELEM + (NELEM >> C::PS)];
+	__shared__ __attribute__((aligned(16))) int32_t rowval[2][TR];
+	constexpr int NCARRY_WORDS = carry_total<C, 0, G0, Gs...>();
+	__shared__ uint32_t carry_mem[NCARRY_WORDS];
+	uint32_t *const tile = tile_mem + 8;
+
+	const int tid = threadIdx.x;
+	const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+	uint32_t t = blockIdx.x * per;
+	const uint32_t t_end = t + per < ntiles ? t + per : ntiles;
+	if (t >= t_end)
+		return;
+	bool discard = false;
+	if (!(tiles[__builtin_amdgcn_readfirstlane(t)].flags & ACM_TILE_FRESH)) {
+		discard = true;                 /* a run that starts inside a stream replays the tile in front of it without storing PCM */
+		t--;
+	}
+
+	const typename PU::Lane ln = PU::lane_consts(tid);
+	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid) >> 6;
+
+	/* row values: thread lr < TR fetches the val of tile row lr (decode.c:589); looked at in finish_val, a whole tile later */
+	const uint32_t lr_fetch = (uint32_t)(tid < TR ? tid : TR - 1);
+	const int rv_pos = PG::rowval_pos(tid < TR ? tid : 0);
+	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
+		const uint32_t q = r.rowpos + lr_fetch;
+		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;     /* q / acm_rows */
+		const uint32_t *p = &hdr[r.hdr_blk + b].val;
+		uint32_t v;
+		asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+		return v;
+	};
+	auto finish_val = [&](uint32_t v) -> int32_t {
+		v <<= OutScale<L>::SHIFT;
+		return (NEG_ODD_ROWS && (tid & 1)) ? -(int32_t)v : (int32_t)v;
+	};
+	auto sgpr_ptr = [&](const uint64_t a) -> const uint8_t * {
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
+	};
+	/* this wave's chunk descriptors of a tile: NSLOT consecutive entries of the table (the packer deals a tile's chunks out to
+	 * the waves).  They come through the scalar cache - the index is wave-uniform; a vector load here would be tracked by the
+	 * compiler's vmcnt bookkeeping, which knows nothing of the asm loads - an iteration before the chunk loads they describe */
+	struct Descs { uint2 w[NSLOT]; };
+	auto fetch_descs = [&](const AcmTile2 &r) -> Descs {
+		const uint64_t at = r.idx_off + wv * (uint32_t)NSLOT;           /* idx_off of a packed tile's record: its first entry in the chunk table */
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
+		const uint2 *run = chunks + (((uint64_t)hi << 32) | lo);
+		Descs ds;
+#pragma unroll
+		for (int s = 0; s < NSLOT; s++)
+			ds.w[s] = run[s];               /* { blob_off16, count | kind << 16 | row0 << 24 } */
+		return ds;
+	};
+	auto load_tile = [&](uint32_t (&d)[NSLOT][4], uint32_t (&pm)[NSLOT], uint32_t (&meta)[NSLOT], const Descs &ds) {
+#pragma unroll
+		for (int s = 0; s < NSLOT; s++) {
+			meta[s] = ds.w[s].y;
+			PU::load(d[s], pm[s], sgpr_ptr(reinterpret_cast<uint64_t>(blob) + (uint64_t)ds.w[s].x * 16u), (meta[s] >> 16) & 0xFFu, ln);
+		}
+	};
+	auto tile_at = [&](const uint32_t k) -> AcmTile2 { return tiles[__builtin_amdgcn_readfirstlane(k < t_end ? k : t_end - 1u)]; };
+
+	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;
+	static_assert(NVEC % NT == 0, "whole rounds");
+	AcmTile2 cur = tile_at(t);
+	uint32_t d[NSLOT][4], pm[NSLOT], meta[NSLOT];
+	uint32_t hv = fetch_val(cur);
+	load_tile(d, pm, meta, fetch_descs(cur));
+	k2_wait<0>();
+	int buf = 0;
+	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
+	bool first_rows = (cur.flags & ACM_TILE_FRESH) != 0;    /* nothing in front of this tile: no "+1" in front of it either */
+	constexpr uint32_t ONE = 1u << OutScale<L>::SHIFT;
+	const uint32_t bias = (tid % PassGeo<C, 0, G0>::SIGMA) == 0 ? ONE : 0u;
+
+	/* tile records come through the scalar cache one iteration ahead, the chunk descriptors of that tile at the top of the
+	 * iteration that issues its chunk loads; the last tile of a run names itself as its successor */
+	AcmTile2 nxt = tile_at(t + 1);
+	for (;;) {
+		const uint32_t tn = t + 1;
+		const bool more = tn < t_end;
+		if (fresh)
+			for (int k = tid; k < NCARRY_WORDS; k += NT)
+				carry_mem[k] = 0u;
+		if (tid < TR)
+			rowval[buf][rv_pos] = finish_val(hv);
+		const Descs dn = fetch_descs(nxt);
+		__syncthreads();                /* row values complete; the previous write-out is done with the tile */
+#ifndef ACM_PK_PRIO_U
+#define ACM_PK_PRIO_U PRIO_FIRST_PASS
+#endif
+		phase_prio<PRIO, ACM_PK_PRIO_U>();
+		{
+			typename PU::v4i r4 = { 0, 0, 0, 0 };
+			if constexpr (PG::NG == 1)
+				r4 = PU::row_values(rowval[buf], 0u, ln);
+#pragma unroll
+			for (int s = 0; s < NSLOT; s++)
+				PU::compute(d[s], pm[s], meta[s], tile, rowval[buf], ln, r4);
+		}
+		phase_prio<PRIO, PRIO_IDLE>();
+
+		hv = fetch_val(nxt);            /* the last tile of a run fetches its own again: no branch around the loads */
+		load_tile(d, pm, meta, dn);
+		phase_prio<PRIO, PRIO_LDS_PASSES>();
+		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
+		run_lds_passes<C, 0, true, 0, G0, Gs...>(tile, tid, fmt, carry_mem, bias, (first_rows && tid < PassGeo<C, 0, G0>::SIGMA) ? 0u : bias);
+		__syncthreads();
+		{
+			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+			v4u *out = discard ? reinterpret_cast<v4u *>(sink) : reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
+#pragma unroll
+			for (int k = 0; k < NVEC / NT; k++) {
+				const int vec = tid + k * NT;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				const v4u o = { q[0], q[1], q[2], q[3] };
+				__builtin_nontemporal_store(o, &out[vec]);
+			}
+		}
+		phase_prio<PRIO, PRIO_IDLE>();
+		k2_wait<NSTORE>();              /* the next tile's chunks are here; only this tile's PCM stores may still be on their way */
+		if (!more)
+			break;
+		fresh = first_rows = (nxt.flags & ACM_TILE_FRESH) != 0;
+		discard = false;
+		cur = nxt;
+		t = tn;
+		nxt = tile_at(t + 1);
+		buf ^= 1;
+	}
+}
+
+struct Tile2PEntry {
+	typedef void (*Fn)(const AcmTile2 *, uint32_t, const uint2 *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	Fn fn;
+	int threads, tile_rows, wg_per_cu, group_rows, slots, pad_shift;
+};
+template <class C, int GR, int... Gs>
+constexpr Tile2PEntry entry_k2p()
+{
+	return Tile2PEntry{ acm_tile2p<C, 4, GR, Gs...>, C::NT, C::TR, 1024 / C::NT, GR, PackGeo<C, GR>::NW * PackGeo<C, GR>::NSLOT, C::PS };
+}
+/* the tile geometries and stage groupings of acm_tile2 (g_tile2); groups of 16 rows = one block of the usual acm_rows = 16
+ * (level 6: 32, or a wave would hold ten chunks) */
+const Tile2PEntry g_tile2p[ACM_K2P_MAX_LEVEL - ACM_K2P_MIN_LEVEL + 1] = {
+	entry_k2p<TileCfg<6, 256, 8192>, 32, 2, 2, 2>(),
+	entry_k2p<TileCfg<7, 256, 8192>, 16, 3, 2, 2>(),
+	entry_k2p<TileCfg<8, 256, 8192>, 16, 3, 3, 2>(),
+	entry_k2p<TileCfg<9, 256, 8192>, 16, 3, 3, 3>(),
+};
+
 /* levels 13-15: the stage-wise kernels apply the first level-12 stages into an int32 plane, this level-12 build of the tile
  * kernel (one 128 KB tile per CU - two 64 KB tiles spill with the 64 prefetch registers of a plane; halo or carry flavour like
  * every other group) reads the plane and does the other twelve */
@@ -1805,6 +2119,61 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	const bool narrow = d_modes && d_idx8 && e.fn_narrow;
 	hipLaunchKernelGGL(narrow ? e.fn_narrow : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx,
 			   narrow ? d_modes : nullptr, narrow ? d_idx8 : nullptr, d_hdr, d_pcm, d_sink, fmt);
+	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
+extern "C" int acmk_tile2p_rows(uint32_t level)
+{
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return 0;
+	return g_tile2p[level - ACM_K2P_MIN_LEVEL].tile_rows;
+}
+
+extern "C" int acmk_tile2p_group_rows(uint32_t level)
+{
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return 0;
+	return g_tile2p[level - ACM_K2P_MIN_LEVEL].group_rows;
+}
+
+extern "C" int acmk_tile2p_slots(uint32_t level)
+{
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return 0;
+	return g_tile2p[level - ACM_K2P_MIN_LEVEL].slots;
+}
+
+extern "C" int acmk_tile2p_waves(uint32_t level)
+{
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return 0;
+	return g_tile2p[level - ACM_K2P_MIN_LEVEL].threads / 64;
+}
+
+extern "C" int acmk_tile2p_pad_shift(uint32_t level)
+{
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return 0;
+	return g_tile2p[level - ACM_K2P_MIN_LEVEL].pad_shift;
+}
+
+extern "C" int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob,
+				  const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
+{
+	if (ntiles == 0)
+		return 0;
+	if (!d_sink || !d_chunks || !d_blob)
+		return -1;
+	if (level < ACM_K2P_MIN_LEVEL || level > ACM_K2P_MAX_LEVEL)
+		return -1;
+	const Tile2PEntry &e = g_tile2p[level - ACM_K2P_MIN_LEVEL];
+	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
+	if (grid > ntiles)
+		grid = ntiles;
+	static_assert(sizeof(acmhip_packed_chunk) == sizeof(uint2), "a chunk descriptor is two words");
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, reinterpret_cast<const uint2 *>(d_chunks), d_blob, d_hdr,
+			   d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

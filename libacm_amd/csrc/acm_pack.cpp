@@ -1,0 +1,231 @@
+/*
+ * acm_pack.cpp - the host stager's packed half (include/acm_hip.h, "Packed staged form").
+ *
+ * The reference stores every filler index through set_pos() as a table look-up into an int32 block matrix
+ * (/root/reference/src/decode.c:174-177); what range an index can have is fixed by its column's filler (zero filler: 0;
+ * k / t fillers: |idx| <= 5; linear filler of `ind` bits: [-2^(ind-1), 2^(ind-1)), decode.c:181-476).  Here the staged
+ * indices of a tile leave the host as "width class per column pair and row group + the indices at that width", sorted
+ * by class so that the device unpacks a whole wavefront's worth with one code path (acm_kernels.hip: acm_tile2p).
+ * The class is taken from the values themselves (the narrowest of 0 / 4 / 8 / 16 bits that holds them), which is never
+ * wider than what the filler codes promise and needs no knowledge of them.
+ *
+ * Pure host code: no HIP call in this file.
+ */
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "acm_device.h"
+#include "acm_hip.h"
+
+namespace {
+
+struct Geo {
+	uint32_t level, cols, pairs, tile_rows, group_rows, nq, rpc, permb, ngroups, slots, waves, per_wave, pad_shift;
+};
+
+bool geo_of(uint32_t level, Geo *g)
+{
+	const int tr = acmk_tile2p_rows(level), gr = acmk_tile2p_group_rows(level);
+	if (tr <= 0 || gr <= 0)
+		return false;
+	g->level = level;
+	g->cols = 1u << level;
+	g->pairs = g->cols / 2;
+	g->tile_rows = (uint32_t)tr;
+	g->group_rows = (uint32_t)gr;
+	g->nq = g->group_rows / 4;
+	g->rpc = 64 / g->nq;
+	g->permb = g->rpc * 2;
+	g->ngroups = g->tile_rows / g->group_rows;
+	g->slots = (uint32_t)acmk_tile2p_slots(level);
+	g->waves = (uint32_t)acmk_tile2p_waves(level);
+	g->per_wave = g->slots / g->waves;
+	g->pad_shift = (uint32_t)acmk_tile2p_pad_shift(level);
+	return true;
+}
+
+inline uint32_t unit_bytes(uint32_t kind) { return kind >= ACMHIP_PK_NIBBLE ? 1u << kind : 0u; }     /* 4 / 8 / 16 */
+
+inline uint64_t round16(uint64_t v) { return (v + 15) & ~15ull; }
+
+/* bytes past a chunk's last unit that a wavefront may still read: all 64 lanes load their unit's dwords, count or not */
+constexpr uint64_t kReadSlack = 64 * 16 + 128;
+
+/* where the first column of pair p sits in the kernel's padded LDS row, in dwords (acm_kernels.hip: lds_at) */
+inline uint32_t lds_place(const Geo &g, uint32_t p) { return 2 * p + ((2 * p) >> g.pad_shift); }
+
+} // namespace
+
+extern "C" int acmhip_packed_tile_rows(uint32_t level)
+{
+	return acmk_tile2p_rows(level);
+}
+
+extern "C" int acmhip_packed_group_rows(uint32_t level)
+{
+	return acmk_tile2p_group_rows(level);
+}
+
+extern "C" int acmhip_packed_slots(uint32_t level)
+{
+	return acmk_tile2p_slots(level);
+}
+
+extern "C" int acmhip_pack_bound(uint32_t level, uint64_t ntiles, uint64_t *max_blob_bytes)
+{
+	Geo g;
+	if (!geo_of(level, &g))
+		return ACMHIP_ERR_ARG;
+	if (max_blob_bytes)     /* every index as a word + every chunk's column-pair list */
+		*max_blob_bytes = ntiles * ((uint64_t)g.tile_rows * g.cols * 2 + (uint64_t)g.slots * (g.permb + 16)) + kReadSlack;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_pack_tiles(uint32_t level, const int16_t *idx, uint64_t ntiles, acmhip_packed_chunk *chunks, uint8_t *blob,
+				 uint64_t blob_base, uint64_t *blob_bytes_out)
+{
+	Geo g;
+	if (!geo_of(level, &g) || (ntiles && (!idx || !chunks || !blob)) || (blob_base & 15))
+		return ACMHIP_ERR_ARG;
+	std::vector<uint16_t> need(g.pairs);            /* per column pair: OR of the magnitudes' bits in this group */
+	std::vector<uint16_t> order[5];                 /* [kind]: the column pairs of that class, ascending */
+	for (auto &o : order)
+		o.reserve(g.pairs);
+	uint64_t nb = 0;
+	for (uint64_t t = 0; t < ntiles; t++) {
+		acmhip_packed_chunk *tc = chunks + t * g.slots;
+		memset(tc, 0, g.slots * sizeof(acmhip_packed_chunk));
+		uint32_t dealt = 0;             /* chunks of this tile so far: chunk k goes to wave k % waves, its slot k / waves */
+		for (uint32_t grp = 0; grp < g.ngroups; grp++) {
+			const int16_t *rows = idx + ((t * g.tile_rows + (uint64_t)grp * g.group_rows) << level);
+			memset(need.data(), 0, g.pairs * sizeof(uint16_t));
+			for (uint32_t r = 0; r < g.group_rows; r++) {
+				const int16_t *row = rows + ((uint64_t)r << level);
+				for (uint32_t p = 0; p < g.pairs; p++) {
+					const int16_t a = row[2 * p], b = row[2 * p + 1];
+					/* v and ~v have the same width in two's complement; bit 15 of the OR marks "not zero" for a lone -1 */
+					need[p] |= (uint16_t)((a ^ (a >> 15)) | (b ^ (b >> 15)) | ((a | b) ? 0x8000 : 0));
+				}
+			}
+			for (auto &o : order)
+				o.clear();
+			for (uint32_t p = 0; p < g.pairs; p++) {
+				const uint16_t m = need[p] & 0x7FFF;
+				const uint32_t kind = !need[p] ? ACMHIP_PK_ZERO : m < 8 ? ACMHIP_PK_NIBBLE : m < 128 ? ACMHIP_PK_BYTE : ACMHIP_PK_WORD;
+				order[kind].push_back((uint16_t)p);
+			}
+			for (uint32_t kind = ACMHIP_PK_WORD; kind >= ACMHIP_PK_ZERO; kind--) {
+				const std::vector<uint16_t> &o = order[kind];
+				const uint32_t ub = unit_bytes(kind);
+				for (size_t at = 0; at < o.size(); at += g.rpc) {
+					const uint32_t count = (uint32_t)std::min<size_t>(g.rpc, o.size() - at);
+					if ((blob_base + nb) / 16 > 0xFFFFFFFFull || dealt >= g.slots)
+						return ACMHIP_ERR_ARG;          /* more than 64 GB of blobs in one arena (the slots cannot run out: acm_kernels.hip MAXCHUNKS) */
+					acmhip_packed_chunk &c = tc[(dealt % g.waves) * g.per_wave + dealt / g.waves];
+					dealt++;
+					c.blob_off16 = (uint32_t)((blob_base + nb) / 16);
+					c.count = (uint16_t)count;
+					c.kind = (uint8_t)kind;
+					c.row0 = (uint8_t)(grp * g.group_rows);
+					uint8_t *out = blob + nb;
+					uint16_t *perm = reinterpret_cast<uint16_t *>(out);
+					for (uint32_t k = 0; k < g.rpc; k++)
+						perm[k] = k < count ? (uint16_t)lds_place(g, o[at + k]) : 0;
+					uint8_t *units = out + g.permb;
+					for (uint32_t k = 0; k < count && ub; k++) {
+						const uint32_t p = o[at + k];
+						for (uint32_t q = 0; q < g.nq; q++) {
+							uint32_t *u = reinterpret_cast<uint32_t *>(units + ((size_t)k * g.nq + q) * ub);
+							/* the unit's rows: q, q + nq, q + 2 nq, q + 3 nq of the group */
+							const int16_t *r0 = rows + ((uint64_t)q << level) + 2 * p;
+							int16_t v[8];
+							for (uint32_t i = 0; i < 4; i++) {
+								v[2 * i] = r0[(uint64_t)(i * g.nq) << level];
+								v[2 * i + 1] = r0[((uint64_t)(i * g.nq) << level) + 1];
+							}
+							if (kind == ACMHIP_PK_WORD) {
+								for (uint32_t i = 0; i < 4; i++)
+									u[i] = (uint32_t)(uint16_t)v[2 * i] | (uint32_t)(uint16_t)v[2 * i + 1] << 16;
+							} else if (kind == ACMHIP_PK_BYTE) {
+								for (uint32_t i = 0; i < 2; i++)
+									u[i] = (uint32_t)(uint8_t)v[4 * i] | (uint32_t)(uint8_t)v[4 * i + 1] << 8 |
+									       (uint32_t)(uint8_t)v[4 * i + 2] << 16 | (uint32_t)(uint8_t)v[4 * i + 3] << 24;
+							} else {
+								uint32_t w = 0;
+								for (uint32_t i = 0; i < 8; i++)
+									w |= ((uint32_t)v[i] & 15u) << (4 * i);
+								u[0] = w;
+							}
+						}
+					}
+					const uint64_t used = g.permb + (uint64_t)count * g.nq * ub;
+					const uint64_t padded = round16(used);
+					memset(out + used, 0, padded - used);
+					nb += padded;
+				}
+			}
+		}
+	}
+	memset(blob + nb, 0, kReadSlack);
+	nb += kReadSlack;
+	if (blob_bytes_out)
+		*blob_bytes_out = nb;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_unpack_tile(uint32_t level, const acmhip_packed_chunk *tile_chunks, const uint8_t *blob, int16_t *idx)
+{
+	Geo g;
+	if (!geo_of(level, &g) || !tile_chunks || !blob || !idx)
+		return ACMHIP_ERR_ARG;
+	/* every (row, column) must be written exactly once */
+	const size_t n = (size_t)g.tile_rows << level;
+	std::vector<uint8_t> seen(n, 0);
+	std::vector<int32_t> pair_of(lds_place(g, g.pairs - 1) + 1, -1);
+	for (uint32_t p = 0; p < g.pairs; p++)
+		pair_of[lds_place(g, p)] = (int32_t)p;
+	for (uint32_t c = 0; c < g.slots; c++) {
+		const acmhip_packed_chunk &ch = tile_chunks[c];
+		if (ch.kind == 0)
+			continue;
+		if (ch.kind > ACMHIP_PK_WORD || ch.count == 0 || ch.count > g.rpc || ch.row0 % g.group_rows || ch.row0 + g.group_rows > g.tile_rows)
+			return ACMHIP_ERR_ARG;
+		const uint8_t *in = blob + (uint64_t)ch.blob_off16 * 16;
+		const uint16_t *perm = reinterpret_cast<const uint16_t *>(in);
+		const uint32_t ub = unit_bytes(ch.kind);
+		for (uint32_t k = 0; k < ch.count; k++) {
+			if (perm[k] >= pair_of.size() || pair_of[perm[k]] < 0)
+				return ACMHIP_ERR_ARG;
+			const uint32_t p = (uint32_t)pair_of[perm[k]];
+			for (uint32_t q = 0; q < g.nq; q++) {
+				const uint32_t *u = reinterpret_cast<const uint32_t *>(in + g.permb + ((size_t)k * g.nq + q) * ub);
+				int16_t v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+				if (ch.kind == ACMHIP_PK_WORD) {
+					for (uint32_t i = 0; i < 4; i++) {
+						v[2 * i] = (int16_t)(u[i] & 0xFFFF);
+						v[2 * i + 1] = (int16_t)(u[i] >> 16);
+					}
+				} else if (ch.kind == ACMHIP_PK_BYTE) {
+					for (uint32_t i = 0; i < 8; i++)
+						v[i] = (int8_t)(u[i / 4] >> (8 * (i % 4)));
+				} else if (ch.kind == ACMHIP_PK_NIBBLE) {
+					for (uint32_t i = 0; i < 8; i++)
+						v[i] = (int16_t)((int32_t)(u[0] << (28 - 4 * i)) >> 28);
+				}
+				for (uint32_t i = 0; i < 8; i++) {
+					const size_t at = ((size_t)(ch.row0 + q + (i / 2) * g.nq) << level) + 2 * p + (i & 1);
+					if (seen[at])
+						return ACMHIP_ERR_ARG;
+					seen[at] = 1;
+					idx[at] = v[i];
+				}
+			}
+		}
+	}
+	for (size_t k = 0; k < n; k++)
+		if (!seen[k])
+			return ACMHIP_ERR_ARG;
+	return ACMHIP_OK;
+}
