@@ -64,9 +64,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other levels, D2D copy rate, end to end)")
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
-    ap.add_argument("--no-narrow", action="store_true",
-                    help="int16 staged indices only: do not give the plan the int8 copy of the tiles that fit a byte "
-                         "(acmhip_plan_attach_narrow; with it the line also carries the int16-only time of the same run)")
+    ap.add_argument("--packed", action="store_true",
+                    help="time the launches on the packed staged form (width class per column pair + packed residuals, "
+                         "include/acm_hip.h) instead of the int16 arena; without it the packed form is a side measurement")
+    ap.add_argument("--no-packed", action="store_true", help="skip the packed-form side measurement")
     ap.add_argument("--workload", choices=["uniform", "corpus"], default="uniform",
                     help="uniform = one shape for every stream (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
@@ -206,7 +207,7 @@ def copy_ceiling():
     return (round(gbs, 1), name.value.decode()) if gbs > 0 else None
 
 
-def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):
+def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):          # "acm_tile2" also matches the packed build, acm_tile2p
     """HBM bytes per launch of the tile kernel, measured on THIS box in THIS run: two child runs of this command under
     rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else enabled - MI355X_MICROARCH.md "HBM"),
     a handful of launches each with the same staged input.  FETCH_SIZE is doubled (gfx950 tallies its 128-byte requests at
@@ -220,7 +221,7 @@ def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu", "--no-extra", "--no-verify",
              "--streams", str(args.streams), "--level", str(args.level), "--rows", str(args.rows), "--blocks", str(args.blocks),
-             "--channels", str(args.channels)] + (["--no-narrow"] if args.no_narrow else [])
+             "--channels", str(args.channels)] + (["--packed"] if args.packed else ["--no-packed"])
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -407,21 +408,24 @@ def precondition(dev, plan, bufs, seconds):
     return n
 
 
-def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1, narrow=True):
+def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1, packed=True):
     """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11); the PCM the
-    timed launches leave behind is compared with the CPU oracle on the first `verify` streams (CRC-32 each)"""
+    timed launches leave behind is compared with the CPU oracle on the first `verify` streams (CRC-32 each).  Where the
+    level has a packed staged form the same plan is timed on it too (and its PCM checked the same way)."""
     import oracle_api as O
     from concurrent.futures import ThreadPoolExecutor
     b = workload.build_uniform(streams, level, rows, blocks, channels=channels, seed0=1 << 20, keep_files=verify)
     bufs = b.upload(dev)
-    plan = capi.Plan(dev, b.descs)
-    precondition(dev, plan, bufs, 0.2)
-    _, ms_wide = time_plan(dev, plan, bufs, steps, 5, lambda: None)
-    n_narrow = plan.attach_narrow(bufs[0]) if narrow else 0      # the verified PCM below is that of the launches with the int8 plane
-    _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None) if n_narrow else (None, ms_wide)
+    pk = pk_ptrs = None
+    if packed and capi.packed_tile_rows(level) > 0:
+        pk = capi.pack_streams(b.idx, b.descs, threads=workload.usable_cpus())
+        pk_ptrs = pk.upload(dev)
+    plan = capi.Plan(dev, b.descs, packed=pk.streams if pk else None)
     tiles = plan.stats().tiles
-    checked = 0
-    if b.files:
+
+    def check():
+        if not b.files:
+            return 0
         d_last = b.descs[len(b.files) - 1]
         host = np.empty(d_last.pcm_off + d_last.n_emit, dtype=np.uint16)
         dev.download(host, bufs[2])
@@ -435,16 +439,27 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
             ok = list(ex.map(one, range(len(b.files))))
         if not all(ok):
             raise RuntimeError("side measurement level %d: HIP output differs from the oracle on %d of %d streams" % (level, ok.count(False), len(ok)))
-        checked = len(ok)
+        return len(ok)
+    precondition(dev, plan, bufs, 0.2)
+    _, ms = time_plan(dev, plan, bufs, steps, 5, lambda: None)
+    checked = check()
+    out = {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "channels": channels, "steps": steps, "verified_streams": checked,
+           "tiles": int(tiles)}
+    rate = b.samples * steps / (ms * 1e-3)
+    out.update(msamples_s=round(rate / 1e6, 1), algo_gbs=round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
+               frac_hbm=round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4))
+    if pk is not None:
+        plan.bind_packed(*pk_ptrs)
+        dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+        _, pms = time_plan(dev, plan, bufs, steps, 5, lambda: None)
+        out["packed_form"] = {"frac_hbm": round(b.samples * ALGO_BYTES_PER_SAMPLE / (pms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "verified_streams": check(), "staged_bytes_per_sample": round(pk.nbytes / b.samples, 3)}
+        for p in pk_ptrs:
+            dev.free(p)
     plan.destroy()
     for p in bufs:
         dev.free(p)
-    rate = b.samples * steps / (ms * 1e-3)
-    return {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "steps": steps, "verified_streams": checked,
-            "msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
-            "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
-            "narrow_tiles": int(n_narrow), "tiles": int(tiles),
-            "int16_only_frac_hbm": round(b.samples * ALGO_BYTES_PER_SAMPLE / (ms_wide / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def main():
@@ -516,14 +531,22 @@ def main():
     else:
         pcm_t = None
         bufs = batch.upload(dev)
-    plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO)
-    # the narrow staged form (part of staging, untimed like the bit parsing): an int8 copy of the lean kernel's tiles, read
-    # instead of the int16 arena by the tiles whose indices fit a byte - the oracle check below runs with it attached
-    narrow = None
-    if not args.no_narrow and not args.stagewise:
+    # the packed staged form of the same streams (host stager: bit parser + packer, untimed like the parsing): bound for the
+    # headline launches only with --packed; otherwise timed as a side measurement behind them
+    pk = pk_ptrs = None
+    t_pack = None
+    want_packed = (args.packed or (not args.no_packed and not args.no_extra)) and not args.stagewise and args.workload == "uniform" \
+        and capi.packed_tile_rows(args.level) > 0
+    if want_packed:
         t0 = time.perf_counter()
-        plan.attach_narrow(bufs[0])
-        narrow = {"pack_seconds": round(time.perf_counter() - t0, 4)}
+        pk = capi.pack_streams(batch.idx, batch.descs, threads=stage_threads)
+        t_pack = time.perf_counter() - t0
+        pk_ptrs = pk.upload(dev)
+    elif args.packed:
+        raise SystemExit("bench.py: --packed needs a uniform workload of a level with a packed form (6-9)")
+    plan = capi.Plan(dev, batch.descs, flags=capi.PLAN_STAGEWISE if args.stagewise else capi.PLAN_AUTO, packed=pk.streams if pk else None)
+    if args.packed:
+        plan.bind_packed(*pk_ptrs)
     stats = plan.stats()
 
     # setup-time check (untimed): every stream of the workload against the CPU oracle, CRC-32 of its PCM
@@ -550,17 +573,26 @@ def main():
                      "msamples_s_per_gpu": round(batch.samples * SUSTAINED_STEPS / swall / 1e6, 1),
                      "frac": round(batch.samples * ALGO_BYTES_PER_SAMPLE / (sev / SUSTAINED_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # the same loop on the int16 arena alone, right behind (the int8 plane detached, then attached again)
-    if narrow is not None:
-        narrow.update(tiles=int(stats.narrow_tiles), tiles_with_rows_in_front=int(stats.narrow_front_tiles))
-        if stats.narrow_tiles and not args.no_extra:        # (profiling runs pass --no-extra: every launch they see is the headline's)
-            plan.attach_narrow(None)
-            nsteps = max(args.steps, min(SUSTAINED_STEPS, 100))
-            _, wev = time_plan(dev, plan, bufs, nsteps, 5, lambda: None)
-            plan.attach_narrow(bufs[0])
-            wms = wev / nsteps
-            narrow.update(int16_only_launch_ms=round(wms, 4), int16_only_steps=nsteps,
-                          int16_only_frac=round(batch.samples * ALGO_BYTES_PER_SAMPLE / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    # the same plan on the other staged form, right behind (every stream's PCM compared with the oracle's again)
+    other_form = None
+    if pk is not None and not args.no_extra:
+        nsteps = max(args.steps, min(SUSTAINED_STEPS, 100))
+        plan.bind_packed(*((None, None) if args.packed else pk_ptrs))
+        dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+        _, oev = time_plan(dev, plan, bufs, nsteps, 5, lambda: None)
+        oms = oev / nsteps
+        other_form = {"form": "int16 index per sample" if args.packed else "packed (class per column pair + packed residuals)",
+                      "launch_ms": round(oms, 4), "steps": nsteps,
+                      "frac": round(batch.samples * ALGO_BYTES_PER_SAMPLE / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "staged_bytes_per_sample_packed": round(pk.nbytes / batch.samples, 3), "host_pack_seconds": round(t_pack, 2)}
+        if want is not None:
+            got = device_crcs(dev, batch, bufs[2], stage_threads)
+            other_form["verified_streams"] = sum(1 for a_, b_ in zip(got, want) if a_ == b_)
+            if got != want:
+                raise SystemExit("bench.py: PCM of the %s differs from the oracle - refusing to report a number" % other_form["form"])
+        plan.bind_packed(*(pk_ptrs if args.packed else (None, None)))
+        plan.launch(*bufs)          # the headline form's PCM is what the final check below looks at
+        dev.sync()
 
     # what the chip's power and clock read while this kernel runs (untimed: 2 s of the same launches)
     power = None
@@ -631,14 +663,14 @@ def main():
     # collect counters on itself.  The file records the kernel source it was measured on; another source -> null.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r4_traffic.json")) as f:
             tj = json.load(f)
         key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
         if args.channels != 1:
             key += "_ch%d" % args.channels
         if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
             traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r3_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
+            traffic_src = "profiles/r4_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
     except Exception:
         traffic = None
 
@@ -650,6 +682,9 @@ def main():
             traffic = lt["hbm_bytes_per_launch"]
             traffic_src = ("measured in this run on this box: two child runs of this command under rocprofv3 --pmc (FETCH_SIZE x2, WRITE_SIZE; "
                            "%d / %d dispatches of the tile kernel, %.0f s)" % (lt["dispatches"][0], lt["dispatches"][1], lt["seconds"]))
+
+    # the same launch priced on the bytes it really moved (the roofline fraction above stays on the algorithmic 4 B/sample)
+    frac_measured = round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
 
     lv_txt = "7-9" if args.workload == "corpus" else args.level
     shape = (args.streams, args.level, args.rows, args.blocks, args.channels)
@@ -672,15 +707,15 @@ def main():
                    "samples_per_step_per_gpu": int(batch.samples), "sharding": "streams (independent), no collective",
                    "kernel": "stagewise" if args.stagewise else "acm_tile2 + acm_fused_tile", "tiles": int(stats.tiles),
                    "launches_per_step": int(stats.launches), "host_stage_seconds": round(t_stage, 2),
-                   "staged_form": "int16 index per sample + {val, pwr} per block" + (
-                       "; int8 copy of %d of the %d tiles (indices that fit a byte), packed on the device while staging" % (
-                           stats.narrow_tiles, stats.tiles) if narrow is not None else ""),
+                   "staged_form": ("packed: width class per column pair and 16-row group + residuals at 0/4/8/16 bits (%.3f B/sample), "
+                                   "{val, pwr} per block; written by the host stager (acmhip_pack_tiles)" % (pk.nbytes / batch.samples))
+                                  if args.packed else "int16 index per sample + {val, pwr} per block, written by the host stager (acm_stage_file)",
                    "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "traffic_committed_profile": traffic_committed,
+                     "traffic_committed_profile": traffic_committed, "frac_of_peak_on_measured_traffic": frac_measured,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": ("acm_tile2<TileCfg<%s,%d,%d>> (+ acm_fused_tile on ragged tails)" % ((lv_txt,) + K2_GEOMETRY.get(args.level, (256, 8192)))
+                     "kernel": ("acm_tile2%s<TileCfg<%s,%d,%d>> (+ acm_fused_tile on ragged tails)" % (("p" if args.packed else "", lv_txt) + K2_GEOMETRY.get(args.level, (256, 8192)))
                                 if args.workload == "corpus" or 6 <= args.level <= 14 else "see DESIGN.md section 2 for level %s" % lv_txt),
                      "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
     }
@@ -690,8 +725,8 @@ def main():
         out["per_rank"] = per_rank
         out["imbalance"] = {"launch_ms_max_over_mean": round(max(ms) / (sum(ms) / len(ms)), 4),
                             "samples_max_over_mean": round(max(sm) / (sum(sm) / len(sm)), 4)}
-    if narrow is not None:
-        out["narrow_tiles"] = narrow
+    if other_form is not None:
+        out["other_staged_form"] = other_form
     if sustained:
         out["sustained"] = sustained
     if power:
@@ -730,11 +765,16 @@ def main():
                 out["roofline"]["d2d_copy_error"] = str(e)[:120]
         if not args.no_extra and not args.stagewise:
             extra = []
-            for (lv, rw, bl, ns) in ((7, 16, 1000, 1024), (11, 64, 16, 1024)):      # same sample count as the headline batch
-                if (lv, rw, bl, ns) == (args.level, args.rows, args.blocks, args.streams):
+            # configs[1] and a level-11 batch with the headline's sample count; configs[4] at its full size (65 536 distinct stereo
+            # streams, 17.2 Gsamples, 34 GB of staged indices + 34 GB of PCM in HBM; ~1 min of staging)
+            for (lv, rw, bl, ns, ch) in ((7, 16, 1000, 1024, 1), (11, 64, 16, 1024, 1), (11, 64, 2, 65536, 2)):
+                if (lv, rw, bl, ns, ch) == (args.level, args.rows, args.blocks, args.streams, args.channels):
                     continue
                 try:
-                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, max(20, args.steps // 3), narrow=not args.no_narrow))
+                    steps = max(20, args.steps // 3) if ns <= 1024 else 10
+                    extra.append(side_measure(dev, capi, workload, lv, rw, bl, ns, steps, channels=ch, packed=not args.no_packed))
+                    if ns > 1024:
+                        extra[-1]["config"] = "BASELINE.json configs[4] at full size"
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
@@ -746,13 +786,20 @@ def main():
                 e2e = {"streams": len(files), "host_threads": workload_cpus()}
                 for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("device_parse", capi.PARSE_DEVICE, False),
                                         ("device_parse_pinned_out", capi.PARSE_DEVICE, True)):
-                    # pinned_out: the caller's PCM buffers are pinned (acmhip_host_alloc), read-back lands in them directly
-                    capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)          # first call sizes the arenas
-                    res, tm = capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
+                    # pinned_out: the caller's PCM buffers are pinned (acmhip_host_alloc), read-back lands in them directly.
+                    # The hosts of this pool are shared: single calls show 1.5-2 x outliers in any mode (profiles/pinned_out_probe.py,
+                    # VERDICT r3 Weak 5), so every leg is the best of three calls behind one that sizes the arenas, all totals kept
+                    capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
+                    runs = []
+                    for _ in range(1 if mode == capi.PARSE_HOST else 3):
+                        res, tm = capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
+                        runs.append((tm.total_s, tm))
+                        del res
+                    tm = min(runs, key=lambda r: r[0])[1]
                     e2e[name] = {"msamples_s": round(tm.samples / tm.total_s / 1e6, 1), "parse_s": round(tm.stage_s, 3),
                                  "h2d_s": round(tm.h2d_s, 3), "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
-                                 "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed}
-                    del res
+                                 "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed,
+                                 "total_s_every_call": [round(r[0], 3) for r in runs]}
                 out["end_to_end"] = e2e
             except Exception as e:
                 out["end_to_end"] = {"error": str(e)[:200]}
@@ -772,6 +819,8 @@ def main():
         print(json.dumps(out), flush=True)
 
     plan.destroy()
+    for p in pk_ptrs or ():
+        dev.free(p)
     if dist is not None:
         dev.free(bufs[0])
         dev.free(bufs[1])

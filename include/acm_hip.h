@@ -128,22 +128,6 @@ void acmhip_plan_destroy(acmhip_plan *plan);
 int  acmhip_plan_launch(acmhip_plan *plan, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
 			int16_t *d_pcm, unsigned fmt);
 
-/*
- * Narrow staged form.  Every k / t filler yields |index| <= 5 and a linear filler of up to 8 bits yields an index
- * that fits a byte (decode.c:181-476), so whole blocks of a stream often need 1 byte per index, not 2.  This call
- * reads the staged indices `d_idx` (as a later acmhip_plan_launch will get them), writes an int8 copy of every tile
- * the lean tile kernel takes into a plane the plan owns (as large as the staged arena the tiles cover) and notes,
- * for the rows each wavefront of the kernel owns, whether their indices all fit, and separately whether the two rows
- * in front of them (which it re-reads) do.  From then on acmhip_plan_launch WITH THE SAME d_idx reads the marked rows
- * from the int8 plane: half the index bytes and half the load instructions on them, identical PCM.  Call it again
- * after the staged indices change; d_idx = NULL detaches.  Blocks until the pack kernels are done.  The build of the
- * tile kernel that can read both planes costs 16-bit rows up to 3 % at some levels, so per level the plan uses it
- * only when enough rows are narrow to pay; *narrow_tiles (may be NULL) receives how many tiles' worth of rows WILL
- * be read from the int8 plane (acmhip_plan_stats.tiles counts all tiles).  A plan none of whose streams reaches the
- * lean kernel is left as it is.
- */
-int  acmhip_plan_attach_narrow(acmhip_plan *plan, const int16_t *d_idx, uint64_t *narrow_tiles);
-
 /* ------------------------------------------------------------------------
  * Packed staged form: filler class per column pair + fixed-width packed residuals
  * (BASELINE.json north_star: "per-block filler indices plus packed residuals").
@@ -217,8 +201,7 @@ typedef struct acmhip_plan_stats {
 	uint32_t fused_streams;  /* streams handled by a one-launch kernel (fused tile kernel, levels 5-12; register kernel, levels 0-4) */
 	uint32_t stagewise_streams;
 	uint32_t launches;       /* kernel launches per acmhip_plan_launch */
-	uint32_t narrow_tiles;   /* tiles' worth of rows the launches read from the int8 plane (acmhip_plan_attach_narrow; 0 while nothing is attached) */
-	uint32_t narrow_front_tiles;     /* ... of which the two rows in front are narrow too (no 16-bit load left for them) */
+	uint32_t reserved[2];
 	uint32_t packed_tiles;   /* tiles that have records of the packed build too (read in packed form while arenas are bound: acmhip_plan_bind_packed) */
 } acmhip_plan_stats;
 int  acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out);

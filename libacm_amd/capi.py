@@ -33,8 +33,8 @@ class StreamDesc(C.Structure):
 
 class PlanStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("tiles", C.c_uint64), ("fused_streams", C.c_uint32),
-                ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("narrow_tiles", C.c_uint32),
-                ("narrow_front_tiles", C.c_uint32), ("packed_tiles", C.c_uint32)]
+                ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("reserved", C.c_uint32 * 2),
+                ("packed_tiles", C.c_uint32)]
 
 
 class PackedChunk(C.Structure):
@@ -79,7 +79,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
-    "acmhip_plan_launch", "acmhip_plan_attach_narrow", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
+    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
@@ -130,7 +130,6 @@ def lib():
     L.acmhip_plan_destroy.argtypes = [vp]
     L.acmhip_plan_destroy.restype = None
     L.acmhip_plan_launch.argtypes = [vp, vp, vp, vp, C.c_uint]
-    L.acmhip_plan_attach_narrow.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.acmhip_plan_get_stats.argtypes = [vp, C.POINTER(PlanStats)]
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
     L.acm_stage_probe.argtypes = [vp, sz, C.c_int, C.POINTER(StageInfo)]
@@ -384,12 +383,6 @@ class Plan:
     def launch(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE):
         _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
 
-    def attach_narrow(self, d_idx):
-        """int8 copy of the lean kernel's tiles of the staged arena d_idx (None detaches) -> tiles' worth of rows that will be read from it"""
-        n = C.c_uint64()
-        _check(lib().acmhip_plan_attach_narrow(self.h, d_idx, C.byref(n)), "acmhip_plan_attach_narrow")
-        return n.value
-
     def time(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE, reps=1):
         ms = C.c_float()
         _check(lib().acmhip_plan_time(self.h, d_idx, d_hdr, d_pcm, fmt, reps, C.byref(ms)), "acmhip_plan_time")
@@ -449,10 +442,9 @@ class Arena:
         self.patches = (Patch * len(self.patch_list))(*self.patch_list) if self.patch_list else None
 
 
-def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, narrow=False, packed=False):
+def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, packed=False):
     """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream.
     patch_subset (tests): keep only these entries of the batch's H1 patch list.
-    narrow: attach the int8 form of the staged indices first (acmhip_plan_attach_narrow).
     packed: stage the packed form too (acmhip_pack_tiles) and bind it: whole tiles from row 0 are read from it."""
     ar = Arena(staged_list, windows)
     if patch_subset is not None and ar.patch_list:
@@ -474,8 +466,6 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
         plan = Plan(dev, ar.descs, ar.patches, flags, packed=pk.streams if pk else None)
         if pk:
             plan.bind_packed(*pk_ptrs)
-        if narrow:
-            plan.attach_narrow(d_idx)
         plan.launch(d_idx, d_hdr, d_pcm, fmt)
         out = np.zeros(ar.pcm_words, dtype=np.uint16)
         dev.download(out, d_pcm)

@@ -47,10 +47,6 @@ struct AcmTile2 {
 	uint32_t flags;        /* ACM_TILE_FRESH */
 };
 
-/* beside every AcmTile2 of a plan with an int8 plane (acm_pack_narrow): two bits per wave of the tile kernel's workgroup -
- * bit 2w: the rows wave w owns are read from the int8 plane, bit 2w + 1: so are the two rows in front of them */
-typedef uint32_t AcmTile2Modes;
-
 /* resolved H1 patch for the stage-wise path: scratch[dst] = value */
 struct AcmDevPatch {
 	uint64_t dst;
@@ -121,8 +117,8 @@ int acmk_launch_fused(uint32_t level, int variant, int cus, int carry, const Acm
 int acmk_tile2_rows(uint32_t level);                            /* rows per acm_tile2 tile, 0 if the level is not covered */
 int acmk_tile2_grid(uint32_t level, int cus);
 #define ACM_K2_SINK_BYTES 65536                               /* >= one tile of PCM: where lead-in tiles put theirs */
-int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Modes *d_modes, const uint8_t *d_idx8,
-		      const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
+int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int16_t *d_pcm,
+		      int16_t *d_sink, unsigned fmt, void *stream);
 /* the packed staged form (include/acm_hip.h): same tiles as acm_tile2 (records with idx_off = the tile's first entry in the chunk table and
  * hdr_blk / rowpos naming the block of tile row 0), stage-0 inputs unpacked from chunks of one width class each */
 int acmk_tile2p_rows(uint32_t level);                           /* rows per packed tile (= acmk_tile2_rows), 0 if the level has no packed build */
@@ -132,14 +128,6 @@ int acmk_tile2p_waves(uint32_t level);
 int acmk_tile2p_pad_shift(uint32_t level);                      /* the tile's LDS rows carry one pad dword per 2^shift elements */
 int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob,
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
-/* which narrow build acm_tile2 has at this level: 1 = as fast on wide tiles as the int16-only build, 2 = about 3 % slower on them
- * (one copy of the first pass with a branch per row pair: three copies do not fit the register file), 0 = none */
-int acmk_tile2_narrow_form(uint32_t level);
-int acmk_tile2_waves(uint32_t level);                           /* waves per workgroup of the level's acm_tile2 build */
-/* fills the int8 plane for every tile of the table and writes the mode words; d_count[0] += waves narrow with the two rows in
- * front of them, d_count[1] += waves narrow behind rows that are not (acmk_tile2_waves(level) waves per tile) */
-int acmk_launch_pack_narrow(uint32_t level, const AcmTile2 *d_tiles, AcmTile2Modes *d_modes, uint32_t ntiles, const int16_t *d_idx, uint8_t *d_idx8,
-			    uint32_t *d_count, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);
 int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,

@@ -62,8 +62,6 @@ struct LevelGroup {
 	uint32_t ntiles = 0;
 	bool carry = false;         /* tile table cut for the carry-mode kernel (no halo rows, ACM_TILE_* flags) */
 	AcmTile2 *d_tiles2 = nullptr;   /* whole tiles of streams decoded from row 0: the lean kernel (acm_tile2) */
-	AcmTile2Modes *d_modes2 = nullptr;      /* beside them once an int8 plane is attached (acmhip_plan_attach_narrow) */
-	bool use_narrow = false;        /* ... and enough of the tiles are narrow for the narrow build of the kernel to pay */
 	uint32_t ntiles2 = 0;
 	/* the whole tiles of the streams that came with a packed form: as records of the packed build (acm_tile2p; idx_off = packed tile
 	 * number) and as plain acm_tile2 records over the int16 arena, which a launch uses while no packed arenas are bound */
@@ -84,12 +82,6 @@ struct acmhip_plan {
 	AcmDevStream *d_streams = nullptr;
 	std::vector<LevelGroup> fused, stagewise, small, prefix;   /* small: levels 0-4, one register-cascade launch; prefix: levels 13-15 */
 	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
-	/* narrow staged form (acmhip_plan_attach_narrow): the int8 plane of the lean kernel's tiles, the staged arena it was
-	 * packed from (launches on any other arena read int16 only) and the extent of that arena the tiles cover */
-	uint8_t *d_idx8 = nullptr;
-	const int16_t *narrow_src = nullptr;
-	uint64_t narrow_extent = 0;            /* int16 units */
-	uint32_t *d_narrow_count = nullptr;
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
 	uint64_t sw_max_elems = 0;
@@ -394,7 +386,6 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	for (auto &g : plan->fused) {
 		(void)hipFree(g.d_tiles);
 		(void)hipFree(g.d_tiles2);
-		(void)hipFree(g.d_modes2);
 		(void)hipFree(g.d_tiles2p);
 		(void)hipFree(g.d_tiles2p_plain);
 		(void)hipFree(g.d_tiles_extra);
@@ -413,8 +404,6 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		if (e)
 			(void)hipEventDestroy(e);
 	(void)hipFree(plan->d_sink);
-	(void)hipFree(plan->d_idx8);
-	(void)hipFree(plan->d_narrow_count);
 	(void)hipFree(plan->d_sw_all);
 	(void)hipFree(plan->d_patches);
 	(void)hipFree(plan->d_plane[0]);
@@ -745,8 +734,6 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			}
 			if (k2 && rc == ACMHIP_OK) {
 				g.ntiles2 = (uint32_t)tiles2[lv].size();
-				for (const AcmTile2 &t2 : tiles2[lv])
-					pl->narrow_extent = std::max<uint64_t>(pl->narrow_extent, t2.idx_off + ((uint64_t)acmk_tile2_rows(lv) << lv));
 				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
 				st.tiles += g.ntiles2;
 				st.launches += g.ntiles2 ? 1 : 0;
@@ -875,12 +862,11 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	for (const LevelGroup &g : pl->fused) {
 		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
 		gi++;
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, g.use_narrow && d_idx == pl->narrow_src ? g.d_modes2 : nullptr, pl->d_idx8,
-					    d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		if (pl->pk_chunks)
 			LAUNCHTRY(acmk_launch_tile2p(g.level, pl->dev->cus, g.d_tiles2p, g.ntiles2p, pl->pk_chunks, pl->pk_blob, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		else
-			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, nullptr, nullptr, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}
@@ -937,62 +923,6 @@ extern "C" int acmhip_plan_bind_packed(acmhip_plan *pl, const acmhip_packed_chun
 	}
 	pl->pk_chunks = d_chunks;
 	pl->pk_blob = d_blob;
-	return ACMHIP_OK;
-}
-
-extern "C" int acmhip_plan_attach_narrow(acmhip_plan *pl, const int16_t *d_idx, uint64_t *narrow_tiles)
-{
-	if (!pl)
-		return ACMHIP_ERR_ARG;
-	HIPTRY(hipSetDevice(pl->dev->ordinal));
-	pl->narrow_src = nullptr;
-	pl->stats.narrow_tiles = pl->stats.narrow_front_tiles = 0;
-	for (LevelGroup &g : pl->fused)
-		g.use_narrow = false;
-	if (narrow_tiles)
-		*narrow_tiles = 0;
-	if (!d_idx || pl->narrow_extent == 0)
-		return ACMHIP_OK;                       /* detached / nothing the lean kernel takes */
-	const size_t ngroups = pl->fused.size();
-	if (!pl->d_idx8)
-		HIPTRY(hipMalloc((void **)&pl->d_idx8, pl->narrow_extent * 2));         /* the int16 arena's pitch: every other row pair's worth unused */
-	if (!pl->d_narrow_count)
-		HIPTRY(hipMalloc((void **)&pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t)));
-	hipStream_t st = pl->dev->stream;
-	HIPTRY(hipMemsetAsync(pl->d_narrow_count, 0, ngroups * 2 * sizeof(uint32_t), st));
-	for (size_t k = 0; k < ngroups; k++) {
-		LevelGroup &g = pl->fused[k];
-		if (g.ntiles2 && !g.d_modes2)
-			HIPTRY(hipMalloc((void **)&g.d_modes2, (size_t)g.ntiles2 * sizeof(AcmTile2Modes)));
-		LAUNCHTRY(acmk_launch_pack_narrow(g.level, g.d_tiles2, g.d_modes2, g.ntiles2, d_idx, pl->d_idx8, pl->d_narrow_count + 2 * k, (void *)st));
-	}
-	std::vector<uint32_t> count(ngroups * 2, 0);
-	HIPTRY(hipMemcpyAsync(count.data(), pl->d_narrow_count, ngroups * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	HIPTRY(hipStreamSynchronize(st));
-	/* Does the narrow build of the kernel pay for this group?  Where it is as fast as the int16-only build on wide tiles
-	 * (three copies of the first pass: levels 6-9 and 13) as soon as a few tiles are narrow; where it is ~3 % slower on
-	 * them (levels 10-12 and 14, narrow rows there are ~8 % faster) from a third of the waves on.  ACM_NARROW=1 / 0
-	 * forces it on for every group with a narrow wave / off (measurements) */
-	const char *force = getenv("ACM_NARROW");
-	for (size_t k = 0; k < ngroups; k++) {
-		LevelGroup &g = pl->fused[k];
-		/* the kernel decides wave by wave (acm_tile2): counted in waves, reported in tiles' worth of them */
-		const uint64_t nw = (uint64_t)std::max(1, acmk_tile2_waves(g.level)), waves = nw * g.ntiles2;
-		const uint64_t both = count[2 * k], narrow = both + count[2 * k + 1];
-		if (force)
-			g.use_narrow = atoi(force) != 0 && narrow > 0;
-		else if (acmk_tile2_narrow_form(g.level) == 1)
-			g.use_narrow = narrow * 50 >= waves && narrow > 0;
-		else
-			g.use_narrow = (both + narrow) * 3 >= 2ull * waves && narrow > 0;       /* a wave narrow only in its own rows counts half */
-		if (g.use_narrow) {
-			pl->stats.narrow_tiles += (uint32_t)(narrow / nw);
-			pl->stats.narrow_front_tiles += (uint32_t)(both / nw);
-		}
-	}
-	pl->narrow_src = d_idx;
-	if (narrow_tiles)
-		*narrow_tiles = pl->stats.narrow_tiles;
 	return ACMHIP_OK;
 }
 

@@ -419,8 +419,8 @@ __device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t
 #undef ACM_SDWA_MUL
 }
 
-/* narrow rows (acm_tile2's int8 plane): one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1), (row + 1, col),
- * (row + 1, col + 1) - and SDWA picks and sign-extends the byte inside the multiply, as it does with the 16-bit words */
+/* byte units of the packed staged form (acm_tile2p): one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1),
+ * (row + 1, col), (row + 1, col + 1) - and SDWA picks and sign-extends the byte inside the multiply, as it does with the 16-bit words */
 __device__ __forceinline__ void mul_idx8_val(const uint32_t r, const int32_t val0, const int32_t val1, uint32_t &r0c0, uint32_t &r0c1,
 					     uint32_t &r1c0, uint32_t &r1c1)
 {
@@ -699,14 +699,9 @@ struct FirstPass {
 	}
 
 	/* rowval[lr + 2] = +-val of tile row lr (pre-scaled), 0 for rows that do not exist (also lr = -2, -1) */
-	/* NARROW (acm_tile2's narrow rows): 0 = 16-bit indices, 1 = the row pairs are 2 x 2 byte blocks, 2 = the warm-up body
-	 * is 16-bit, the tile's own bodies are byte blocks, 3 = whatever narrow_warm / narrow_body say at run time.
-	 * acm_tile2 picks one of three compile-time instantiations per tile and wave where that fits the register file: with the unpack
-	 * behind a run-time branch per body the first pass of a WIDE tile is 3 % slower (the scheduler no longer interleaves
-	 * unpack and butterflies) */
-	template <bool CARRY = false, int NARROW = 0>
+	template <bool CARRY = false>
 	static __device__ __forceinline__ void compute(const uint32_t (&raw)[NREG], uint32_t *tile, const int32_t *rowval,
-						       const int row_first, const int tid, const bool narrow_warm = false, const bool narrow_body = false)
+						       const int row_first, const int tid)
 	{
 		constexpr int LR_MIN = CARRY ? -2 : 0;          /* carry mode: the two rows above the tile carry weight */
 		const int seg = tid / TPS;
@@ -735,11 +730,6 @@ struct FirstPass {
 #pragma unroll
 					for (int u = 0; u < BODY; u++)
 						v[w][u] = raw[w * NRAW + (b + (WARM ? 1 : 0)) * BODY + u] & (uint32_t)(u < U ? v0 : v1);
-			} else if (W == 2 && !PLANE && (NARROW == 3 ? (b < 0 ? narrow_warm : narrow_body) : (b < 0 ? NARROW == 1 : NARROW >= 1))) {
-				/* narrow rows (wave-uniform): register (body, q) = int8 indices of this lane's two columns in both rows of the body */
-#pragma unroll
-				for (int q = 0; q < U; q++)
-					mul_idx8_val(raw[(b + (WARM ? 1 : 0)) * BODY + q], v0, v1, v[0][q], v[W - 1][q], v[0][U + q], v[W - 1][U + q]);
 			} else if constexpr (W == 2 && U % 4 == 0) {
 #pragma unroll
 				for (int u = 0; u < BODY; u += 4) {
@@ -1234,7 +1224,7 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
  * waves per SIMD), so the tile loop is written for instruction count: 32 KB tiles at four workgroups per CU, all
  * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
  */
-template <class C, int G, int W, int ABL = 0, int NAR = 0>
+template <class C, int G, int W, int ABL = 0>
 struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segment, the first one included, re-runs the two rows in front of it */
 	using FP = FirstPass<C, G, W, ABL, true>;
 	static constexpr int L = C::L, COLS = C::COLS, U = FP::U, BODY = FP::BODY, SIGMA = FP::SIGMA, NB = FP::NB, NRAW = FP::NRAW;
@@ -1250,11 +1240,9 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	 * whose two rows in front do not exist (they are read from rows 0..1 instead and weigh 0).
 	 * The loads are issued by hand (see k2_wait): one SGPR base, one VGPR offset, compile-time immediates. */
 	template <int K>
-	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-							const uint32_t voff_warm)
+	static __device__ __forceinline__ void load_one(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 		constexpr int b = K / BODY - 1, half = (K % BODY) / U, q = K % U;
-		const uint8_t *const base = b < 0 ? base_warm : base_body;
 		constexpr int off = (((2 * (b + 1) + half) * COLS) + q * SIGMA) * 2;
 		constexpr int imm = off % 4096, far = off - imm;        /* 12 bits in the instruction, the rest on the scalar base */
 		if (ABL & 1)                            /* timing-only build: no HBM loads */
@@ -1262,76 +1250,17 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 		else
 			asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(raw[K]) : "v"(b < 0 ? voff_warm : voff), "s"(base + far), "n"(imm) : "memory");
 	}
-	/* Narrow rows (acm_tile2's mode word says which, wave by wave): their indices fit a byte and sit in the
-	 * int8 plane in 2 x 2 blocks - the dword at the byte offset the int16 plane has for (row 2p, columns 2j, 2j + 1) holds
-	 * rows 2p, 2p + 1 x columns 2j, 2j + 1 - so the load of a body's FIRST row, from the other base, brings both rows, and
-	 * the loads of its second row are skipped: half the loads, half the bytes, the same instructions.
-	 * The skip is a scalar branch INSIDE the asm statement that holds a body's second-row loads: every register has one
-	 * definition on every path, so the compiler has nothing to merge where the paths meet (a merge is a copy, and a copy
-	 * of a register whose load is in flight copies the old content: tests/test_isa_invariants.py). */
-	template <int B, int Q>
-	static constexpr int off2() { return (((2 * B + 1) * COLS) + Q * SIGMA) * 2; }       /* body B (0 = the warm-up), second row, column group Q */
-	template <int B, int... Qs>
-	static __device__ __forceinline__ void load_second_row_plain(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, std::integer_sequence<int, Qs...>)
+	template <int... Ks>
+	static __device__ __forceinline__ void load_all(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm,
+							std::integer_sequence<int, Ks...>)
 	{
-		(load_one<B * BODY + U + Qs>(raw, base, base, vo, vo), ...);
+		(load_one<Ks>(raw, base, voff, voff_warm), ...);
 	}
-	/* flags: the tile's mode word (AcmTile2Modes); bit: this wave's body / warm-up bit in it - set = the row pair is one load */
-	template <int B>
-	static __device__ __forceinline__ void load_second_row(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t vo, const uint32_t flags,
-							       const uint32_t bit)
-	{
-		static_assert(U == 4 || U == 8, "a first pass of two or three stages");
-		constexpr int K = B * BODY + U;
-		if constexpr (!NAR) {            /* the build for plans without an int8 plane: no branch */
-			load_second_row_plain<B>(raw, base, vo, std::make_integer_sequence<int, U>{});
-			return;
-		}
-#define ACM_LD2(N) "global_load_dword %" #N ", %[vo], %[b" #N "] offset:%[i" #N "]\n\t"
-#define ACM_IN2(N) [b##N] "s"(base + (off2<B, N>() - off2<B, N>() % 4096)), [i##N] "n"(off2<B, N>() % 4096)
-		if constexpr (ABL & 1) {
-#pragma unroll
-			for (int q = 0; q < U; q++)
-				raw[K + q] = vo + q;
-		} else if constexpr (U == 4) {
-			asm volatile("s_bitcmp1_b32 %[fl], %[bit]\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ".Lacm_narrow%=:"
-				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3])
-				     : [vo] "v"(vo), [fl] "s"(flags), [bit] "s"(bit), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3)
-				     : "memory", "scc");
-		} else {
-			asm volatile("s_bitcmp1_b32 %[fl], %[bit]\n\ts_cbranch_scc1 .Lacm_narrow%=\n\t" ACM_LD2(0) ACM_LD2(1) ACM_LD2(2) ACM_LD2(3) ACM_LD2(4)
-				     ACM_LD2(5) ACM_LD2(6) ACM_LD2(7) ".Lacm_narrow%=:"
-				     : "=&v"(raw[K]), "=&v"(raw[K + 1]), "=&v"(raw[K + 2]), "=&v"(raw[K + 3]), "=&v"(raw[K + 4]), "=&v"(raw[K + 5]),
-				       "=&v"(raw[K + 6]), "=&v"(raw[K + 7])
-				     : [vo] "v"(vo), [fl] "s"(flags), [bit] "s"(bit), ACM_IN2(0), ACM_IN2(1), ACM_IN2(2), ACM_IN2(3), ACM_IN2(4), ACM_IN2(5),
-				       ACM_IN2(6), ACM_IN2(7)
-				     : "memory", "scc");
-		}
-#undef ACM_LD2
-#undef ACM_IN2
-	}
-	template <int B, int... Qs>
-	static __device__ __forceinline__ void load_first_row(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-							      const uint32_t voff_warm, std::integer_sequence<int, Qs...>)
-	{
-		(load_one<B * BODY + Qs>(raw, base_warm, base_body, voff, voff_warm), ...);
-	}
-	template <int... Bs>
-	static __device__ __forceinline__ void load_bodies(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-							   const uint32_t voff_warm, const uint32_t modes, const uint32_t warm_bit, const uint32_t body_bit,
-							   std::integer_sequence<int, Bs...>)
-	{
-		((load_first_row<Bs>(raw, base_warm, base_body, voff, voff_warm, std::make_integer_sequence<int, U>{}),
-		  load_second_row<Bs>(raw, Bs == 0 ? base_warm : base_body, Bs == 0 ? voff_warm : voff, modes, Bs == 0 ? warm_bit : body_bit)), ...);
-	}
-	/* the warm-up body (the two rows in front of every segment) and the wave's own bodies choose their plane separately: rows
-	 * that fit a byte may follow rows that do not (bits warm_bit / body_bit of the tile's mode word).
-	 * Rows are asked for in address order */
-	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base_warm, const uint8_t *base_body, const uint32_t voff,
-						    const uint32_t voff_warm, const uint32_t modes, const uint32_t warm_bit, const uint32_t body_bit)
+	/* rows are asked for in address order */
+	static __device__ __forceinline__ void load(uint32_t (&raw)[NRAW], const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
 		static_assert(W == 2, "two adjacent columns per lane");
-		load_bodies(raw, base_warm, base_body, voff, voff_warm, modes, warm_bit, body_bit, std::make_integer_sequence<int, NB + 1>{});
+		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
 	}
 };
 
@@ -1360,16 +1289,14 @@ __device__ __forceinline__ void k2_wait()
 	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
 }
 
-/* NAR: 0 = int16 arena only; 1, 2 = the build for plans with an int8 plane (narrow rows), with three copies of the first pass /
- * with one copy that branches per body (FirstPass::compute) */
-template <class C, int WPS, int ABL, int NAR, int G0, int... Gs>
+template <class C, int WPS, int ABL, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
-acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const AcmTile2Modes *__restrict__ modes,
-	  const uint8_t *__restrict__ idx8, const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
+	  int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
-	using FP = FirstPass2<C, G0, 2, ABL, NAR>;
+	using FP = FirstPass2<C, G0, 2, ABL>;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
 
@@ -1420,41 +1347,13 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
-	/* Narrow rows (the NAR build, launched when the plan has an int8 plane: acm_pack_narrow wrote a mode word beside every
-	 * record, two bits per WAVE of this workgroup - bit 2w: the rows wave w owns fit a byte and are read from the int8 plane,
-	 * bit 2w + 1: so are the two rows in front of them, which the wave's first segment re-reads as its warm-up (the last two
-	 * of the wave before, or of the tile before).  The int8 plane has the int16 arena's pitch: a tile's place in it is its
-	 * place in the arena + (idx8 - idx), FirstPass2::load).  A wave is the unit because the choice must be wave-uniform;
-	 * per wave rather than per tile, because at the lower levels a tile is several blocks of the stream (level 7, 16 rows
-	 * per block: a wave's rows are exactly one block) and a block's indices are narrow or not as a whole.
-	 * Narrow rows behind rows that are not: the wave reads its warm-up rows from the int16 arena - every segment's, so
-	 * those of its later segments come from HBM a second time, in 16 bits; acm_pack_narrow allows that for waves of at most
-	 * two segments (level 9 on; with more the wave stays wide).  Reading EVERY warm-up row of a tile wide was measured:
-	 * slower than a wide tile.  All of it is scalar work, and little: every instruction here is an issue slot of a kernel
-	 * that has none to spare (a dozen more per tile cost the wide tiles 3 %) */
-	const uint32_t body_bit = 2u * (((uint32_t)__builtin_amdgcn_readfirstlane(tid) >> 6) & 15u), warm_bit = body_bit + 1u;
-	auto body_narrow = [&](const uint32_t m) -> bool { return NAR && ((m >> body_bit) & 1u) != 0; };
-	auto warm_narrow = [&](const uint32_t m) -> bool { return NAR && ((m >> warm_bit) & 1u) != 0; };
 	auto sgpr_ptr = [&](const uint64_t a) -> const uint8_t * {
 		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
 		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
 		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
 	};
-	auto fetch_modes = [&](const uint32_t k) -> uint32_t {
-		if constexpr (NAR)
-			return modes[__builtin_amdgcn_readfirstlane(k)];
-		else
-			return 0u;
-	};
-	const uint64_t to8 = NAR ? reinterpret_cast<uint64_t>(idx8) - reinterpret_cast<uint64_t>(idx) : 0;
-	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r, const uint32_t m) {
-		const uint64_t a = reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS);
-		if constexpr (NAR) {
-			FP::load(raw, sgpr_ptr(a + (warm_narrow(m) ? to8 : 0)), sgpr_ptr(a + (body_narrow(m) ? to8 : 0)), voff, warm_off(r), m, warm_bit, body_bit);
-		} else {
-			const uint8_t *const base = sgpr_ptr(a);
-			FP::load(raw, base, base, voff, warm_off(r), 0u, 0u, 0u);
-		}
+	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r) {
+		FP::load(raw, sgpr_ptr(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS)), voff, warm_off(r));
 	};
 
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;      /* 16-byte PCM stores per thread and tile */
@@ -1464,8 +1363,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
 	uint32_t raw[FP::NRAW];
 	uint32_t hv = fetch_val(cur);
-	uint32_t mcur = fetch_modes(t);
-	load_tile(raw, cur, mcur);
+	load_tile(raw, cur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1477,7 +1375,6 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records come through the scalar cache one iteration ahead (asked for behind the PCM stores, used after the
 	 * next first pass); the last tile of a run names itself as its successor */
 	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
-	uint32_t mnxt = fetch_modes(t + 1 < t_end ? t + 1 : t);
 	for (;;) {
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
@@ -1490,14 +1387,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		if constexpr (NAR == 2)
-			FP::template compute<true, 3>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid, warm_narrow(mcur), body_narrow(mcur));
-		else if (!body_narrow(mcur))
-			FP::template compute<true, 0>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
-		else if (warm_narrow(mcur))
-			FP::template compute<true, 1>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
-		else
-			FP::template compute<true, 2>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -1505,7 +1395,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(2);
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
-		load_tile(raw, nxt, mnxt);
+		load_tile(raw, nxt);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
@@ -1543,8 +1433,6 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		cur = nxt;
 		t = tn;
 		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
-		mcur = mnxt;
-		mnxt = fetch_modes(t + 1 < t_end ? t + 1 : t);
 		buf ^= 1;
 	}
 #ifdef ACM_STAMPS
@@ -1555,34 +1443,25 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 }
 
 struct Tile2Entry {
-	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const AcmTile2Modes *, const uint8_t *, const acmhip_blkhdr *, int16_t *, int16_t *,
-			   unsigned);
-	Fn fn;                  /* int16 arena only */
-	Fn fn_narrow;           /* the build that reads the rows the mode words mark from the int8 plane (a dozen more scalar instructions per tile) */
+	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	Fn fn;
 	int threads, tile_rows, wg_per_cu;
-	int narrow_form;        /* acm_tile2's NAR of fn_narrow */
-	int tps, rps;           /* first pass: threads and rows per segment (acm_pack_narrow works out which rows a wave owns) */
 };
-template <int G0, int...>
-constexpr int first_group() { return G0; }
-/* NARFORM: which narrow build (acm_tile2's NAR) fits 128 registers at this geometry */
-template <class C, int NARFORM, int... Gs>
+template <class C, int... Gs>
 constexpr Tile2Entry entry_k2()
 {
-	return Tile2Entry{ acm_tile2<C, 4, 0, 0, Gs...>, acm_tile2<C, 4, 0, NARFORM, Gs...>, C::NT, C::TR, 1024 / C::NT, NARFORM,
-			   FirstPass2<C, first_group<Gs...>(), 2>::FP::TPS, FirstPass2<C, first_group<Gs...>(), 2>::FP::RPS };
+	return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT };
 }
 /* bigger tiles: WPC workgroups per CU */
-template <class C, int WPC, int NARFORM, int... Gs>
+template <class C, int WPC, int... Gs>
 constexpr Tile2Entry entry_k2w()
 {
-	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, 0, Gs...>, acm_tile2<C, WPC * C::NT / 256, 0, NARFORM, Gs...>, C::NT, C::TR, WPC, NARFORM,
-			   FirstPass2<C, first_group<Gs...>(), 2>::FP::TPS, FirstPass2<C, first_group<Gs...>(), 2>::FP::RPS };
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC };
 }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 0, 3, 3, 3>, nullptr, 256, 16, 4, 0, 32, 2 }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
@@ -1596,22 +1475,22 @@ const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
  * equal; level 9 as 64 KB tiles of 512 threads -0.4 %; level 10 (2,3,3,2) -1.5 %, (2,2,3,3) -2.5 %, 64 KB tiles -1.5 %;
  * level 11 as 64 KB tiles of 512 threads, two per CU, (2,3,3,3): -2.7 %, which had been the best without priorities) */
 const Tile2Entry g_tile2[ACM_K2_MAX_LEVEL - ACM_K2_MIN_LEVEL + 1] = {
-	entry_k2<TileCfg<6, 256, 8192>, 1, 2, 2, 2>(),
-	entry_k2<TileCfg<7, 256, 8192>, 1, 3, 2, 2>(),
-	entry_k2<TileCfg<8, 256, 8192>, 1, 3, 3, 2>(),
-	entry_k2<TileCfg<9, 256, 8192>, 1, 3, 3, 3>(),
-	entry_k2<TileCfg<10, 256, 8192>, 2, 3, 3, 2, 2>(),      /* narrow builds of levels 10-12 and 14: three copies of the first pass spill 5-11 registers */
-	entry_k2<TileCfg<11, 256, 8192>, 2, 3, 3, 3, 2>(),
-	entry_k2w<TileCfg<12, 512, 16384>, 2, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
+	entry_k2<TileCfg<6, 256, 8192>, 2, 2, 2>(),
+	entry_k2<TileCfg<7, 256, 8192>, 3, 2, 2>(),
+	entry_k2<TileCfg<8, 256, 8192>, 3, 3, 2>(),
+	entry_k2<TileCfg<9, 256, 8192>, 3, 3, 3>(),
+	entry_k2<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
+	entry_k2<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
+	entry_k2w<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),   /* two 64 KB tiles per CU (127 registers): +19 % over one 128 KB tile, whose waves are all in the same phase */
 	/* level 13: four rows are 128 KB - one workgroup of sixteen waves per CU (still four per SIMD), no plane, no prefix sweep:
 	 * 4 B of HBM traffic per sample instead of the 12 B of the prefix + plane pair.  A two-stage first pass makes the
 	 * whole tile ONE segment (1024 threads x two adjacent columns = the 2048 residues of stride 2048): two warm-up rows per
 	 * four rows instead of per two, 24 instead of 32 prefetch registers: +8 % over (3,2,3,3,2) (2.94 against 3.18 ms for
 	 * 2.1 Gsamples; at levels 10 and 11 the same trade loses 3 %: an LDS-pass stage costs more than a first-pass stage) */
-	entry_k2w<TileCfg<13, 1024, 32768>, 1, 1, ACM_L13_GROUPS>(),
+	entry_k2w<TileCfg<13, 1024, 32768>, 1, ACM_L13_GROUPS>(),
 	/* level 14: one row pair is the 128 KB tile (the first pass's body is two rows: the least a tile can be), 155 KB of LDS
 	 * with the carries of the first LDS pass (two bodies of stride 256 = 4096 elements) */
-	entry_k2w<TileCfg<14, 1024, 32768>, 1, 2, ACM_L14_GROUPS>(),
+	entry_k2w<TileCfg<14, 1024, 32768>, 1, ACM_L14_GROUPS>(),
 };
 inline const Tile2Entry &tile2_entry(uint32_t level)
 {
@@ -1772,7 +1651,7 @@ acm_tile2p(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint
 	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
 	using PG = PackGeo<C, GR>;
 	using PU = PhaseU<C, PG>;
-	constexpr int NSLOT = PG::NSLOT, NW = PG::NW;
+	constexpr int NSLOT = PG::NSLOT;
 	static_assert(TR <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;
 
@@ -2097,8 +1976,8 @@ extern "C" int acmk_tile2_grid(uint32_t level, int cus)
 	return (cus > 0 ? cus : 256) * tile2_entry(level).wg_per_cu;
 }
 
-extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const AcmTile2Modes *d_modes, const uint8_t *d_idx8,
-				 const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
+extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const int16_t *d_idx, const acmhip_blkhdr *d_hdr,
+				 int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
 		return 0;
@@ -2116,9 +1995,7 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	const bool narrow = d_modes && d_idx8 && e.fn_narrow;
-	hipLaunchKernelGGL(narrow ? e.fn_narrow : e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx,
-			   narrow ? d_modes : nullptr, narrow ? d_idx8 : nullptr, d_hdr, d_pcm, d_sink, fmt);
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
@@ -2174,118 +2051,6 @@ extern "C" int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_til
 	static_assert(sizeof(acmhip_packed_chunk) == sizeof(uint2), "a chunk descriptor is two words");
 	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, reinterpret_cast<const uint2 *>(d_chunks), d_blob, d_hdr,
 			   d_pcm, d_sink, fmt);
-	ACMK_CHECK_LAUNCH();
-	return 0;
-}
-
-/*
- * The narrow staged form of a tile table: every tile's indices as int8 in the plane the lean kernel reads narrow rows from (the
- * 2 x 2 block of rows 2p, 2p + 1 x columns 2j, 2j + 1 at the byte offset of (row 2p, column 2j) in the int16 plane: same pitch,
- * every other row's worth of bytes unused), and beside every record its mode word (AcmTile2Modes: per wave of the tile
- * kernel's workgroup, do the rows it owns fit a byte, and do the two rows in front of them).  One workgroup per tile; a thread
- * turns 2 rows x 8 columns (two 16-byte reads) into 16 bytes.  count[0] += waves narrow in both respects, count[1] += waves
- * with narrow rows of their own behind rows that are not (over all tiles).
- */
-namespace {
-__global__ void __launch_bounds__(256)
-acm_pack_narrow(const AcmTile2 *__restrict__ tiles, AcmTile2Modes *__restrict__ modes, const uint32_t ntiles, const uint32_t level,
-		const uint32_t tile_rows, const uint32_t nwaves, const uint32_t tps, const uint32_t rps, const int16_t *__restrict__ idx,
-		uint8_t *__restrict__ idx8, uint32_t *__restrict__ count)
-{
-	__shared__ uint32_t wide_pair[65];              /* [p + 1]: row pair p of the tile has an index that needs 16 bits; [0]: the pair in front */
-	__shared__ uint32_t mode_word;
-	const uint32_t t = blockIdx.x;
-	if (t >= ntiles)
-		return;
-	const AcmTile2 r = tiles[t];
-	const uint32_t cols = 1u << level, per_row = cols / 8, npairs = tile_rows / 2, units = npairs * per_row;
-	const uint4 *src = reinterpret_cast<const uint4 *>(idx + r.idx_off);          /* stream offsets are multiples of 8 indices */
-	uint4 *dst = reinterpret_cast<uint4 *>(idx8 + 2 * r.idx_off);      /* row pair p at the offset of row 2p: the pitch of the int16 plane */
-	if (threadIdx.x <= npairs)
-		wide_pair[threadIdx.x] = 0u;
-	if (threadIdx.x == 0)
-		mode_word = 0u;
-	__syncthreads();
-	auto look = [&](uint32_t &acc, const uint32_t w) {
-		acc |= (uint32_t)((int32_t)(int16_t)w + 128) | (uint32_t)(((int32_t)w >> 16) + 128);    /* 0..255 <=> fits */
-	};
-	for (uint32_t u = threadIdx.x; u < units; u += 256) {
-		const uint32_t p = u / per_row, j = u % per_row;
-		const uint4 a = src[(2 * p) * per_row + j], b = src[(2 * p + 1) * per_row + j];
-		uint32_t wide = 0;
-		auto pack = [&](const uint32_t w0, const uint32_t w1) -> uint32_t {
-			look(wide, w0);
-			look(wide, w1);
-			return (w0 & 0xFFu) | ((w0 >> 8) & 0xFF00u) | ((w1 & 0xFFu) << 16) | ((w1 << 8) & 0xFF000000u);
-		};
-		dst[(2 * p) * per_row + j] = make_uint4(pack(a.x, b.x), pack(a.y, b.y), pack(a.z, b.z), pack(a.w, b.w));
-		if (wide & ~0xFFu)
-			atomicOr(&wide_pair[p + 1], 1u);
-	}
-	if (!(r.flags & ACM_TILE_FRESH))
-		for (uint32_t u = threadIdx.x; u < 2 * per_row; u += 256) {
-			const uint4 a = *(src - 2 * per_row + u);                   /* the two rows in front: the previous tile packs them */
-			uint32_t wide = 0;
-			look(wide, a.x);
-			look(wide, a.y);
-			look(wide, a.z);
-			look(wide, a.w);
-			if (wide & ~0xFFu)
-				atomicOr(&wide_pair[0], 1u);
-		}
-	__syncthreads();
-	if (threadIdx.x < nwaves) {
-		/* the rows wave w of the tile kernel owns: those of the first-pass segments its lanes belong to */
-		const uint32_t w = threadIdx.x, first_seg = w * 64u / tps, last_seg = ((w + 1u) * 64u - 1u) / tps;
-		const uint32_t p_lo = first_seg * rps / 2u, p_hi = (last_seg + 1u) * rps / 2u;
-		bool body = true;
-		for (uint32_t p = p_lo; p < p_hi; p++)
-			body = body && wide_pair[p + 1] == 0u;
-		const bool front = wide_pair[p_lo] == 0u;               /* the pair in front of the wave's rows ([0]: in front of the tile) */
-		/* narrow rows behind wide ones: the wave reads ALL its warm-up rows wide - worth it for at most two segments per wave */
-		const bool narrow = body && (front || last_seg - first_seg < 2u);
-		if (narrow)
-			atomicOr(&mode_word, (front ? 3u : 1u) << (2u * (w & 15u)));
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const uint32_t m = mode_word;
-		modes[t] = m;
-		const uint32_t both = (uint32_t)__popc(m & 0xAAAAAAAAu), body = (uint32_t)__popc(m & 0x55555555u);
-		if (both)
-			atomicAdd(&count[0], both);
-		if (body - both)
-			atomicAdd(&count[1], body - both);
-	}
-}
-}
-
-extern "C" int acmk_tile2_narrow_form(uint32_t level)
-{
-	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
-		return 0;
-	return tile2_entry(level).narrow_form;
-}
-
-extern "C" int acmk_tile2_waves(uint32_t level)
-{
-	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
-		return 0;
-	return tile2_entry(level).threads / 64;
-}
-
-extern "C" int acmk_launch_pack_narrow(uint32_t level, const AcmTile2 *d_tiles, AcmTile2Modes *d_modes, uint32_t ntiles, const int16_t *d_idx,
-				       uint8_t *d_idx8, uint32_t *d_count, void *stream)
-{
-	if (ntiles == 0)
-		return 0;
-	if (level < ACM_K2_MIN_LEVEL || level > ACM_K2_MAX_LEVEL)
-		return -1;
-	const Tile2Entry &e = tile2_entry(level);
-	if (e.tile_rows > 128 || e.threads > 1024)
-		return -1;
-	hipLaunchKernelGGL(acm_pack_narrow, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, d_tiles, d_modes, ntiles, level,
-			   (uint32_t)e.tile_rows, (uint32_t)e.threads / 64u, (uint32_t)e.tps, (uint32_t)e.rps, d_idx, d_idx8, d_count);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

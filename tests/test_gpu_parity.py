@@ -12,9 +12,9 @@ from libacm_amd import capi
 pytestmark = pytest.mark.gpu
 
 
-def check_streams(dev, files, flags=capi.PLAN_AUTO, fmt=capi.FMT_S16LE, force_chans=0, narrow=False):
+def check_streams(dev, files, flags=capi.PLAN_AUTO, fmt=capi.FMT_S16LE, force_chans=0):
     staged = [capi.stage_file(f, force_chans) for f in files]
-    got, st = capi.synth(dev, staged, fmt=fmt, flags=flags, return_stats=True, narrow=narrow)
+    got, st = capi.synth(dev, staged, fmt=fmt, flags=flags, return_stats=True)
     be, sg = fmt_args(fmt)
     for k, (f, g) in enumerate(zip(files, got)):
         want, status = oracle_pcm(f, force_chans, be, sg)
@@ -85,104 +85,6 @@ def test_lean_tile_kernel_levels_13_14(dev, force_k2, level, rows):
     assert st.fused_streams == 2
     for fmt in (capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE):
         check_streams(dev, [g], fmt=fmt)
-
-
-@pytest.fixture
-def force_narrow(monkeypatch):
-    """ACM_NARROW=1: the narrow build of the tile kernel runs as soon as one tile is narrow (default: when enough are to pay)"""
-    monkeypatch.setenv("ACM_NARROW", "1")
-
-
-@pytest.mark.parametrize("level", [6, 7, 8, 9, 10, 11, 12, 13, 14])
-@pytest.mark.parametrize("rows,pwr_max", [(1, 6), (3, 12), (16, 6), (16, 12), (17, 9), (700, 7)])
-def test_narrow_tiles_matrix(dev, force_k2, force_narrow, level, rows, pwr_max):
-    """acmhip_plan_attach_narrow: tiles whose indices fit a byte are read from the int8 plane (half the loads), the others from
-    the int16 arena, tile by tile in one launch; pwr <= 6 keeps every index inside a byte (linear fillers have at most
-    pwr + 1 bits), pwr up to 12 mixes narrow and wide tiles and tiles whose own rows fit but not the two rows in front"""
-    tr = 4 if level == 13 else 2 if level == 14 else (16384 if level >= 11 else 8192) >> level
-    nblocks = max(2, (7 * tr + rows - 1) // rows + 1)
-    f = make_stream(8000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=5, pwr_min=min(4, pwr_max), pwr_max=pwr_max)
-    st = check_streams(dev, [f], narrow=True)
-    assert st.narrow_tiles <= st.tiles
-    if pwr_max <= 7:
-        assert st.narrow_tiles >= 7, (st.narrow_tiles, st.tiles)        # at least 7 whole tiles, every one of them narrow
-
-
-@pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_U16BE])
-def test_narrow_tiles_batch(dev, force_k2, force_narrow, fmt):
-    """many streams of every level, narrow and wide ones interleaved: workgroup runs start inside streams (lead-in tiles,
-    narrow or not) and cross from a narrow stream into a wide one"""
-    files = []
-    for i in range(41):
-        lv = 6 + i % 9
-        rows = [16, 5, 33, 1][i % 4]
-        pm = [5, 12, 7, 9][(i // 2) % 4]
-        files.append(make_stream(8800 + i, lv, rows, 2 + (i * 5) % 11 + ((16384 >> lv) * (1 + i % 3)) // rows,
-                                 channels=1 + i % 2, cut=i % 3, pwr_min=min(4, pm), pwr_max=pm, val_max=65535 if i % 5 == 0 else 255))
-    st = check_streams(dev, files, fmt=fmt, narrow=True)
-    assert 0 < st.narrow_tiles < st.tiles
-
-
-@pytest.mark.parametrize("level", [9, 11])
-def test_narrow_build_is_used_only_where_it_pays(dev, force_k2, level, monkeypatch):
-    """per level group acmhip_plan_attach_narrow counts the narrow tiles and keeps the int16-only build of the kernel when they
-    are too few: level 9 (narrow build as fast on wide tiles) takes it from 2 % on, level 11 (3 % slower on wide tiles) from a
-    third on; ACM_NARROW=0 / 1 overrides"""
-    blocks = 80
-    quiet = make_stream(9100 + level, level, 16, blocks, pwr_min=3, pwr_max=7)          # every tile narrow
-    mixed = make_stream(9200 + level, level, 16, blocks, pwr_min=7, pwr_max=12)         # about one block in six
-    for f, expect_default in ((quiet, "all"), (mixed, "some" if level == 9 else "none")):
-        for env, expect in ((None, expect_default), ("0", "none"), ("1", "all" if f is quiet else "some")):
-            if env is None:
-                monkeypatch.delenv("ACM_NARROW", raising=False)
-            else:
-                monkeypatch.setenv("ACM_NARROW", env)
-            st = check_streams(dev, [f], narrow=True)
-            lean = (blocks * 16) // ((8192 >> level) if level < 13 else 1)
-            assert {"none": st.narrow_tiles == 0, "some": 0 < st.narrow_tiles < lean, "all": st.narrow_tiles == lean}[expect], (
-                level, env, expect, st.narrow_tiles, lean)
-
-
-def test_narrow_plane_follows_the_arena_it_was_packed_from(dev, force_k2):
-    """a launch on any other arena than the attached one reads int16 only; attaching again re-packs; NULL detaches"""
-    a = capi.stage_file(make_stream(8901, 9, 16, 12, pwr_min=4, pwr_max=6))
-    b = capi.stage_file(make_stream(8902, 9, 16, 12, pwr_min=9, pwr_max=12))       # same shape, indices that need 16 bits
-    want = {k: oracle_pcm(make_stream(8901 + k, 9, 16, 12, pwr_min=(4, 9)[k], pwr_max=(6, 12)[k]))[0] for k in (0, 1)}
-    ar_a, ar_b = capi.Arena([a]), capi.Arena([b])
-    d = {k: (dev.malloc(ar.idx.nbytes), dev.malloc(ar.hdr.nbytes)) for k, ar in ((0, ar_a), (1, ar_b))}
-    d_pcm = dev.malloc(ar_a.pcm_words * 2)
-    out = np.zeros(ar_a.pcm_words, dtype=np.uint16)
-    try:
-        for k, ar in ((0, ar_a), (1, ar_b)):
-            dev.upload(d[k][0], ar.idx)
-            dev.upload(d[k][1], ar.hdr)
-        plan = capi.Plan(dev, ar_a.descs, None, capi.PLAN_AUTO)
-
-        def run(k):
-            plan.launch(d[k][0], d[k][1], d_pcm)
-            dev.download(out, d_pcm)
-            dev.sync()
-            assert np.array_equal(out[:want[k].size], want[k]), k
-
-        assert plan.attach_narrow(d[0][0]) == 12 and plan.stats().narrow_tiles == 12
-        run(0)
-        run(1)                                  # the other arena: the int8 plane (packed from arena 0) must not be read
-        assert plan.attach_narrow(d[1][0]) == 0
-        run(1)
-        run(0)
-        dev.upload(d[1][0], ar_a.idx)           # new content in an attached arena: attach again
-        dev.upload(d[1][1], ar_a.hdr)
-        assert plan.attach_narrow(d[1][0]) == 12
-        want[1] = want[0]
-        run(1)
-        assert plan.attach_narrow(None) == 0 and plan.stats().narrow_tiles == 0
-        run(1)
-        plan.destroy()
-    finally:
-        for k in d:
-            dev.free(d[k][0])
-            dev.free(d[k][1])
-        dev.free(d_pcm)
 
 
 def test_lean_tile_kernel_exact_multiple(dev, force_k2):

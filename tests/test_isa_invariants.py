@@ -1,4 +1,5 @@
-"""Generated-code invariants of the lean tile kernel (libacm_amd/csrc/acm_kernels.hip: acm_tile2).
+"""Generated-code invariants of the lean tile kernels (libacm_amd/csrc/acm_kernels.hip: acm_tile2 and its packed-form build
+acm_tile2p, whose mangled names both match `acm_tile2`).
 
 acm_tile2 issues its global loads from inline asm and waits for them by hand (one `s_waitcnt vmcnt(N)` at the end
 of the iteration that issued them), so the compiler does not know that the destination registers of those loads are
@@ -122,7 +123,7 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                     state_in[t] |= pending
                     work.append(t)
         assert n_loads >= 2 * 13, (name, n_loads)          # prologue + in-loop sets of staged-index loads
-    assert n_kernels >= 4
+    assert n_kernels >= 13                                 # nine levels of acm_tile2, four of acm_tile2p
 
 
 def test_every_wait_is_written_by_hand(kernel_asm):
@@ -178,4 +179,19 @@ def test_phase_priorities_are_in_the_tile_loop(kernel_asm):
         else:
             assert set(prios) == {"0", "2", "3"}, (name[:60], prios)
         n += 1
-    assert n >= 9
+    assert n >= 13
+
+
+def test_packed_build_reads_its_descriptors_through_the_scalar_cache(kernel_asm):
+    """acm_tile2p: chunk descriptors and tile records are scalar loads (a vector load would bring a compiler-placed vmcnt wait
+    with it: checked above), the chunk data are the hand-issued dword loads inside the branchy asm statements"""
+    n = 0
+    for name, lines in tile2_bodies(kernel_asm):
+        if "acm_tile2p" not in name:
+            continue
+        n += 1
+        text = "\n".join(lines)
+        assert "flat_load" not in text and "buffer_load" not in text, name[:60]
+        assert text.count("s_load_dwordx8") >= 2, name[:60]
+        assert text.count(".Lacm_pk") >= 10 and text.count(".Lacm_un_") >= 10, name[:60]
+    assert n == 4
