@@ -210,7 +210,8 @@ struct acm_batch_prestaged {
 		bool ok = false;
 	};
 	std::vector<Item> items;
-	std::vector<const uint8_t *> data;      /* the file images the items pointed at (identity check in acm_batch_decode) */
+	std::vector<const uint8_t *> data;      /* the file images the items pointed at, and their lengths (identity check in acm_batch_decode) */
+	std::vector<size_t> len;
 	int16_t *idx = nullptr;
 	acmhip_blkhdr *hdr = nullptr;
 	size_t idx_cap = 0, hdr_cap = 0;        /* bytes */
@@ -272,8 +273,10 @@ extern "C" void acm_batch_prestage_free(acm_batch_prestaged *p)
 {
 	if (!p)
 		return;
-	g_stage_cache.put(p->idx, p->idx_cap);
-	g_stage_cache.put(p->hdr, p->hdr_cap);
+	if (p->idx && p->idx_cap)
+		g_stage_cache.put(p->idx, p->idx_cap);
+	if (p->hdr && p->hdr_cap)
+		g_stage_cache.put(p->hdr, p->hdr_cap);
 	delete p;
 }
 
@@ -291,12 +294,14 @@ extern "C" int acm_batch_prestage(const acm_batch_item *items, size_t n, const a
 		return ACMHIP_ERR_NOMEM;
 	p->items.resize(n);
 	p->data.resize(n);
+	p->len.resize(n);
 	p->force_chans = opts.force_chans;
 	const int threads_wanted = opts.threads > 0 ? opts.threads : default_threads();
 	Pool pool((int)std::min<size_t>((size_t)threads_wanted, std::max<size_t>(1, n)));
 	pool.run(n, [&](size_t i) {
 		acm_batch_prestaged::Item &s = p->items[i];
 		p->data[i] = items[i].data;
+		p->len[i] = items[i].len;
 		s.status = acm_stage_probe(items[i].data, items[i].len, opts.force_chans, &s.info);
 		s.ok = s.status == ACM_OK;
 		if (s.ok)
@@ -372,8 +377,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		if (pre->items.size() != n || pre->force_chans != opts.force_chans)
 			return ACMHIP_ERR_ARG;
 		for (size_t i = 0; i < n; i++)
-			if (pre->data[i] != items[i].data)
-				return ACMHIP_ERR_ARG;
+			if (pre->data[i] != items[i].data || pre->len[i] != items[i].len)
+				return ACMHIP_ERR_ARG;          /* the staged blocks are copied into arenas laid out from THESE items' lengths */
 		opts.parse = ACM_BATCH_PARSE_HOST;
 	}
 	acm_batch_timing tm{};
@@ -652,6 +657,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				return;
 			}
 			const uint64_t bl = (uint64_t)ps.info.rows * ps.info.cols;
+			if (ps.need_blocks != s.need_blocks || ps.info.blocks > s.need_blocks) {      /* cannot happen for the same bytes */
+				it.status = ACM_ERR_OTHER;
+				s.ok = false;
+				return;
+			}
 			memcpy(h_idx + s.idx_off, pre->idx + ps.idx_off, ps.info.blocks * bl * sizeof(int16_t));
 			memcpy(h_hdr + s.hdr_off, pre->hdr + ps.hdr_off, ps.info.blocks * sizeof(acmhip_blkhdr));
 			s.patches = ps.patches;

@@ -53,6 +53,17 @@ struct acmhip_device {
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
 	std::mutex arena_mutex;
+	/* device blocks of destroyed plans (tile tables, planes, the lead-in sink), kept for the next plan: hipMalloc / hipFree
+	 * synchronise the whole device - every stream of the process, an RCCL transfer in flight included - and a batch builds and
+	 * drops a plan per chunk */
+	struct Block {
+		void *ptr;
+		size_t bytes;
+	};
+	std::vector<Block> spare;
+	size_t spare_bytes = 0;
+	std::mutex spare_mutex;
+	static constexpr size_t SPARE_MAX_BYTES = (size_t)768 << 20, SPARE_MAX_BLOCKS = 256;
 };
 
 /* per level: the fused-kernel tile table, or the stage-wise stream list */
@@ -79,6 +90,7 @@ struct LevelGroup {
 
 struct acmhip_plan {
 	acmhip_device *dev = nullptr;
+	std::vector<acmhip_device::Block> blocks;       /* every device allocation of this plan (handed back to the handle's spare list) */
 	AcmDevStream *d_streams = nullptr;
 	std::vector<LevelGroup> fused, stagewise, small, prefix;   /* small: levels 0-4, one register-cascade launch; prefix: levels 13-15 */
 	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
@@ -165,6 +177,8 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 		return;
 	(void)hipSetDevice(dev->ordinal);
 	(void)hipStreamSynchronize(dev->stream);
+	for (const acmhip_device::Block &b : dev->spare)
+		(void)hipFree(b.ptr);
 	for (int k = 0; k < ACM_ARENA_SLOTS; k++) {
 		if (!dev->arena[k])
 			continue;
@@ -327,13 +341,48 @@ extern "C" int acmhip_download(acmhip_device *dev, void *hptr, const void *dptr,
 
 namespace {
 
-template <typename T>
-int to_device(acmhip_device *dev, const std::vector<T> &v, T **out)
+/* device memory for a plan: a spare block of a destroyed plan if one fits (no more than twice the size), else hipMalloc */
+int plan_malloc(acmhip_plan *pl, void **out, size_t bytes)
 {
+	acmhip_device *dev = pl->dev;
+	*out = nullptr;
+	if (bytes < 256)
+		bytes = 256;
+	{
+		std::lock_guard<std::mutex> g(dev->spare_mutex);
+		size_t best = dev->spare.size();
+		for (size_t k = 0; k < dev->spare.size(); k++)
+			if (dev->spare[k].bytes >= bytes && dev->spare[k].bytes <= 2 * bytes + 4096 &&
+			    (best == dev->spare.size() || dev->spare[k].bytes < dev->spare[best].bytes))
+				best = k;
+		if (best != dev->spare.size()) {
+			const acmhip_device::Block b = dev->spare[best];
+			dev->spare.erase(dev->spare.begin() + (long)best);
+			dev->spare_bytes -= b.bytes;
+			pl->blocks.push_back(b);
+			*out = b.ptr;
+			return ACMHIP_OK;
+		}
+	}
+	void *p = nullptr;
+	HIPTRY(hipMalloc(&p, bytes));
+	pl->blocks.push_back(acmhip_device::Block{ p, bytes });
+	*out = p;
+	return ACMHIP_OK;
+}
+
+template <typename T>
+int to_device(acmhip_plan *pl, const std::vector<T> &v, T **out)
+{
+	acmhip_device *dev = pl->dev;
 	*out = nullptr;
 	if (v.empty())
 		return ACMHIP_OK;
-	HIPTRY(hipMalloc((void **)out, v.size() * sizeof(T)));
+	{
+		const int rc = plan_malloc(pl, (void **)out, v.size() * sizeof(T));
+		if (rc != ACMHIP_OK)
+			return rc;
+	}
 	/* done when this returns (the host vector dies with the caller), on a non-blocking stream of the handle's own: neither
 	 * the device stream - which may be the caller's and busy with the chunks of a batch still in flight (acm_batch_decode
 	 * builds the plan of chunk k+1 while chunk k runs) - nor the legacy null stream, whose copies join every blocking
@@ -380,34 +429,31 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 		return;
 	if (plan->dev) {
 		(void)hipSetDevice(plan->dev->ordinal);
-		(void)hipStreamSynchronize(plan->dev->stream);
+		(void)hipStreamSynchronize(plan->dev->stream);   /* the launches of this plan are done with its tables (side streams join the device stream) */
 	}
-	(void)hipFree(plan->d_streams);
-	for (auto &g : plan->fused) {
-		(void)hipFree(g.d_tiles);
-		(void)hipFree(g.d_tiles2);
-		(void)hipFree(g.d_tiles2p);
-		(void)hipFree(g.d_tiles2p_plain);
-		(void)hipFree(g.d_tiles_extra);
-	}
-	for (auto &g : plan->stagewise)
-		(void)hipFree(g.d_list);
-	for (auto &g : plan->prefix) {
-		(void)hipFree(g.d_list);
-		(void)hipFree(g.d_tiles);
-	}
-	for (auto &g : plan->small)
-		(void)hipFree(g.d_list);
 	if (plan->ev_fork)
 		(void)hipEventDestroy(plan->ev_fork);
 	for (hipEvent_t e : plan->ev_join)
 		if (e)
 			(void)hipEventDestroy(e);
-	(void)hipFree(plan->d_sink);
-	(void)hipFree(plan->d_sw_all);
-	(void)hipFree(plan->d_patches);
-	(void)hipFree(plan->d_plane[0]);
-	(void)hipFree(plan->d_plane[1]);
+	if (plan->dev) {
+		acmhip_device *dev = plan->dev;
+		std::vector<acmhip_device::Block> drop;
+		{
+			std::lock_guard<std::mutex> g(dev->spare_mutex);
+			for (const acmhip_device::Block &b : plan->blocks) {
+				if (dev->spare.size() < acmhip_device::SPARE_MAX_BLOCKS && dev->spare_bytes + b.bytes <= acmhip_device::SPARE_MAX_BYTES &&
+				    b.bytes <= acmhip_device::SPARE_MAX_BYTES / 4) {
+					dev->spare.push_back(b);
+					dev->spare_bytes += b.bytes;
+				} else {
+					drop.push_back(b);
+				}
+			}
+		}
+		for (const acmhip_device::Block &b : drop)
+			(void)hipFree(b.ptr);
+	}
 	delete plan;
 }
 
@@ -704,14 +750,14 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		return ACMHIP_ERR_NOMEM;
 	pl->dev = dev;
 	pl->variant = variant;
-	int rc = to_device(dev, ds, &pl->d_streams);
+	int rc = to_device(pl, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
 		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty() || !tiles2p[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
 			if (!tiles_extra[lv].empty()) {
 				g.ntiles_extra = (uint32_t)tiles_extra[lv].size();
-				rc = to_device(dev, tiles_extra[lv], &g.d_tiles_extra);
+				rc = to_device(pl, tiles_extra[lv], &g.d_tiles_extra);
 				st.tiles += g.ntiles_extra;
 				st.launches += 1;
 				if (tiles[lv].empty())
@@ -726,22 +772,19 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
-			rc = to_device(dev, use, &g.d_tiles);
-			if (k2 && rc == ACMHIP_OK && !pl->d_sink) {
-				hipError_t e = hipMalloc((void **)&pl->d_sink, ACM_K2_SINK_BYTES);
-				if (e != hipSuccess)
-					rc = hip_fail(e, "hipMalloc(lead-in sink)");
-			}
+			rc = to_device(pl, use, &g.d_tiles);
+			if (k2 && rc == ACMHIP_OK && !pl->d_sink)
+				rc = plan_malloc(pl, (void **)&pl->d_sink, ACM_K2_SINK_BYTES);
 			if (k2 && rc == ACMHIP_OK) {
 				g.ntiles2 = (uint32_t)tiles2[lv].size();
-				rc = to_device(dev, tiles2[lv], &g.d_tiles2);
+				rc = to_device(pl, tiles2[lv], &g.d_tiles2);
 				st.tiles += g.ntiles2;
 				st.launches += g.ntiles2 ? 1 : 0;
 				if (rc == ACMHIP_OK && !tiles2p[lv].empty()) {
 					g.ntiles2p = (uint32_t)tiles2p[lv].size();
-					rc = to_device(dev, tiles2p[lv], &g.d_tiles2p);
+					rc = to_device(pl, tiles2p[lv], &g.d_tiles2p);
 					if (rc == ACMHIP_OK)
-						rc = to_device(dev, tiles2p_plain[lv], &g.d_tiles2p_plain);
+						rc = to_device(pl, tiles2p_plain[lv], &g.d_tiles2p_plain);
 					st.tiles += g.ntiles2p;
 					st.packed_tiles += g.ntiles2p;
 					st.launches += 1;
@@ -758,7 +801,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			g.level = lv;
 			g.nlist = (uint32_t)small_lists[lv].size();
 			g.max_emit = grp_max_emit[lv];
-			rc = to_device(dev, small_lists[lv], &g.d_list);
+			rc = to_device(pl, small_lists[lv], &g.d_list);
 			pl->small.push_back(g);
 			st.launches += 1;
 		}
@@ -770,12 +813,12 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				g.prefix_patched = g.prefix_patched || (id < n && has_patch[id]);
 			g.nlist = (uint32_t)prefix_lists[lv].size();
 			g.max_elems = grp_max_elems[lv];
-			rc = to_device(dev, prefix_lists[lv], &g.d_list);
+			rc = to_device(pl, prefix_lists[lv], &g.d_list);
 			if (rc == ACMHIP_OK) {
 				g.carry = carry_wanted(prefix_tiles_carry[lv].size(), (size_t)acmk_plane_grid(dev->cus), (size_t)acmk_plane_tile_rows());
 				const std::vector<AcmTile> &use = g.carry ? prefix_tiles_carry[lv] : prefix_tiles[lv];
 				g.ntiles = (uint32_t)use.size();
-				rc = to_device(dev, use, &g.d_tiles);
+				rc = to_device(pl, use, &g.d_tiles);
 			}
 			pl->prefix.push_back(g);
 			st.tiles += g.ntiles;
@@ -787,7 +830,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			g.nlist = (uint32_t)lists[lv].size();
 			g.max_elems = grp_max_elems[lv];
 			g.max_emit = grp_max_emit[lv];
-			rc = to_device(dev, lists[lv], &g.d_list);
+			rc = to_device(pl, lists[lv], &g.d_list);
 			pl->stagewise.push_back(g);
 			st.launches += lv + 1;          /* stages + emit */
 		}
@@ -797,19 +840,16 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		pl->sw_max_elems = sw_max;
 		pl->plane_elems = plane;
 		if (!sw_all.empty()) {
-			rc = to_device(dev, sw_all, &pl->d_sw_all);
+			rc = to_device(pl, sw_all, &pl->d_sw_all);
 			st.launches += 1;                       /* unpack */
 		}
 		if (rc == ACMHIP_OK && !dp.empty()) {
 			pl->npatches = dp.size();
-			rc = to_device(dev, dp, &pl->d_patches);
+			rc = to_device(pl, dp, &pl->d_patches);
 			st.launches += 1;
 		}
-		for (int b = 0; b < 2 && rc == ACMHIP_OK; b++) {
-			hipError_t e = hipMalloc((void **)&pl->d_plane[b], plane * sizeof(int32_t));
-			if (e != hipSuccess)
-				rc = hip_fail(e, "hipMalloc(stage-wise plane)");
-		}
+		for (int b = 0; b < 2 && rc == ACMHIP_OK; b++)
+			rc = plan_malloc(pl, (void **)&pl->d_plane[b], plane * sizeof(int32_t));
 	}
 	if (rc != ACMHIP_OK) {
 		acmhip_plan_destroy(pl);

@@ -50,6 +50,7 @@ using acmfill::kCleanEof;
 constexpr uint64_t kWindowSamplesMax = 64u << 20;       /* read-ahead ceiling per window (buffers are sized by min(this, the stream): a
                                                            whole 40-Msample file fits, so that parsing can run ahead for as long
                                                            as a prewarmed device takes to come up) */
+constexpr uint64_t kWindowSamplesUnknownLength = 4u << 20;      /* ... for a data source that does not say how long it is */
 constexpr uint64_t kWindowSamplesFirst = 64u << 10;     /* first window: keep time-to-first-sample short */
 
 /* ---- process-wide default device for the single-stream API ----
@@ -187,6 +188,15 @@ bool alloc_window(HipStream *hs)
 	const uint64_t total_blocks = ((uint64_t)a->total_values + bl - 1) / bl;
 	uint64_t cap = std::max<uint64_t>(1, kWindowSamplesMax / bl);
 	cap = std::min(cap, std::max<uint64_t>(1, total_blocks));
+	/* the header's total_values is a promise, not a fact: the buffers - host and device - are sized by what the
+	 * data source can hold when it says how long it is (a block costs at least its 20-bit header and a 5-bit filler code per
+	 * column, decode.c:491-502, 586-589; the reader appends one zero byte, :57-61), and by the old 4-Msample window when it does not */
+	if (a->data_len > 0) {
+		const uint64_t bits = (uint64_t)a->data_len * 8 + 8;
+		cap = std::min(cap, bits / (20 + 5 * (uint64_t)a->info.acm_cols) + 1);
+	} else {
+		cap = std::min(cap, std::max<uint64_t>(1, kWindowSamplesUnknownLength / bl));
+	}
 	hs->win_cap = (uint32_t)cap;
 	hs->carry_max = a->info.acm_rows >= 2 ? 1 : 2;
 	hs->grow = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1, kWindowSamplesFirst / bl));

@@ -12,10 +12,12 @@
 #include <errno.h>
 #include <getopt.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/types.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
@@ -121,20 +123,42 @@ static int pad_output(const char *name, FILE *out, char *buf, int done, int tota
 /*
  * Leaving costs as much as arriving: when a process that used the GPU ends, the kernel gives back its device memory and
  * unpins its pinned arenas before the parent's wait() returns - 0.16-0.27 s behind the last output byte of a 0.8 s batch run
- * (profiles/r3_cli_probe.txt), 0.08 s even for a program that only initialised the runtime.  So the decode runs in a CHILD
- * (forked before anything touches HIP); when every output is written and closed the child sends its exit code through a
- * pipe and goes on to die at its own pace, and the process the caller waits for returns that code at once.  A child that
- * ends any other way closes the pipe without a byte: the parent then waits for it and passes its status on.
- * ACMTOOL_NO_DETACH=1 keeps everything in one process.
+ * (profiles/r3_cli_probe.txt), 0.08 s even for a program that only initialised the runtime.  With ACMTOOL_DETACH=1 the decode
+ * therefore runs in a CHILD (forked before anything touches HIP); when every output is written and closed the child sends its
+ * exit code through a pipe and goes on to die at its own pace, and the process the caller waits for returns that code at once.
+ * Off by default (the GPU context of the detached child outlives the command, back-to-back commands stack them):
+ * the numbers the documents lead with are those of the one-process run.  While detached:
+ *   - a terminating signal sent to the waiting process is passed on to the child (a supervisor's kill, timeout(1)), and the
+ *     child asks the kernel for SIGTERM should its parent die another way, until it has reported its code;
+ *   - a child that ends any other way than through fast_exit() closes the pipe without a byte: the parent waits for it and
+ *     passes its status on, 128 + signal for a signalled one;
+ *   - never under a profiler or any other tool library that initialises the GPU before main() (rocprofv3 preloads one): a
+ *     forked child cannot use a HIP runtime it inherited.
  */
 static int done_fd = -1;
+static volatile sig_atomic_t detached_child = 0;
+
+static void pass_signal_on(int sig)
+{
+	if (detached_child > 0)
+		kill((pid_t)detached_child, sig);
+}
+
+static int tool_library_preloaded(void)
+{
+	const char *pre = getenv("LD_PRELOAD");
+	return getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROFILER_REGISTER_ENABLED") ||
+	       (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler")));
+}
 
 static void detach_teardown(void)
 {
+	static const int passed_on[] = { SIGTERM, SIGINT, SIGHUP, SIGQUIT };
 	int fds[2];
 	pid_t pid;
-	const char *no = getenv("ACMTOOL_NO_DETACH");
-	if ((no && atoi(no)) || pipe(fds) != 0)
+	size_t k;
+	const char *yes = getenv("ACMTOOL_DETACH");
+	if (!yes || !atoi(yes) || tool_library_preloaded() || pipe(fds) != 0)
 		return;
 	fflush(NULL);
 	pid = fork();
@@ -146,9 +170,19 @@ static void detach_teardown(void)
 	if (pid == 0) {
 		close(fds[0]);
 		done_fd = fds[1];
+		prctl(PR_SET_PDEATHSIG, SIGTERM);       /* until the code has been reported (fast_exit) */
+		if (getppid() == 1)                     /* the parent is gone already */
+			_exit(128 + SIGTERM);
 		return;                 /* the child does the work */
 	}
 	close(fds[1]);
+	detached_child = (sig_atomic_t)pid;
+	for (k = 0; k < sizeof(passed_on) / sizeof(passed_on[0]); k++) {
+		struct sigaction sa;
+		memset(&sa, 0, sizeof(sa));
+		sa.sa_handler = pass_signal_on;
+		sigaction(passed_on[k], &sa, NULL);     /* no SA_RESTART: read() below returns EINTR and goes round again */
+	}
 	{
 		unsigned char code = 0;
 		ssize_t n;
@@ -160,7 +194,7 @@ static void detach_teardown(void)
 			_exit(code);
 		while (waitpid(pid, &st, 0) < 0 && errno == EINTR)
 			;
-		_exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+		_exit(WIFEXITED(st) ? WEXITSTATUS(st) : WIFSIGNALED(st) ? 128 + WTERMSIG(st) : 1);
 	}
 }
 
@@ -171,9 +205,14 @@ static void fast_exit(int code)
 	if (done_fd >= 0) {
 		unsigned char c = (unsigned char)code;
 		ssize_t n;
+		prctl(PR_SET_PDEATHSIG, 0);             /* the parent leaves now; what is left is the teardown */
 		do
 			n = write(done_fd, &c, 1);
 		while (n < 0 && errno == EINTR);
+		/* whoever captures this command's output waits for every holder of the pipes to close them */
+		close(0);
+		close(1);
+		close(2);
 	}
 	_exit(code);
 }

@@ -1,5 +1,5 @@
 # Where the wall clock of `acmtool -B` goes outside the batch itself (start-up before the first trace line, exit behind the last
-# one) by the number of groups parsed ahead; ACMTOOL_NO_DETACH=1 shows the undetached exit.  usage: bash profiles/cli_exit_probe.sh   (GPU box)
+# one) by the number of groups parsed ahead; ACMTOOL_DETACH=1 shows the detached exit.  usage: bash profiles/cli_exit_probe.sh   (GPU box)
 N=4000
 D=/dev/shm/acm_cli_probe2
 rm -rf $D; mkdir -p $D/in

@@ -71,21 +71,20 @@ def test_cli_decoding(dev, rec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detach", ["0", "1"], ids=["detached", "one_process"])
+@pytest.mark.parametrize("detach", ["1", "0"], ids=["detached", "one_process"])
 def test_cli_returns_when_the_outputs_are_closed(dev, detach):
-    """acmtool decodes in a child that reports its exit code once every output is written and closed (the kernel's teardown of
-    the GPU process is not the caller's to wait for); ACMTOOL_NO_DETACH=1 keeps one process.  Either way: the same files, the
-    same messages, the same exit code - and the files are complete the moment the tool returns (stdout / stderr go to files
-    here: a pipe would be held open by the child and make the caller wait for it anyway)."""
-    env = dict(os.environ, ACMTOOL_NO_DETACH=detach)
+    """ACMTOOL_DETACH=1: acmtool decodes in a child that reports its exit code once every output is written and closed (the
+    kernel's teardown of the GPU process is then not the caller's to wait for); the default is one process.  Either way: the
+    same files, the same messages, the same exit code - and the files are complete the moment the tool returns (with pipes
+    for stdout / stderr too: the detached child closes its ends before it goes on to die)."""
+    env = dict(os.environ, ACMTOOL_DETACH=detach)
     with tempfile.TemporaryDirectory() as td:
         from helpers import make_stream
         files = {"a.acm": make_stream(7700, 7, 16, 40), "b.acm": make_stream(7701, 9, 4, 11, channels=2), "c.acm": b"not an acm file"}
         for n, d in files.items():
             open(os.path.join(td, n), "wb").write(d)
         for flags in (["-d", "-q", "-r"], ["-d", "-q", "-B"]):
-            with open(os.path.join(td, "out.txt"), "wb") as so, open(os.path.join(td, "err.txt"), "wb") as se:
-                rc = subprocess.call([tool()] + flags + sorted(files), cwd=td, env=env, stdout=so, stderr=se)
+            r = subprocess.run([tool()] + flags + sorted(files), cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             ext = ".raw" if "-r" in flags else ".wav"
             import oracle_api as O
             for n in ("a", "b"):
@@ -94,12 +93,44 @@ def test_cli_returns_when_the_outputs_are_closed(dev, detach):
                 assert got[-len(want):] == want and len(got) == len(want) + (0 if ext == ".raw" else 44), (flags, n)
                 os.remove(os.path.join(td, n + ext))
             assert not os.path.exists(os.path.join(td, "c" + ext))
-            assert rc == 0 and b"c.acm" in open(os.path.join(td, "err.txt"), "rb").read(), flags
+            assert r.returncode == 0 and b"c.acm" in r.stderr, flags
         # a child that does not get as far as reporting: the parent passes its status on
         rc = subprocess.call([tool(), "-d", "-q", "-o", os.path.join(td, "nodir", "x.wav"), "a.acm"], cwd=td, env=env,
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert rc == subprocess.call([tool(), "-d", "-q", "-o", os.path.join(td, "nodir", "x.wav"), "a.acm"], cwd=td,
-                                     env=dict(env, ACMTOOL_NO_DETACH="1"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                     env=dict(env, ACMTOOL_DETACH="0"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+@pytest.mark.gpu
+def test_cli_detached_child_follows_its_parent(dev):
+    """a signal that ends the process the caller waits for must not leave the GPU child decoding as an orphan.
+    A long decode, detached; SIGTERM to the waiting process: it reports 128 + SIGTERM and the child is gone with it (the output
+    file stops growing).  Under a tool library that initialises the GPU before main() (rocprofv3's) the tool never forks."""
+    import signal
+    import time
+    from helpers import make_stream
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "long.acm"), "wb").write(make_stream(7710, 9, 16, 6000))          # 49 Msamples
+        env = dict(os.environ, ACMTOOL_DETACH="1")
+        p = subprocess.Popen([tool(), "-d", "-q", "-r", "long.acm"], cwd=td, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        time.sleep(0.05)
+        kids = [int(x) for x in subprocess.run(["pgrep", "-P", str(p.pid)], stdout=subprocess.PIPE, text=True).stdout.split()]
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(30)
+        if kids:                                    # it had forked already: the child got the signal too
+            assert rc in (128 + signal.SIGTERM, -signal.SIGTERM), rc
+            deadline = time.time() + 10
+            while time.time() < deadline and os.path.exists("/proc/%d" % kids[0]) and \
+                    open("/proc/%d/stat" % kids[0]).read().split(")")[1].split()[0] != "Z":
+                time.sleep(0.05)
+            assert not os.path.exists("/proc/%d" % kids[0]) or open("/proc/%d/stat" % kids[0]).read().split(")")[1].split()[0] == "Z"
+        # with a tool library announced in the environment: one process, same result
+        env2 = dict(env, ROCP_TOOL_LIBRARIES="/nonexistent/librocprofiler-sdk-tool.so")
+        open(os.path.join(td, "s.acm"), "wb").write(make_stream(7711, 7, 16, 40))
+        p = subprocess.Popen([tool(), "-d", "-q", "-r", "s.acm"], cwd=td, env=env2, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        time.sleep(0.02)
+        assert not subprocess.run(["pgrep", "-P", str(p.pid)], stdout=subprocess.PIPE, text=True).stdout.split()
+        assert p.wait(60) == 0
 
 
 @pytest.mark.gpu

@@ -120,7 +120,30 @@ def test_corpus_shards_balance_at_8_ranks():
     assert max(loads) / (sum(loads) / 8) <= 1.02, loads
 
 
-def _worker(rank, world, port, q, paths=None, product_parser=False):
+def check_pipeline_trace(trace, rank, nch, ring):
+    """what decode_sharded's trace must look like on a rank with `nch` chunks (task 6): a sender posts the send
+    of chunk k before it decodes chunk k + 1 and first waits for it when the buffer comes round again (behind decode k + 1);
+    the root posts receives before its first own decode and never has more than `ring` of them outstanding"""
+    at = {ev: n for n, ev in enumerate(trace)}
+    if rank != 0:
+        assert [e for e in trace if e[0] == "decode"] == [("decode", k) for k in range(nch)], trace
+        for k in range(nch - 1):
+            assert at[("send", k)] < at[("decode", k + 1)], trace
+        for k in range(nch - 2):
+            assert at[("decode", k + 1)] < at[("send_done", k)] < at[("decode", k + 2)], trace
+    else:
+        first_decode = min(n for n, e in enumerate(trace) if e[0] == "decode")
+        assert any(e[0] == "recv_posted" for e in trace[:first_decode]), trace
+        out = 0
+        for e in trace:
+            out += (e[0] == "recv_posted") - (e[0] == "recv_done")
+            assert 0 <= out <= ring, trace
+        posted = [e[1:] for e in trace if e[0] == "recv_posted"]
+        done = [e[1:] for e in trace if e[0] == "recv_done"]
+        assert posted == done and len(posted) >= 4, trace
+
+
+def _worker(rank, world, port, q, paths=None, product_parser=False, chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -133,8 +156,12 @@ def _worker(rank, world, port, q, paths=None, product_parser=False):
         else:
             # file images: every rank holds the same list, only ids are scattered
             files = corpus()
+        trace = []
+        nch = chunks or (2 if product_parser else 1)
         out = batch.decode_sharded(files, host_parse_decoder if product_parser else oracle_decoder, dist=dist, root=0,
-                                   device=torch.device("cpu"), chunks=2 if product_parser else 1)
+                                   device=torch.device("cpu"), chunks=nch, ring=2, trace=trace)
+        if chunks:
+            check_pipeline_trace(trace, rank, nch, 2)
         if rank == 0:
             check(out, corpus())
             q.put("ok")
@@ -146,8 +173,10 @@ def _worker(rank, world, port, q, paths=None, product_parser=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("by_path,product_parser", [(False, False), (True, False), (True, True)])
-def test_two_ranks_gloo(by_path, product_parser, tmp_path):
+@pytest.mark.parametrize("by_path,product_parser,chunks", [(False, False, None), (True, False, None), (True, True, None), (True, True, 5)])
+def test_two_ranks_gloo(by_path, product_parser, chunks, tmp_path):
+    """chunks=5: the pipelined C2 - send of chunk k under way while chunk k + 1 decodes, two receives at most outstanding on
+    the root - with the order of events asserted on both ranks (check_pipeline_trace)"""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -162,7 +191,7 @@ def test_two_ranks_gloo(by_path, product_parser, tmp_path):
             paths.append(str(p))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, paths, product_parser)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, paths, product_parser, chunks)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -197,7 +226,10 @@ def _nccl_worker(rank, world, port, q, paths):
     torch.cuda.set_device(ordinal)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", ordinal))
     try:
-        out = batch.decode_sharded(paths if rank == 0 else None, batch.GpuDecoder(ordinal), dist=dist, root=0, chunks=2)
+        trace = []
+        out = batch.decode_sharded(paths if rank == 0 else None, batch.GpuDecoder(ordinal), dist=dist, root=0, chunks=4, ring=2, trace=trace)
+        if world > 1:
+            check_pipeline_trace(trace, rank, 4, 2)
         if rank == 0:
             check(out, corpus())
             q.put("ok")

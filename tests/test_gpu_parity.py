@@ -563,6 +563,11 @@ def test_batch_prestaged(dev, pinned):
         assert capi.lib().acm_batch_decode(dev.h, items, len(files) - 1, C.byref(opts), None) != 0
         bufs2, items2 = capi._batch_items(files[::-1])
         assert capi.lib().acm_batch_decode(dev.h, items2, len(files), C.byref(opts), None) != 0
+        # the same buffers with another length (a reused buffer): refused, not copied into arenas laid out for the new length
+        items[3].len -= 40
+        assert capi.lib().acm_batch_decode(dev.h, items, len(files), C.byref(opts), None) != 0
+        items[3].len += 40
+        assert capi.lib().acm_batch_decode(dev.h, items, len(files), C.byref(opts), None) == 0
     finally:
         capi.lib().acm_batch_prestage_free(pre)
 

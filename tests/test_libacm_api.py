@@ -147,6 +147,38 @@ def test_short_reads_and_read_errors_discard():
             s.close()
 
 
+def test_window_buffers_follow_the_file_not_its_header():
+    """a header may promise 2^32 - 1 samples (decode.c:734-738 takes it as it is); the read-ahead buffers of the stream are sized by
+    what the data source can hold when it says how long it is, and by a 4-Msample window when it does not (they were
+    256 MB per open stream for such a file).  Decode-and-discard never touches a device, so this runs anywhere."""
+    import os
+    from helpers import make_stream
+
+    def vm_kb():
+        return int(open("/proc/self/statm").read().split()[0]) * os.sysconf("SC_PAGE_SIZE") // 1024
+    good = make_stream(4400, 9, 16, 6)
+    lying = bytearray(good)
+    lying[4:8] = (0xFFFFFFFF).to_bytes(4, "little")
+    for kw, limit_kb in (({}, 8 << 10), ({"with_length": False}, 40 << 10)):
+        before = vm_kb()
+        streams = [ours(bytes(lying), **kw) for _ in range(4)]
+        for s in streams:
+            assert s.err == 0
+            rc, _ = s.read(4096, discard=True)          # parses the first window (acm_read(NULL): decode.c:859-866)
+            assert rc == 4096
+        grown = (vm_kb() - before) // 4
+        for s in streams:
+            words = 2048
+            while True:                                 # ... and the stream still ends where its bytes end
+                rc, _ = s.read(1 << 20, discard=True)
+                if rc <= 0:
+                    break
+                words += rc // 2
+            assert words == 6 * 16 * 512
+            s.close()
+        assert grown < limit_kb, (kw, grown)
+
+
 def test_corrupt_streams_discard():
     for case in golden()["F3_corrupt"]:
         s = ours(golden_file(case["file"]))
