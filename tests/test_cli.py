@@ -125,7 +125,8 @@ def test_cli_detached_child_follows_its_parent(dev):
                 time.sleep(0.05)
             assert not os.path.exists("/proc/%d" % kids[0]) or open("/proc/%d/stat" % kids[0]).read().split(")")[1].split()[0] == "Z"
         # with a tool library announced in the environment: one process, same result
-        env2 = dict(env, ROCP_TOOL_LIBRARIES="/nonexistent/librocprofiler-sdk-tool.so")
+        # (a preload that does not exist: ld.so says so on stderr and goes on; ROCP_TOOL_LIBRARIES would make the runtime look for it)
+        env2 = dict(env, LD_PRELOAD="/nonexistent/librocprofiler-sdk-tool.so")
         open(os.path.join(td, "s.acm"), "wb").write(make_stream(7711, 7, 16, 40))
         p = subprocess.Popen([tool(), "-d", "-q", "-r", "s.acm"], cwd=td, env=env2, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         time.sleep(0.02)
