@@ -784,21 +784,23 @@ def main():
             try:
                 files = [f.tobytes() for f in batch.files]
                 e2e = {"streams": len(files), "host_threads": workload_cpus()}
-                for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("device_parse", capi.PARSE_DEVICE, False),
-                                        ("device_parse_pinned_out", capi.PARSE_DEVICE, True)):
+                for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("host_parse_packed_staging", capi.PARSE_HOST, False),
+                                        ("device_parse", capi.PARSE_DEVICE, False), ("device_parse_pinned_out", capi.PARSE_DEVICE, True)):
                     # pinned_out: the caller's PCM buffers are pinned (acmhip_host_alloc), read-back lands in them directly.
                     # The hosts of this pool are shared: single calls show 1.5-2 x outliers in any mode (profiles/pinned_out_probe.py,
                     # VERDICT r3 Weak 5), so every leg is the best of three calls behind one that sizes the arenas, all totals kept
-                    capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
+                    pkd = name == "host_parse_packed_staging"        # ACM_BATCH_STAGE_PACKED: the pool packs too, half the upload
+                    capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin, packed=pkd)
                     runs = []
                     for _ in range(1 if mode == capi.PARSE_HOST else 3):
-                        res, tm = capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin)
+                        res, tm = capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin, packed=pkd)
                         runs.append((tm.total_s, tm))
                         del res
                     tm = min(runs, key=lambda r: r[0])[1]
                     e2e[name] = {"msamples_s": round(tm.samples / tm.total_s / 1e6, 1), "parse_s": round(tm.stage_s, 3),
                                  "h2d_s": round(tm.h2d_s, 3), "kernel_s": round(tm.kernel_s, 4), "d2h_s": round(tm.d2h_s, 3),
-                                 "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed,
+                                 "total_s": round(tm.total_s, 3), "device_parsed": tm.device_parsed, "h2d_bytes": tm.h2d_bytes,
+                                 "packed_streams": tm.packed_streams,
                                  "total_s_every_call": [round(r[0], 3) for r in runs]}
                 out["end_to_end"] = e2e
             except Exception as e:

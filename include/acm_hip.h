@@ -282,6 +282,10 @@ typedef struct acm_batch_opts {
 } acm_batch_opts;
 
 /* opts->flags */
+#define ACM_BATCH_STAGE_PACKED 2u   /* host parsing only: the pool also packs the whole tiles of every clean stream (acmhip_pack_tiles) and the
+                                       upload carries the packed form + the int16 rows the other kernels still read (ragged tails) instead
+                                       of the whole int16 arena - about half the bytes over PCIe and through HBM, for ~30 % more host
+                                       work per stream and a synthesis launch that is 10-18 % slower (acm_tile2p).  Off by default. */
 #define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
                                        the PCM straight into it, stream by stream, instead of through the library's own pinned
                                        arena and a host copy (taken for streams of 64 KB of PCM and more on average) */
@@ -304,6 +308,8 @@ typedef struct acm_batch_timing {
 	double alloc_s;          /* pinned + device arena allocation */
 	uint64_t device_parsed;  /* ACM_BATCH_PARSE_DEVICE: streams staged by the device parser ... */
 	uint64_t host_parsed;    /* ... and streams (re)parsed by the host reader */
+	uint64_t packed_streams; /* ACM_BATCH_STAGE_PACKED: streams whose whole tiles travelled in packed form */
+	uint64_t h2d_bytes;      /* staged bytes (indices in either form, block headers, file images for the device parser) sent to the device */
 } acm_batch_timing;
 
 int  acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_t n,

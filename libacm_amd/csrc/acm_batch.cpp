@@ -159,6 +159,10 @@ struct Slot {
 	uint32_t chunk = 0;
 	bool ok = false;
 	bool host_staged = false;       /* staged by the host reader (its arena slice has to go H2D) */
+	/* ACM_BATCH_STAGE_PACKED: the stream's chunk-table entries (reserved from the headers), how many whole tiles the pool packed
+	 * (0: the stream travels as int16) and where its blobs landed in the blob arena */
+	uint64_t pk_chunk_off = 0, pk_chunk_cap = 0;
+	uint32_t pk_ntiles = 0;
 };
 
 /* Blocks a file can possibly hold: the header promises total_values, but arenas are sized by this - a block costs at
@@ -178,6 +182,8 @@ struct Chunk {
 	uint64_t idx_begin = 0, idx_end = 0;    /* arena ranges (int16 units; the PCM arena has the same layout) */
 	uint64_t hdr_begin = 0, hdr_end = 0;
 	std::atomic<int> unparsed{ 0 };
+	std::atomic<uint64_t> pk_used{ 0 };     /* ACM_BATCH_STAGE_PACKED: bytes of this chunk's blob region handed out so far */
+	uint64_t pk_chunk_begin = 0, pk_chunk_end = 0;  /* its range of the chunk table (entries) */
 	std::atomic<int> back{ 0 };             /* 1 = PCM is in the pinned arena, -1 = the read-back failed */
 	acmhip_plan *plan = nullptr;
 	hipEvent_t ev[5] = {};                  /* h2d begin, h2d end, kernel end (device stream); d2h begin, d2h end (copy stream) */
@@ -460,6 +466,27 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 	}
 
+	/* the packed staged form (opt-in, host parsing): chunk-table entries are reserved per stream from what the headers promise;
+	 * a pipeline chunk's blobs share the region of the blob arena that mirrors its slice of the int16 arena (a stream whose
+	 * packed form does not fit there - indices that need 16 bits throughout - simply travels as int16) */
+	bool stage_packed = (opts.flags & ACM_BATCH_STAGE_PACKED) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
+			    !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
+	uint64_t pk_chunks_total = 0;
+	if (stage_packed)
+		for (size_t c = 0; c < chunks.size(); c++) {
+			chunks[c].pk_chunk_begin = pk_chunks_total;
+			for (size_t i = chunks[c].first; i < chunks[c].last; i++) {
+				Slot &s = slots[i];
+				const int tr = s.ok ? acmhip_packed_tile_rows(s.info.level) : 0;
+				if (tr <= 0)
+					continue;
+				s.pk_chunk_off = pk_chunks_total;
+				s.pk_chunk_cap = s.need_blocks * s.info.rows / (uint64_t)tr * (uint64_t)acmhip_packed_slots(s.info.level);
+				pk_chunks_total += s.pk_chunk_cap;
+			}
+			chunks[c].pk_chunk_end = pk_chunks_total;
+		}
+
 	/* AUTO: the device walk takes as long as the longest stream takes one wavefront, the host pool takes total / threads.
 	 * Measured (profiles/r2_parse_probe.txt): a wavefront alone on its SIMD walks at ~1/5 of a host core's parsing rate
 	 * (up to 1024 streams), with four per SIMD at ~1/9 (up to the 32 K streams acm_parse_scan_wave takes), a lane of
@@ -473,6 +500,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		const uint64_t per_thread = n <= 1024 ? 5 : n <= 32768 ? 9 : 16;
 		dev_parse = longest > 0 && idx_total / longest >= per_thread * (uint64_t)threads_wanted;
 	}
+	if (dev_parse)
+		stage_packed = false;           /* the device parser stages int16 */
 	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
@@ -540,6 +569,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	uint32_t *d_colpos = nullptr;
 	acmhip_blkhdr *h_hdr = nullptr, *d_hdr = nullptr;
 	uint8_t *h_files = nullptr, *d_files = nullptr, *h_jobs = nullptr, *d_jobs = nullptr;
+	uint8_t *h_pkblob = nullptr, *d_pkblob = nullptr;
+	acmhip_packed_chunk *h_pkchunk = nullptr, *d_pkchunk = nullptr;
+	const uint64_t pk_blob_bytes = idx_total * sizeof(int16_t) + 4096;     /* region of chunk c = bytes [2 idx_begin, 2 idx_end) */
 	hipStream_t st_main = (hipStream_t)acmhip_device_stream(dev), st_copy = nullptr;
 	int rc = ACMHIP_OK;
 	std::mutex m;
@@ -595,6 +627,14 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_IDX, idx_total * sizeof(int16_t), (void **)&h_idx));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_HDR, hdr_total * sizeof(acmhip_blkhdr), (void **)&h_hdr));
 	}
+	if (stage_packed && pk_chunks_total) {
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKBLOB, pk_blob_bytes, (void **)&h_pkblob));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKBLOB, pk_blob_bytes, (void **)&d_pkblob));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKCHUNK, pk_chunks_total * sizeof(acmhip_packed_chunk), (void **)&h_pkchunk));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKCHUNK, pk_chunks_total * sizeof(acmhip_packed_chunk), (void **)&d_pkchunk));
+	} else {
+		stage_packed = false;
+	}
 	if (!keep_on_device && !direct_out)
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_arena_words * sizeof(int16_t), (void **)&h_pcm));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
@@ -643,8 +683,40 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	tm.alloc_s = secs(t_hdr, t_alloc);
 	BNOTE("headers %.3f ms, arenas + events %.3f ms; %zu chunks, %zu parse groups", secs(t0, t_hdr) * 1e3, tm.alloc_s * 1e3, chunks.size(), groups.size());
 
+	/* the packed half of the host stager: the whole tiles of a clean stream, from the int16 rows the reader has just written
+	 * (they are still in the cache), into the chunk's region of the blob arena */
+	auto host_pack = [&](size_t i) {
+		Slot &s = slots[i];
+		if (!stage_packed || !s.ok || !s.pk_chunk_cap || !s.patches.empty() || items[i].words == 0)
+			return;
+		const int tr = acmhip_packed_tile_rows(s.info.level);
+		const uint64_t full_rows = std::min<uint64_t>((uint64_t)s.info.blocks * s.info.rows, items[i].words >> s.info.level);
+		const uint64_t ntiles = full_rows / (uint64_t)tr, slots_per = (uint64_t)acmhip_packed_slots(s.info.level);
+		if (ntiles == 0 || ntiles * slots_per > s.pk_chunk_cap)
+			return;
+		uint64_t bound = 0;
+		if (acmhip_pack_bound(s.info.level, ntiles, &bound) != ACMHIP_OK)
+			return;
+		static thread_local std::vector<uint8_t> scratch;
+		if (scratch.size() < bound)
+			scratch.resize(bound);
+		uint64_t bytes = 0;
+		acmhip_packed_chunk *tc = h_pkchunk + s.pk_chunk_off;
+		if (acmhip_pack_tiles(s.info.level, h_idx + s.idx_off, ntiles, tc, scratch.data(), 0, &bytes) != ACMHIP_OK)
+			return;
+		Chunk &ch = chunks[s.chunk];
+		const uint64_t region = ch.idx_begin * sizeof(int16_t), region_len = (ch.idx_end - ch.idx_begin) * sizeof(int16_t);
+		const uint64_t at = ch.pk_used.fetch_add((bytes + 15) & ~15ull);
+		if (at + bytes > region_len)
+			return;                 /* does not fit beside the others: this stream travels as int16 (its entries stay unused) */
+		memcpy(h_pkblob + region + at, scratch.data(), bytes);
+		for (uint64_t k = 0; k < ntiles * slots_per; k++)
+			if (tc[k].kind)
+				tc[k].blob_off16 += (uint32_t)((region + at) / 16);
+		s.pk_ntiles = (uint32_t)ntiles;
+	};
 	/* the exact host reader, one stream */
-	auto host_stage = [&](size_t i) {
+	auto host_stage_int16 = [&](size_t i) {
 		Slot &s = slots[i];
 		acm_batch_item &it = items[i];
 		acm_stage_info info{};
@@ -688,6 +760,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		s.host_staged = true;
 		it.status = info.end_status;
 		it.words = deliverable_words(info.total_values, (uint64_t)info.rows * info.cols, info.channels, info.blocks);
+	};
+	auto host_stage = [&](size_t i) {
+		host_stage_int16(i);
+		host_pack(i);
 	};
 
 	/* 2a. device parsing (optional): the streams the device parser takes are copied into the pinned file arena by the pool,
@@ -857,10 +933,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		Chunk &ch = chunks[c];
 		std::vector<acmhip_stream_desc> descs;
 		std::vector<acmhip_patch> patches;
+		std::vector<acmhip_packed_stream> packed;
 		for (size_t i = ch.first; i < ch.last; i++) {
 			Slot &s = slots[i];
 			if (!s.ok || items[i].words == 0)
 				continue;
+			packed.push_back(acmhip_packed_stream{ s.pk_chunk_off, s.pk_ntiles, 0 });
 			acmhip_stream_desc d{};
 			d.idx_off = s.idx_off;
 			d.hdr_off = s.hdr_off;
@@ -884,7 +962,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 		if (descs.empty())
 			return ACMHIP_OK;
-		return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
+		if (!stage_packed)
+			return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
+		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
+		if (r == ACMHIP_OK)
+			r = acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
+		return r;
 	};
 	/* chunks made of device-parsed streams only: their plans are cut NOW, from what the headers promise (a stream the
 	 * device parser flags later gets its chunk's plan rebuilt), while the queues are still empty - a plan's small table
@@ -1097,7 +1180,38 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				tm.samples += items[i].words;
 		if (ch.plan) {
 			HTRY(hipEventRecord(ch.ev[0], st_main));
-			if (!dev_parse) {
+			if (!dev_parse && stage_packed) {
+				/* the packed form of the chunk: the used front of its blob region, its chunk-table entries; of the int16 arena only
+				 * what the other kernels read - streams that were not packed, and behind a packed stream's whole tiles its ragged
+				 * tail with the two rows in front of it */
+				const uint64_t region = ch.idx_begin * sizeof(int16_t), region_len = (ch.idx_end - ch.idx_begin) * sizeof(int16_t);
+				const uint64_t used = std::min<uint64_t>(ch.pk_used.load(), region_len);
+				if (used)
+					HTRY(hipMemcpyAsync(d_pkblob + region, h_pkblob + region, used, hipMemcpyHostToDevice, st_main));
+				tm.h2d_bytes += used + (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk) + (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
+				if (ch.pk_chunk_end > ch.pk_chunk_begin)
+					HTRY(hipMemcpyAsync(d_pkchunk + ch.pk_chunk_begin, h_pkchunk + ch.pk_chunk_begin,
+							    (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk), hipMemcpyHostToDevice, st_main));
+				for (size_t i = ch.first; i < ch.last; i++) {
+					const Slot &s = slots[i];
+					if (!s.ok || s.info.blocks == 0)
+						continue;
+					const uint64_t cols = s.info.cols, nrows = (uint64_t)s.info.blocks * s.info.rows;
+					uint64_t from_row = 0;
+					if (s.pk_ntiles) {
+						const uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)acmhip_packed_tile_rows(s.info.level);
+						if (rows2 * cols >= items[i].words)
+							continue;               /* nothing behind the whole tiles is emitted */
+						from_row = rows2 >= 2 ? rows2 - 2 : 0;
+					}
+					HTRY(hipMemcpyAsync(d_idx + s.idx_off + from_row * cols, h_idx + s.idx_off + from_row * cols,
+							    (nrows - from_row) * cols * sizeof(int16_t), hipMemcpyHostToDevice, st_main));
+					tm.h2d_bytes += (nrows - from_row) * cols * sizeof(int16_t);
+				}
+				HTRY(hipMemcpyAsync(d_hdr + ch.hdr_begin, h_hdr + ch.hdr_begin, (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr),
+						    hipMemcpyHostToDevice, st_main));
+			} else if (!dev_parse) {
+				tm.h2d_bytes += (ch.idx_end - ch.idx_begin) * sizeof(int16_t) + (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
 				HTRY(hipMemcpyAsync(d_idx + ch.idx_begin, h_idx + ch.idx_begin, (ch.idx_end - ch.idx_begin) * sizeof(int16_t),
 						    hipMemcpyHostToDevice, st_main));
 				HTRY(hipMemcpyAsync(d_hdr + ch.hdr_begin, h_hdr + ch.hdr_begin, (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr),
@@ -1241,6 +1355,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			h2d_files_s = ms * 1e-3;
 	}
 	tm.h2d_s += h2d_files_s;
+	if (dev_parse)
+		tm.h2d_bytes += files_total;
+	for (const Slot &s : slots)
+		tm.packed_streams += s.pk_ntiles != 0;
 	/* host-side staging: headers, then until the last stream was parsed - by the pool, or by the device (whose walks
 	 * overlap the uploads of the later groups and the synthesis / read-back of the earlier ones) */
 	tm.stage_s = secs(t0, t_hdr) + std::max(secs(t_alloc, t_parsed), secs(t_alloc, t_dev_parsed));

@@ -94,8 +94,9 @@ extern "C" {
  * from ACM_ARENA_D_IDX on.  hipHostMalloc of gigabytes costs ~0.1 s; the batch front end reuses them across
  * calls.  A device handle serves one batch at a time (acmhip_arena_lock/unlock bracket acm_batch_decode). */
 enum {
-	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS,
+	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS, ACM_ARENA_H_PKBLOB, ACM_ARENA_H_PKCHUNK,
 	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_COLPOS, ACM_ARENA_D_JOBS, ACM_ARENA_D_STAGE,
+	ACM_ARENA_D_PKBLOB, ACM_ARENA_D_PKCHUNK,
 	ACM_ARENA_SLOTS
 };
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);

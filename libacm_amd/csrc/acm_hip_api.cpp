@@ -767,8 +767,10 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
 			const size_t n2 = tiles2[lv].size() + tiles2p[lv].size();
+			/* streams that came with a packed form always take the lean kernel: their caller may have staged nothing else for
+			 * these rows (acm_batch_decode with ACM_BATCH_STAGE_PACKED uploads the int16 form of the ragged tails only) */
 			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? n2 > 0         /* levels 13, 14: decided before the cut */
-						  : getenv("ACM_K2") ? n2 > 0 : n2 >= 8 * grid2);
+						  : getenv("ACM_K2") ? n2 > 0 : (n2 >= 8 * grid2 || !tiles2p[lv].empty()));
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();

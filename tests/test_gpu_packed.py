@@ -107,3 +107,36 @@ def test_packed_and_int16_launches_of_one_plan_agree(dev, force_k2):
     plan.destroy()
     for p in (d_idx, d_hdr, d_pcm) + ptrs:
         dev.free(p)
+
+
+@pytest.mark.parametrize("prestage", [False, True])
+def test_batch_decode_stages_packed(dev, prestage):
+    """acm_batch_decode with ACM_BATCH_STAGE_PACKED: the host pool packs the whole tiles of every clean stream of a level that
+    has the form, the upload carries the packed form and the int16 rows of the ragged tails only - same PCM and statuses as the
+    oracle for clean, ragged, stereo, truncated, H1-patched, tiny and non-ACM files of every level, fewer bytes over PCIe"""
+    import oracle_api as O
+    files = [make_stream(17000 + i, [7, 9, 5, 8, 11, 6, 13, 9][i % 8], [16, 3, 1, 33][i % 4], 3 + (i * 7) % 23 + (8192 >> [7, 9, 5, 8, 11, 6, 13, 9][i % 8]) // 4,
+                         channels=1 + i % 2, cut=i % 5, pwr_max=[12, 6, 15][i % 3], val_max=65535 if i % 3 == 2 else 255) for i in range(61)]
+    files[5] = files[5][:len(files[5]) * 2 // 3]
+    files[11] = b"RIFFnope"
+    files[17] = make_stream(17990, 7, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    files[23] = make_stream(17991, 9, 16, 1)                 # one block = one tile exactly: nothing travels as int16
+    files[29] = make_stream(17992, 9, 16, 64, mix=2, single_code=16, pwr_min=15, pwr_max=15)     # 16-bit indices throughout
+    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage)
+    res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, packed=True)
+    assert tm0.packed_streams == 0 and tm.packed_streams >= 25, (tm0.packed_streams, tm.packed_streams)
+    assert tm.h2d_bytes < 0.8 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
+    for k, f in enumerate(files):
+        o = O.Oracle(f)
+        if o.err < 0:
+            assert res[k][0] == o.err and res[k][1].size == 0, k
+            continue
+        want, wst = oracle_pcm(f)
+        assert res[k][0] == wst and np.array_equal(res[k][1], want), k
+        assert plain[k][0] == wst and np.array_equal(plain[k][1], want), k
+    # the device parser stages int16: the flag is ignored there
+    res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, packed=True)
+    assert tm.packed_streams == 0
+    for k, f in enumerate(files):
+        if O.Oracle(f).err >= 0:
+            assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
