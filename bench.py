@@ -668,6 +668,8 @@ def main():
         key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
         if args.channels != 1:
             key += "_ch%d" % args.channels
+        if args.packed:
+            key += "_packed"
         if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
             traffic = tj[key]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r4_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
