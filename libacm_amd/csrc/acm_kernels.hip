@@ -419,18 +419,6 @@ __device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t
 #undef ACM_SDWA_MUL
 }
 
-/* byte units of the packed staged form (acm_tile2p): one loaded register holds a 2 x 2 block of int8 indices - bytes (row, col), (row, col + 1),
- * (row + 1, col), (row + 1, col + 1) - and SDWA picks and sign-extends the byte inside the multiply, as it does with the 16-bit words */
-__device__ __forceinline__ void mul_idx8_val(const uint32_t r, const int32_t val0, const int32_t val1, uint32_t &r0c0, uint32_t &r0c1,
-					     uint32_t &r1c0, uint32_t &r1c1)
-{
-#define ACM_SDWA_MUL8(D, VAL, BYTE) "v_mul_i32_i24_sdwa " D ", sext(%4), " VAL " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" BYTE " src1_sel:DWORD\n\t"
-	asm(ACM_SDWA_MUL8("%0", "%5", "BYTE_0") ACM_SDWA_MUL8("%1", "%5", "BYTE_1") ACM_SDWA_MUL8("%2", "%6", "BYTE_2") ACM_SDWA_MUL8("%3", "%6", "BYTE_3")
-	    : "=&v"(r0c0), "=&v"(r0c1), "=&v"(r1c0), "=&v"(r1c1)
-	    : "v"(r), "v"(val0), "v"(val1));
-#undef ACM_SDWA_MUL8
-}
-
 /* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
 __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
