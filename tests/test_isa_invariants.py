@@ -116,6 +116,11 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                     continue
                 bad = reads_of(op, ops, text) & pending
                 assert not bad, "%s line %d reads v%s while its load is in flight: %s" % (name[:60], ln, sorted(bad), text)
+                # ... nor WRITE one: a loaded value the compiler finds dead (round 4 met the first positions of a warm-up body once
+                # their multiplies were single statements) leaves its register free for anything else while the load is still on its way
+                if not op.startswith(("global_store", "ds_write", "s_", "buffer_store")) and ops:
+                    clobbered = regs_of(ops[0]) & pending
+                    assert not clobbered, "%s line %d writes v%s while a load into it is in flight: %s" % (name[:60], ln, sorted(clobbered), text)
                 if op.startswith("global_load"):
                     pending |= regs_of(ops[0])
             for t in blocks[k][2]:
