@@ -143,6 +143,43 @@ def check_pipeline_trace(trace, rank, nch, ring):
         assert posted == done and len(posted) >= 4, trace
 
 
+def _worker_few(rank, world, port, q, nfiles):
+    """fewer files than ranks / than chunks: a rank may get nothing at all, a chunk plan may be empty"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        files = corpus()[:nfiles]
+        out = batch.decode_sharded(files, oracle_decoder, dist=dist, root=0, device=torch.device("cpu"), chunks=4, ring=1)
+        if rank == 0:
+            check(out, files)
+            q.put("ok")
+    except Exception as e:
+        q.put("rank %d: %r" % (rank, e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nfiles", [0, 1, 3])
+def test_two_ranks_gloo_fewer_files_than_ranks_or_chunks(nfiles):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_few, args=(r, 2, port, q, nfiles)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
+
+
 def _worker(rank, world, port, q, paths=None, product_parser=False, chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
