@@ -165,10 +165,14 @@ typedef struct acmhip_packed_chunk {
 
 /* beside acmhip_stream_desc i: rows [0, ntiles * tile_rows) of the stream are staged in packed form as well */
 typedef struct acmhip_packed_stream {
-	uint64_t chunk_off;      /* the chunk-table entry the stream's first tile starts at (tile k: chunk_off + k * slots of its level) */
-	uint32_t ntiles;         /* 0: this stream has no packed form */
-	uint32_t reserved;
+	uint64_t chunk_off;      /* ACMHIP_FORM_PACKED: the chunk-table entry the stream's first tile starts at (tile k: chunk_off + k * slots
+				  * of its level);  ACMHIP_FORM_BYTEPLANE: where the stream's byte-plane block (acmhip_mform_rows) starts in
+				  * the byte-plane arena, in 2-byte units */
+	uint32_t ntiles;         /* 0: this stream has no second staged form */
+	uint32_t form;           /* ACMHIP_FORM_* */
 } acmhip_packed_stream;
+#define ACMHIP_FORM_PACKED    0u
+#define ACMHIP_FORM_BYTEPLANE 1u
 
 int  acmhip_packed_tile_rows(uint32_t level);     /* rows per packed tile, 0 if the level has no packed form */
 int  acmhip_packed_group_rows(uint32_t level);    /* rows that share one width class per column pair */
@@ -194,6 +198,33 @@ int  acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream_desc *str
 /* device tables the packed tiles of this plan are read from by every later launch (both NULL: back to the int16 form) */
 int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob);
 
+/* ------------------------------------------------------------------------
+ * Byte-plane staged form: the int16 form's two bytes per sample, in the order the matrix cores take them.
+ *
+ * The first three stages of the cascade (decode.c:527-590) are linear; over one residue class of the columns (columns
+ * c + q * cols/8, q = 0..7) they are one banded 16 x 32 integer matrix per row pair, and a level whose lean-kernel
+ * build starts with a three-stage pass (acmhip_mform_tile_rows(level) != 0) has a build that runs that matrix on
+ * v_mfma_i32_16x16x32_i8 instead of the vector ALU.  Its B operand wants, per row and per residue c < cols/8, the
+ * eight low bytes of the indices of columns c, c + cols/8, ... (stored minus 128, i.e. with bit 7 flipped, so that they
+ * are signed bytes; the kernel adds the 128 back through the accumulator) followed by their eight high bytes:
+ *
+ *   block of a stream = 2 rows of zeros (what the cascade sees in front of row 0), then its rows;
+ *   row               = cols/8 residues x 16 bytes: lo(c), lo(c + cols/8), ... lo(c + 7 cols/8), hi(c), ... hi(c + 7 cols/8)
+ *                       with lo(x) = (idx[x] & 0xff) ^ 0x80, hi(x) = idx[x] >> 8
+ *
+ * Same size as the int16 form (plus the two rows), same tiles, same records; only whole tiles are staged this way, the
+ * ragged tail of a stream stays int16 (as with the packed form).
+ * ---------------------------------------------------------------------- */
+int  acmhip_mform_tile_rows(uint32_t level);     /* rows per tile of the matrix-core build, 0 if the level has none */
+/* bytes of a block holding nrows rows (incl. the two rows of zeros in front) */
+uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);
+/* host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them) -> out[acmhip_mform_bytes(level, nrows)] */
+int  acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out);
+/* the inverse, for tests and tools */
+int  acmhip_mform_unrows(uint32_t level, const uint8_t *block, uint64_t nrows, int16_t *idx);
+/* device arena the byte-plane tiles of this plan are read from by every later launch (NULL: back to the int16 form) */
+int  acmhip_plan_bind_mform(acmhip_plan *plan, const uint8_t *d_mform);
+
 /* introspection for benchmarks/tests */
 typedef struct acmhip_plan_stats {
 	uint64_t samples;        /* total n_emit */
@@ -201,7 +232,8 @@ typedef struct acmhip_plan_stats {
 	uint32_t fused_streams;  /* streams handled by a one-launch kernel (fused tile kernel, levels 5-12; register kernel, levels 0-4) */
 	uint32_t stagewise_streams;
 	uint32_t launches;       /* kernel launches per acmhip_plan_launch */
-	uint32_t reserved[2];
+	uint32_t reserved;
+	uint32_t mform_tiles;    /* tiles of streams that came with a byte-plane form (read from it while an arena is bound: acmhip_plan_bind_mform) */
 	uint32_t packed_tiles;   /* tiles that have records of the packed build too (read in packed form while arenas are bound: acmhip_plan_bind_packed) */
 } acmhip_plan_stats;
 int  acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out);

@@ -33,8 +33,8 @@ class StreamDesc(C.Structure):
 
 class PlanStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("tiles", C.c_uint64), ("fused_streams", C.c_uint32),
-                ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("reserved", C.c_uint32 * 2),
-                ("packed_tiles", C.c_uint32)]
+                ("stagewise_streams", C.c_uint32), ("launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("mform_tiles", C.c_uint32), ("packed_tiles", C.c_uint32)]
 
 
 class PackedChunk(C.Structure):
@@ -42,7 +42,10 @@ class PackedChunk(C.Structure):
 
 
 class PackedStream(C.Structure):
-    _fields_ = [("chunk_off", C.c_uint64), ("ntiles", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("chunk_off", C.c_uint64), ("ntiles", C.c_uint32), ("form", C.c_uint32)]
+
+
+FORM_PACKED, FORM_BYTEPLANE = 0, 1
 
 
 PACKED_CHUNK_DT = np.dtype([("blob_off16", "<u4"), ("count", "<u2"), ("kind", "u1"), ("row0", "u1")])
@@ -83,6 +86,7 @@ ACMHIP_SYMBOLS = [
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
+    "acmhip_mform_tile_rows", "acmhip_mform_bytes", "acmhip_mform_rows", "acmhip_mform_unrows", "acmhip_plan_bind_mform",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -148,6 +152,12 @@ def lib():
     L.acmhip_unpack_tile.argtypes = [C.c_uint32, vp, vp, vp]
     L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(PackedStream), C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_bind_packed.argtypes = [vp, vp, vp]
+    L.acmhip_mform_tile_rows.argtypes = [C.c_uint32]
+    L.acmhip_mform_bytes.argtypes = [C.c_uint32, C.c_uint64]
+    L.acmhip_mform_bytes.restype = C.c_uint64
+    L.acmhip_mform_rows.argtypes = [C.c_uint32, vp, C.c_uint64, vp]
+    L.acmhip_mform_unrows.argtypes = [C.c_uint32, vp, C.c_uint64, vp]
+    L.acmhip_plan_bind_mform.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -254,6 +264,57 @@ class PackedArena:
     @property
     def nbytes(self):
         return self.chunks.nbytes + self.blob.nbytes
+
+
+class MformArena:
+    """The byte-plane staged form (acmhip_mform_rows) of several streams in one host array (.data, uint8) and .streams
+    (PackedStream with form = FORM_BYTEPLANE beside each stream descriptor)."""
+
+    def __init__(self, data, streams):
+        self.data, self.streams = data, streams
+
+    def upload(self, dev):
+        p = dev.malloc(max(self.data.nbytes, 16))
+        for o in range(0, self.data.size, 1 << 28):
+            dev.upload(p + o, self.data[o:o + (1 << 28)])
+        return p
+
+    @property
+    def nbytes(self):
+        return self.data.nbytes
+
+
+def mform_streams(idx, descs, threads=1):
+    """The byte-plane form of every stream of a staged arena that can have one (whole tiles from row 0 of the levels
+    acmhip_mform_tile_rows() covers)."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    n = len(descs)
+    ntiles, off, rows = [0] * n, [0] * n, [0] * n
+    at = 0
+    for i, d in enumerate(descs):
+        tr = L.acmhip_mform_tile_rows(d.level)
+        if tr > 0 and d.row_begin == 0:
+            ntiles[i] = min(d.nrows, d.n_emit >> d.level) // tr
+            rows[i] = ntiles[i] * tr
+        off[i] = at
+        if ntiles[i]:
+            at += (L.acmhip_mform_bytes(d.level, rows[i]) + 255) // 256 * 256
+    data = np.zeros(max(at, 16), dtype=np.uint8)
+
+    def one(i):
+        if ntiles[i]:
+            d = descs[i]
+            _check(L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], data[off[i]:].ctypes.data), "acmhip_mform_rows")
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(one, range(n)))
+    return MformArena(data, [PackedStream(off[i] // 2, ntiles[i], FORM_BYTEPLANE) for i in range(n)])
+
+
+def mform_unrows(level, block, nrows):
+    out = np.zeros(nrows << level, dtype=np.int16)
+    _check(lib().acmhip_mform_unrows(level, block.ctypes.data, nrows, out.ctypes.data), "acmhip_mform_unrows")
+    return out
 
 
 def pack_streams(idx, descs, threads=1):
@@ -380,6 +441,10 @@ class Plan:
         """device tables of the packed staged form for every later launch (both None: back to the int16 arena)"""
         _check(lib().acmhip_plan_bind_packed(self.h, d_chunks, d_blob), "acmhip_plan_bind_packed")
 
+    def bind_mform(self, d_mform):
+        """device arena of the byte-plane staged form for every later launch (None: back to the int16 arena)"""
+        _check(lib().acmhip_plan_bind_mform(self.h, d_mform), "acmhip_plan_bind_mform")
+
     def launch(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE):
         _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
 
@@ -442,10 +507,11 @@ class Arena:
         self.patches = (Patch * len(self.patch_list))(*self.patch_list) if self.patch_list else None
 
 
-def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, packed=False):
+def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return_stats=False, patch_subset=None, packed=False, mform=False):
     """Upload staged streams, run the hot path once, return one PCM array (uint16 view of the bytes) per stream.
     patch_subset (tests): keep only these entries of the batch's H1 patch list.
-    packed: stage the packed form too (acmhip_pack_tiles) and bind it: whole tiles from row 0 are read from it."""
+    packed: stage the packed form too (acmhip_pack_tiles) and bind it: whole tiles from row 0 are read from it.
+    mform: the same with the byte-plane form (acmhip_mform_rows) and the matrix-core build of the lean kernel."""
     ar = Arena(staged_list, windows)
     if patch_subset is not None and ar.patch_list:
         ar.patch_list = [ar.patch_list[k] for k in patch_subset]
@@ -463,8 +529,16 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
             for i in patched:
                 pk.streams[i].ntiles = 0
             pk_ptrs = pk.upload(dev)
+        elif mform:
+            patched = {p.stream for p in ar.patch_list}
+            pk = mform_streams(ar.idx, ar.descs)
+            for i in patched:
+                pk.streams[i].ntiles = 0
+            pk_ptrs = (pk.upload(dev),)
         plan = Plan(dev, ar.descs, ar.patches, flags, packed=pk.streams if pk else None)
-        if pk:
+        if pk and mform:
+            plan.bind_mform(pk_ptrs[0])
+        elif pk:
             plan.bind_packed(*pk_ptrs)
         plan.launch(d_idx, d_hdr, d_pcm, fmt)
         out = np.zeros(ar.pcm_words, dtype=np.uint16)

@@ -84,6 +84,10 @@ struct AcmParseResult {
  * workgroups per CU whose two-row stage-0 history fits LDS beside the tile */
 #define ACM_K2P_MIN_LEVEL 6
 #define ACM_K2P_MAX_LEVEL 9
+/* levels whose acm_tile2 build has a three-stage first pass and therefore a build that runs it on the matrix cores, fed with the
+ * byte-plane staged form (acmhip_mform_rows) */
+#define ACM_K2M_MIN_LEVEL 7
+#define ACM_K2M_MAX_LEVEL 12
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 
@@ -129,6 +133,10 @@ int acmk_tile2p_waves(uint32_t level);
 int acmk_tile2p_pad_shift(uint32_t level);                      /* the tile's LDS rows carry one pad dword per 2^shift elements */
 int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob,
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
+/* the byte-plane staged form: the same tile records as acm_tile2 (idx_off counts staged samples = two bytes each in either form) */
+int acmk_tile2m_rows(uint32_t level);                           /* = acmk_tile2_rows, 0 if the level has no such build */
+int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_blkhdr *d_hdr,
+		       int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);
 int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,

@@ -78,6 +78,9 @@ struct LevelGroup {
 	 * number) and as plain acm_tile2 records over the int16 arena, which a launch uses while no packed arenas are bound */
 	AcmTile2 *d_tiles2p = nullptr, *d_tiles2p_plain = nullptr;
 	uint32_t ntiles2p = 0;
+	/* the same for streams that came with a byte-plane form (acm_tile2's matrix-core build) */
+	AcmTile2 *d_tiles2m = nullptr, *d_tiles2m_plain = nullptr;
+	uint32_t ntiles2m = 0;
 	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
 	uint32_t ntiles_extra = 0;
 	uint32_t *d_list = nullptr;
@@ -104,6 +107,7 @@ struct acmhip_plan {
 	acmhip_plan_stats stats{};
 	const acmhip_packed_chunk *pk_chunks = nullptr; /* acmhip_plan_bind_packed: device tables of the packed staged form */
 	const uint8_t *pk_blob = nullptr;
+	const uint8_t *mform = nullptr;                 /* acmhip_plan_bind_mform */
 	int variant = 0;                        /* fused-kernel variant the tile tables were cut for */
 	/* several tile-kernel groups (a corpus of mixed levels): their launches are independent, so they go round robin
 	 * over the device stream and two side streams - the ramp-up and the tail of one launch overlap the next one's
@@ -491,7 +495,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		patch_rows[patches[p].stream].push_back(patches[p].sample >> streams[patches[p].stream].level);
 	for (auto &v : patch_rows)
 		std::sort(v.begin(), v.end());
-	std::vector<std::vector<AcmTile2>> tiles2(16), tiles2p(16), tiles2p_plain(16);
+	std::vector<std::vector<AcmTile2>> tiles2(16), tiles2p(16), tiles2p_plain(16), tiles2m(16), tiles2m_plain(16);
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
 	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
@@ -596,12 +600,18 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				rows2 = full_rows / T2 * T2;
 				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
 				/* a stream that came with its packed form: the same tiles once more as records of the packed build */
-				const bool pk = packed && packed[i].ntiles && acmk_tile2p_rows(s.level) == (int)T2;
-				if (pk && packed[i].ntiles < rows2 / T2) {
-					set_err("stream %zu: %u packed tiles, %llu whole tiles to decode", i, packed[i].ntiles, (unsigned long long)(rows2 / T2));
+				if (packed && packed[i].ntiles && packed[i].form > ACMHIP_FORM_BYTEPLANE) {
+					set_err("stream %zu: staged form %u", i, packed[i].form);
 					return ACMHIP_ERR_ARG;
 				}
-				std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : tiles2[s.level];
+				const bool pk = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_PACKED && acmk_tile2p_rows(s.level) == (int)T2;
+				const bool mf = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_BYTEPLANE && acmk_tile2m_rows(s.level) == (int)T2;
+				if ((pk || mf) && packed[i].ntiles < rows2 / T2) {
+					set_err("stream %zu: %u tiles in its second staged form, %llu whole tiles to decode", i, packed[i].ntiles,
+						(unsigned long long)(rows2 / T2));
+					return ACMHIP_ERR_ARG;
+				}
+				std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : mf ? tiles2m_plain[s.level] : tiles2[s.level];
 				for (uint64_t r = 0; r < rows2; r += T2) {
 					const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
 					plain.push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
@@ -610,6 +620,11 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 					if (pk)
 						tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
 										     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
+										     r == 0 ? ACM_TILE_FRESH : 0u });
+					/* the byte-plane block holds the same rows at the same spacing, two rows of zeros in front */
+					if (mf)
+						tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + ((r + 2) << s.level), s.pcm_off + (r << s.level),
+										     (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
 										     r == 0 ? ACM_TILE_FRESH : 0u });
 				}
 			}
@@ -752,7 +767,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	pl->variant = variant;
 	int rc = to_device(pl, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
-		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty() || !tiles2p[lv].empty()) {
+		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty() || !tiles2p[lv].empty() || !tiles2m[lv].empty()) {
 			LevelGroup g;
 			g.level = lv;
 			if (!tiles_extra[lv].empty()) {
@@ -766,11 +781,11 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			const size_t grid = (size_t)acmk_fused_grid(lv, variant, dev->cus);
 			/* the lean kernel replays one tile per workgroup as a lead-in: worth it from a few tiles per workgroup on */
 			const size_t grid2 = (size_t)acmk_tile2_grid(lv, dev->cus);
-			const size_t n2 = tiles2[lv].size() + tiles2p[lv].size();
+			const size_t n2 = tiles2[lv].size() + tiles2p[lv].size() + tiles2m[lv].size();
 			/* streams that came with a packed form always take the lean kernel: their caller may have staged nothing else for
 			 * these rows (acm_batch_decode with ACM_BATCH_STAGE_PACKED uploads the int16 form of the ragged tails only) */
 			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? n2 > 0         /* levels 13, 14: decided before the cut */
-						  : getenv("ACM_K2") ? n2 > 0 : (n2 >= 8 * grid2 || !tiles2p[lv].empty()));
+						  : getenv("ACM_K2") ? n2 > 0 : (n2 >= 8 * grid2 || !tiles2p[lv].empty() || !tiles2m[lv].empty()));
 			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
@@ -789,6 +804,15 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 						rc = to_device(pl, tiles2p_plain[lv], &g.d_tiles2p_plain);
 					st.tiles += g.ntiles2p;
 					st.packed_tiles += g.ntiles2p;
+					st.launches += 1;
+				}
+				if (rc == ACMHIP_OK && !tiles2m[lv].empty()) {
+					g.ntiles2m = (uint32_t)tiles2m[lv].size();
+					rc = to_device(pl, tiles2m[lv], &g.d_tiles2m);
+					if (rc == ACMHIP_OK)
+						rc = to_device(pl, tiles2m_plain[lv], &g.d_tiles2m_plain);
+					st.tiles += g.ntiles2m;
+					st.mform_tiles += g.ntiles2m;
 					st.launches += 1;
 				}
 				if (g.ntiles == 0)
@@ -909,6 +933,10 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 			LAUNCHTRY(acmk_launch_tile2p(g.level, pl->dev->cus, g.d_tiles2p, g.ntiles2p, pl->pk_chunks, pl->pk_blob, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		else
 			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		if (pl->mform)
+			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+		else
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}
@@ -965,6 +993,14 @@ extern "C" int acmhip_plan_bind_packed(acmhip_plan *pl, const acmhip_packed_chun
 	}
 	pl->pk_chunks = d_chunks;
 	pl->pk_blob = d_blob;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_bind_mform(acmhip_plan *pl, const uint8_t *d_mform)
+{
+	if (!pl)
+		return ACMHIP_ERR_ARG;
+	pl->mform = d_mform;
 	return ACMHIP_OK;
 }
 

@@ -1250,6 +1250,247 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 		static_assert(W == 2, "two adjacent columns per lane");
 		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NRAW>{});
 	}
+	/* what acm_tile2 asks of its first pass (FirstPassM below answers the same questions for the byte-plane form) */
+	struct Raw { uint32_t r[NRAW]; };
+	static __device__ __forceinline__ void load(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	{
+		load(raw.r, base, voff, voff_warm);
+	}
+	struct Tables { };
+	static constexpr bool SIGNED_ROWVAL = true;              /* odd tile rows carry -val when stage 0 is an N stage; rows in front of a stream weigh 0 */
+	static __device__ __forceinline__ bool fresh_lane(const int tid) { return tid < FP::TPS; }      /* lanes whose two rows in front are missing in a stream's first tile */
+	static __device__ __forceinline__ void fill_tables(Tables &, const int) { }
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &)
+	{
+		FP::template compute<true>(raw.r, tile, rowval, fresh_stream ? 0 : 2, tid);
+	}
+};
+
+/*
+ * The same first pass on the matrix cores, for the byte-plane staged form (acmhip_mform_rows, acm_pack.cpp).
+ * Three stages over one residue class are a banded integer matrix (tools/gen_mfma_tables.py): the 16 stage-2 outputs of a row
+ * pair = A (16 x 32, |coefficient| <= 8) x the 32 stage-0 inputs of that pair and the pair in front.  With the unpack multiply
+ * moved behind the matrix (val is constant over a block; the rows of a unit mostly share it) one v_mfma_i32_16x16x32_i8 does
+ * 16 outputs x 16 residues, and what is left for the vector ALU is one shift-add (low and high byte planes) and one multiply-add
+ * (val, and what the "+1" of decode.c:561-564 has become) per sample instead of two per sample and stage plus the unpack.
+ * Staged bytes are the same two per sample as the int16 form, in the order the B operand wants them: per row, per residue
+ * c < cols/8, eight low bytes (columns c + q*cols/8, stored minus 128 so that they are signed) and eight high bytes.  The -128
+ * comes back through the accumulator input (128 x the coefficient sums, ACM_MF_KROW).
+ * A unit = (row pair, 16 residues); a wave does eight of them per tile.  Lane l feeds input row l/16 of the four (two in
+ * front, the pair itself) for residue l%16 and receives outputs 4*(l/16) .. +3 of that residue.
+ * Units whose four rows do not share one val (a block boundary inside) run the matrix once per row, with the other rows'
+ * coefficients masked out of A (a lane only holds the coefficients of its own input row: the mask is a lane select).
+ */
+typedef int32_t v4i_t __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+#include "acm_mfma_tables.inc"
+
+template <class C>
+struct FirstPassM {
+	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS, TR = C::TR;
+	static constexpr int G = 3, U = 8, SIGMA = COLS / U;
+	static constexpr int NGRP = SIGMA / 16;                 /* groups of 16 residues per row pair */
+	static constexpr int NW = NT / 64;
+	static constexpr int NUNIT = (TR / 2) * NGRP;
+	static constexpr int NU = NUNIT / NW;                   /* units per wave and tile */
+	static constexpr int NRAW = NU * 4;
+	static_assert(SIGMA % 16 == 0 && NU * NW == NUNIT && NU >= 1, "whole units per wave");
+	/* a wave's units are consecutive in (row pair, group) order: several pairs per wave, or several waves per pair */
+	static constexpr bool MANYG = NGRP > NU;
+	static_assert(MANYG ? NGRP % NU == 0 : NU % NGRP == 0, "units of a wave are whole row pairs, or a whole fraction of one");
+	static constexpr int WPP = MANYG ? NGRP / NU : 1;       /* waves per row pair */
+	static constexpr int ROWB = COLS * 2;                   /* staged bytes per row */
+	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
+	static constexpr bool SIGNED_ROWVAL = false;            /* rowval = val << SHIFT for every row; rows in front of a stream repeat row 0's */
+
+	struct Raw { v4u_t r[NU]; };
+	/* per-lane operands that never change, parked in LDS between tiles (registers are what the LDS passes are short of) */
+	struct Tables {
+		uint64_t a[64];             /* lane's 8 coefficients: output l%16, inputs of row l/16 */
+		v4i_t kc[4];                /* accumulator input of outputs 4*rs .. +3: 128 x the coefficient sums of all four rows */
+		v4i_t krow[4][4];           /* [input row][rs]: the same for one input row */
+		v4i_t khalf[2][4];          /* [rows in front / the pair itself][rs] */
+		v4i_t bias[2][5];           /* [rows in front missing][rs, 4 = lanes that do not own residue 0]: the "+1" response, scaled */
+	};
+
+	static constexpr int pair_of(int k) { return MANYG ? 0 : k / NGRP; }                    /* relative to the wave's first row pair */
+	static constexpr int grp_of(int k) { return MANYG ? k : k % NGRP; }                     /* relative to the wave's first group */
+	static constexpr bool first_of_pair(int k) { return MANYG ? k == 0 : k % NGRP == 0; }
+	static __device__ __forceinline__ int pair0(const int tid) { return MANYG ? (tid >> 6) / WPP : (tid >> 6) * (NU / (MANYG ? 1 : NGRP)); }
+	static __device__ __forceinline__ int grp0(const int tid) { return MANYG ? ((tid >> 6) % WPP) * NU : 0; }
+
+	/* byte offset of this lane's first 16 staged bytes relative to tile row -2 */
+	static __device__ __forceinline__ uint32_t lane_offset(const int tid)
+	{
+		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
+		return (uint32_t)((2 * pair0(tid) + rs) * ROWB + (grp0(tid) * 16 + n) * 16);
+	}
+	/* the two rows in front of a stream exist in this form (two rows of zeros, written by the stager): no lane reads anywhere else */
+	static __device__ __forceinline__ bool fresh_lane(const int) { return false; }
+	template <int K>
+	static __device__ __forceinline__ void load_one(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t)
+	{
+		constexpr int off = pair_of(K) * 2 * ROWB + grp_of(K) * 256;
+		static_assert(off < 4096, "12-bit immediate");
+		asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(raw.r[K]) : "v"(voff), "s"(base), "n"(off) : "memory");
+	}
+	template <int... Ks>
+	static __device__ __forceinline__ void load_all(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm, std::integer_sequence<int, Ks...>)
+	{
+		(load_one<Ks>(raw, base, voff, voff_warm), ...);
+	}
+	static __device__ __forceinline__ void load(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	{
+		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NU>{});
+	}
+
+	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid)
+	{
+		constexpr int32_t ONE = 1 << OutScale<L>::SHIFT;
+		if (tid < 64) {
+			const int rs = tid >> 4, m = tid & 15;
+			uint64_t a = 0;
+			for (int j = 0; j < 8; j++)
+				a |= (uint64_t)(uint8_t)ACM_MF_A[VARIANT][m][8 * rs + j] << (8 * j);
+			t.a[tid] = a;
+		}
+		if (tid < 4) {
+			const int rs = tid;
+			v4i_t kc = { 0, 0, 0, 0 };
+			for (int r = 0; r < 4; r++) {
+				v4i_t kr;
+				for (int i = 0; i < 4; i++)
+					kr[i] = ACM_MF_KROW[VARIANT][r][4 * rs + i];
+				t.krow[r][rs] = kr;
+				kc += kr;
+				if (r == 1)
+					t.khalf[0][rs] = kc;
+			}
+			t.kc[rs] = kc;
+			t.khalf[1][rs] = kc - t.khalf[0][rs];
+			for (int f = 0; f < 2; f++) {
+				v4i_t b;
+				for (int i = 0; i < 4; i++)
+					b[i] = ACM_MF_BIAS[VARIANT][f][4 * rs + i] * ONE;
+				t.bias[f][rs] = b;
+			}
+		}
+		if (tid < 2)
+			t.bias[tid][4] = v4i_t{ 0, 0, 0, 0 };
+	}
+
+	static __device__ __forceinline__ v4i_t mfma(const uint64_t a, const uint64_t b, const v4i_t c)
+	{
+		return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+	}
+	/* y (+)= c * val for the lane's four outputs: |c| < 2^22 (48 x 32768 at most) and val << SHIFT < 2^23, so the 24-bit multiplier is
+	 * exact mod 2^32.  One asm statement per four (see mul_idx_val_x4); its inputs are VALU results, never the matrix core's own registers
+	 * (the compiler does not look inside asm for the wait states those need). */
+	template <bool ACC>
+	static __device__ __forceinline__ void scale4(v4i_t &y, const v4i_t c, const int32_t val)
+	{
+		int32_t y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+		if constexpr (ACC)
+			asm("v_mad_i32_i24 %0, %4, %8, %0\n\tv_mad_i32_i24 %1, %5, %8, %1\n\tv_mad_i32_i24 %2, %6, %8, %2\n\tv_mad_i32_i24 %3, %7, %8, %3"
+			    : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "s"(val));
+		else
+			asm("v_mul_i32_i24_e32 %0, %8, %4\n\tv_mul_i32_i24_e32 %1, %8, %5\n\tv_mul_i32_i24_e32 %2, %8, %6\n\tv_mul_i32_i24_e32 %3, %8, %7"
+			    : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "s"(val));
+		y = v4i_t{ y0, y1, y2, y3 };
+	}
+	/* low-byte and high-byte products of one unit -> index-weighted sums */
+	static __device__ __forceinline__ v4i_t join(const v4i_t d, const v4i_t e)
+	{
+		v4i_t c;
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			c[i] = (int32_t)(((uint32_t)e[i] << 8) + (uint32_t)d[i]);
+		return c;
+	}
+
+	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put two rows of zeros there) */
+	static constexpr int UPP = MANYG ? NU : NGRP;           /* units of one row pair in a wave */
+	static constexpr int NPW = NU / UPP;                    /* row pairs per wave */
+	template <int PP, int... Js>
+	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int rs,
+							const bool owns0, const uint64_t a, const Tables &t, std::integer_sequence<int, Js...>)
+	{
+		constexpr int PS = C::PS;
+		const v4i_t zero = { 0, 0, 0, 0 };
+		const int32_t va = __builtin_amdgcn_readfirstlane(rv[0]), vb = __builtin_amdgcn_readfirstlane(rv[1]);      /* rows 2P-2, 2P-1 */
+		const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]), vd = __builtin_amdgcn_readfirstlane(rv[3]);      /* rows 2P, 2P+1 */
+		/* the "+1" only reaches the lane that owns residue 0, in the unit of group 0 (the pair's first unit, if this wave has it) */
+		const v4i_t yb = t.bias[nothing_in_front ? 1 : 0][owns0 ? rs : 4];
+		auto lo = [&](int k) { return ((uint64_t)raw.r[k].y << 32) | raw.r[k].x; };
+		auto hi = [&](int k) { return ((uint64_t)raw.r[k].w << 32) | raw.r[k].z; };
+		auto store = [&](int k, const v4i_t y) {
+			uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
+		};
+		if (va == vb && vb == vc && vc == vd) {
+			/* one val over all four rows (the usual case): the multiply moves behind the matrix */
+			const v4i_t kc = t.kc[rs];
+			auto unit = [&](auto jj) {
+				constexpr int k = PP * UPP + decltype(jj)::value;
+				constexpr bool with_bias = grp_of(k) == 0;
+				const v4i_t c = join(mfma(a, lo(k), kc), mfma(a, hi(k), zero));
+				v4i_t y = yb;
+				scale4<with_bias>(y, c, vc);
+				store(k, y);
+			};
+			(unit(std::integral_constant<int, Js>{}), ...);
+		} else if (va == vb && vc == vd) {
+			/* a block boundary between the pair and the rows in front of it: the matrix once per half */
+			const uint64_t a_front = rs < 2 ? a : 0ull, a_pair = rs < 2 ? 0ull : a;
+			const v4i_t k_front = t.khalf[0][rs], k_pair = t.khalf[1][rs];
+			auto unit = [&](auto jj) {
+				constexpr int k = PP * UPP + decltype(jj)::value;
+				constexpr bool with_bias = grp_of(k) == 0;
+				const v4i_t c1 = join(mfma(a_front, lo(k), k_front), mfma(a_front, hi(k), zero));
+				const v4i_t c2 = join(mfma(a_pair, lo(k), k_pair), mfma(a_pair, hi(k), zero));
+				v4i_t y = yb;
+				scale4<with_bias>(y, c1, va);
+				scale4<true>(y, c2, vc);
+				store(k, y);
+			};
+			(unit(std::integral_constant<int, Js>{}), ...);
+		} else {
+			/* anything else (odd acm_rows): once per input row */
+			auto unit = [&](auto jj) {
+				constexpr int k = PP * UPP + decltype(jj)::value;
+				constexpr bool with_bias = grp_of(k) == 0;
+				v4i_t y = with_bias ? yb : zero;
+#pragma unroll 1
+				for (int r = 0; r < 4; r++) {
+					const uint64_t ar = (rs == r) ? a : 0ull;
+					const v4i_t c = join(mfma(ar, lo(k), t.krow[r][rs]), mfma(ar, hi(k), zero));
+					scale4<true>(y, c, r == 0 ? va : (r == 1 ? vb : (r == 2 ? vc : vd)));
+				}
+				store(k, y);
+			};
+			(unit(std::integral_constant<int, Js>{}), ...);
+		}
+	}
+	template <int... PPs>
+	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int rs, const bool owns0,
+							 const uint64_t a, const Tables &t, std::integer_sequence<int, PPs...>)
+	{
+		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, rs, owns0, a, t, std::make_integer_sequence<int, UPP>{}), ...);
+	}
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t)
+	{
+		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
+		const int p0 = pair0(tid), g0 = grp0(tid);
+		const bool owns0 = (n == 0) && (g0 == 0);                       /* residue 0 sits in group 0 */
+		const uint64_t a = t.a[lane];
+		/* LDS place of output 4*rs of the lane's residue in the wave's first unit */
+		constexpr int PS = C::PS;
+		uint32_t *const o0 = tile + lds_at<PS>(2 * p0 * COLS + g0 * 16) + n + (4 * rs * SIGMA + ((4 * rs * SIGMA) >> PS));
+		const bool missing = fresh_stream && __builtin_amdgcn_readfirstlane(p0) == 0;     /* the wave's first row pair has nothing in front of it */
+		run_pairs(raw, o0, rowval + 2 * p0, missing, rs, owns0, a, t, std::make_integer_sequence<int, NPW>{});
+	}
 };
 
 /*
@@ -1277,14 +1518,16 @@ __device__ __forceinline__ void k2_wait()
 	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
 }
 
-template <class C, int WPS, int ABL, int G0, int... Gs>
+/* MFORM: idx is the byte-plane staged form and the first pass runs on the matrix cores (FirstPassM); everything else is the same */
+template <class C, int WPS, int ABL, bool MFORM, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
 acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
 	  int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
-	constexpr bool NEG_ODD_ROWS = StageKind<L, 0>::N;
-	using FP = FirstPass2<C, G0, 2, ABL>;
+	using FP = std::conditional_t<MFORM, FirstPassM<C>, FirstPass2<C, G0, 2, ABL>>;
+	static_assert(!MFORM || G0 == 3, "the coefficient tables are those of a three-stage first pass");
+	constexpr bool NEG_ODD_ROWS = FP::SIGNED_ROWVAL && StageKind<L, 0>::N;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
 
@@ -1292,9 +1535,11 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	__shared__ int32_t rowval[2][TR + 2];
 	constexpr int NCARRY_WORDS = carry_total<C, G0, Gs...>();
 	__shared__ uint32_t carry_mem[NCARRY_WORDS];
+	__shared__ typename FP::Tables fp_tables;
 	uint32_t *const tile = tile_mem + 8;
 
 	const int tid = threadIdx.x;
+	FP::fill_tables(fp_tables, tid);                /* read behind the first barrier of the tile loop */
 	const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
 	uint32_t t = blockIdx.x * per;
 	const uint32_t t_end = t + per < ntiles ? t + per : ntiles;
@@ -1308,7 +1553,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	}
 
 	const uint32_t voff = FP::lane_offset(tid);
-	const uint32_t seg0 = (tid < FP::TPS) ? 0xFFFFFFFFu : 0u;
+	const uint32_t seg0 = FP::fresh_lane(tid) ? 0xFFFFFFFFu : 0u;
 
 	/* row values of one tile: thread lr < TR + 2 fetches the val of tile row lr - 2 (decode.c:589).  Every lane of every
 	 * wave issues the load (lanes beyond the tile repeat its last row) so that all waves count the same vector-memory
@@ -1327,7 +1572,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		return v;
 	};
 	auto finish_val = [&](uint32_t v, const AcmTile2 &r) -> int32_t {
-		if ((r.flags & ACM_TILE_FRESH) && tid < 2)
+		if (FP::SIGNED_ROWVAL && (r.flags & ACM_TILE_FRESH) && tid < 2)
 			v = 0;
 		v <<= OutScale<L>::SHIFT;
 		return (NEG_ODD_ROWS && (tid & 1)) ? -(int32_t)v : (int32_t)v;
@@ -1340,7 +1585,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
 		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
 	};
-	auto load_tile = [&](uint32_t (&raw)[FP::NRAW], const AcmTile2 &r) {
+	auto load_tile = [&](typename FP::Raw &raw, const AcmTile2 &r) {
 		FP::load(raw, sgpr_ptr(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS)), voff, warm_off(r));
 	};
 
@@ -1349,7 +1594,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records through the scalar cache (the index is wave-uniform; readfirstlane says so to the compiler):
 	 * a vector load here would be tracked by the compiler's vmcnt bookkeeping, which knows nothing of the asm loads */
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
-	uint32_t raw[FP::NRAW];
+	typename FP::Raw raw;
 	uint32_t hv = fetch_val(cur);
 	load_tile(raw, cur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
@@ -1375,7 +1620,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		FP::template compute<true>(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) ? 0 : 2, tid);
+		FP::run(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) != 0, tid, fp_tables);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -1438,18 +1683,18 @@ struct Tile2Entry {
 template <class C, int... Gs>
 constexpr Tile2Entry entry_k2()
 {
-	return Tile2Entry{ acm_tile2<C, 4, 0, Gs...>, C::NT, C::TR, 1024 / C::NT };
+	return Tile2Entry{ acm_tile2<C, 4, 0, false, Gs...>, C::NT, C::TR, 1024 / C::NT };
 }
 /* bigger tiles: WPC workgroups per CU */
 template <class C, int WPC, int... Gs>
 constexpr Tile2Entry entry_k2w()
 {
-	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, Gs...>, C::NT, C::TR, WPC };
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, false, Gs...>, C::NT, C::TR, WPC };
 }
 #ifdef ACM_ABLATION
 /* timing-only builds of the level-9 kernel with parts removed (wrong output by design): ACM_K2_ABL=<mask> */
 template <int ABL>
-constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, 3, 3, 3>, 256, 16, 4 }; }
+constexpr Tile2Entry abl_k2() { return Tile2Entry{ acm_tile2<TileCfg<9, 256, 8192>, 4, ABL, false, 3, 3, 3>, 256, 16, 4 }; }
 const struct { int mask; Tile2Entry e; } g_tile2_abl[] = {
 	{ 1, abl_k2<1>() }, { 2, abl_k2<2>() }, { 4, abl_k2<4>() }, { 6, abl_k2<6>() }, { 8, abl_k2<8>() }, { 16, abl_k2<16>() },
 	{ 17, abl_k2<17>() }, { 23, abl_k2<23>() }, { 32, abl_k2<32>() }, { 25, abl_k2<25>() }, { 31, abl_k2<31>() }, { 12, abl_k2<12>() },
@@ -1484,6 +1729,25 @@ inline const Tile2Entry &tile2_entry(uint32_t level)
 {
 	return g_tile2[level - ACM_K2_MIN_LEVEL];
 }
+/* the same geometries with the first pass on the matrix cores (levels whose first pass has three stages) */
+template <class C, int... Gs>
+constexpr Tile2Entry entry_k2m()
+{
+	return Tile2Entry{ acm_tile2<C, 4, 0, true, Gs...>, C::NT, C::TR, 1024 / C::NT };
+}
+template <class C, int WPC, int... Gs>
+constexpr Tile2Entry entry_k2mw()
+{
+	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, true, Gs...>, C::NT, C::TR, WPC };
+}
+const Tile2Entry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
+	entry_k2m<TileCfg<7, 256, 8192>, 3, 2, 2>(),
+	entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(),
+	entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(),
+	entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
+	entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
+	entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),
+};
 
 // ---------------------------------------------------------------------------
 // K2P: the lean tile kernel on the packed staged form
@@ -1984,6 +2248,32 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	if (grid > ntiles)
 		grid = ntiles;
 	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
+	ACMK_CHECK_LAUNCH();
+	return 0;
+}
+
+extern "C" int acmk_tile2m_rows(uint32_t level)
+{
+	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
+		return 0;
+	return g_tile2m[level - ACM_K2M_MIN_LEVEL].tile_rows;
+}
+
+extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_blkhdr *d_hdr,
+				  int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
+{
+	if (ntiles == 0)
+		return 0;
+	if (!d_sink || !d_mform)
+		return -1;
+	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
+		return -1;
+	const Tile2Entry &e = g_tile2m[level - ACM_K2M_MIN_LEVEL];
+	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
+	if (grid > ntiles)
+		grid = ntiles;
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, reinterpret_cast<const int16_t *>(d_mform), d_hdr, d_pcm,
+			   d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

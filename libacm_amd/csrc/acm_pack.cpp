@@ -229,3 +229,60 @@ extern "C" int acmhip_unpack_tile(uint32_t level, const acmhip_packed_chunk *til
 			return ACMHIP_ERR_ARG;
 	return ACMHIP_OK;
 }
+
+/* ---------------------------------------------------------------------------
+ * byte-plane staged form (include/acm_hip.h): the int16 form's bytes in the order acm_tile2's matrix-core build reads them
+ * --------------------------------------------------------------------------- */
+extern "C" int acmhip_mform_tile_rows(uint32_t level)
+{
+	return acmk_tile2m_rows(level);
+}
+
+extern "C" uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows)
+{
+	return (nrows + 2) * (2ull << level);
+}
+
+extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out)
+{
+	if (!acmk_tile2m_rows(level) || (!idx && nrows) || !out)
+		return ACMHIP_ERR_ARG;
+	const size_t cols = (size_t)1 << level, sigma = cols / 8, rowb = cols * 2;
+	/* the two rows in front of the stream: index 0 everywhere */
+	for (size_t c = 0; c < 2 * sigma; c++) {
+		memset(out + c * 16, 0x80, 8);
+		memset(out + c * 16 + 8, 0x00, 8);
+	}
+	for (uint64_t r = 0; r < nrows; r++) {
+		const int16_t *src = idx + r * cols;
+		uint8_t *dst = out + (r + 2) * rowb;
+		for (size_t c = 0; c < sigma; c++) {
+			uint8_t *d = dst + c * 16;
+			for (size_t q = 0; q < 8; q++) {
+				const uint16_t x = (uint16_t)src[c + q * sigma];
+				d[q] = (uint8_t)(x ^ 0x80u);
+				d[8 + q] = (uint8_t)(x >> 8);
+			}
+		}
+	}
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *block, uint64_t nrows, int16_t *idx)
+{
+	if (!acmk_tile2m_rows(level) || !block || (!idx && nrows))
+		return ACMHIP_ERR_ARG;
+	const size_t cols = (size_t)1 << level, sigma = cols / 8, rowb = cols * 2;
+	for (size_t c = 0; c < 2 * sigma; c++)
+		for (size_t q = 0; q < 8; q++)
+			if (block[c * 16 + q] != 0x80 || block[c * 16 + 8 + q] != 0)
+				return ACMHIP_ERR_ARG;
+	for (uint64_t r = 0; r < nrows; r++) {
+		const uint8_t *src = block + (r + 2) * rowb;
+		int16_t *dst = idx + r * cols;
+		for (size_t c = 0; c < sigma; c++)
+			for (size_t q = 0; q < 8; q++)
+				dst[c + q * sigma] = (int16_t)(uint16_t)((src[c * 16 + q] ^ 0x80u) | ((unsigned)src[c * 16 + 8 + q] << 8));
+	}
+	return ACMHIP_OK;
+}

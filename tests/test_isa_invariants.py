@@ -127,8 +127,8 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                 if not pending <= state_in[t]:
                     state_in[t] |= pending
                     work.append(t)
-        assert n_loads >= 2 * 13, (name, n_loads)          # prologue + in-loop sets of staged-index loads
-    assert n_kernels >= 13                                 # nine levels of acm_tile2, four of acm_tile2p
+        assert n_loads >= 2 * 9, (name, n_loads)           # prologue + in-loop sets of staged-index loads (the matrix-core builds: 8 + the row values)
+    assert n_kernels >= 19                                 # nine levels of acm_tile2, six matrix-core builds of it, four of acm_tile2p
 
 
 def test_every_wait_is_written_by_hand(kernel_asm):
@@ -138,6 +138,11 @@ def test_every_wait_is_written_by_hand(kernel_asm):
         assert not any(l.strip().startswith("scratch_") for l in lines), name[:60]     # a spill is a compiler-tracked vector access
         stores = [l for l in lines if l.strip().startswith("global_store")]
         assert len(stores) in (4, 8), (name[:60], len(stores))
+        if "Lb1E" in name and "acm_tile2I" in name:
+            # the matrix-core builds first fill their coefficient tables from constant memory: compiler-tracked loads and their waits,
+            # all in front of the first hand-issued load (nothing of the kernel's own is in flight there)
+            first_hand = next(k for k, l in enumerate(lines) if l.strip().startswith(";;#ASMSTART") and lines[k + 1].strip().startswith("global_load"))
+            lines = lines[first_hand:]
         waits = [l.strip() for l in lines if "vmcnt" in l]
         assert sorted(waits) == ["s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(%d)" % len(stores)], (name[:60], waits)
 
