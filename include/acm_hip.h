@@ -318,6 +318,10 @@ typedef struct acm_batch_opts {
                                        upload carries the packed form + the int16 rows the other kernels still read (ragged tails) instead
                                        of the whole int16 arena - about half the bytes over PCIe and through HBM, for ~30 % more host
                                        work per stream and a synthesis launch that is 10-18 % slower (acm_tile2p).  Off by default. */
+#define ACM_BATCH_STAGE_BYTEPLANE 4u /* host parsing only: the pool also re-orders the whole tiles of every clean stream of levels 7-12 into the
+                                       byte-plane form (acmhip_mform_rows; same bytes) and the upload carries that + the int16 rows the other
+                                       kernels still read: the synthesis launch runs its first pass on the matrix cores (+3-7 %).  Wins over
+                                       ACM_BATCH_STAGE_PACKED when both are set. */
 #define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
                                        the PCM straight into it, stream by stream, instead of through the library's own pinned
                                        arena and a host copy (taken for streams of 64 KB of PCM and more on average) */

@@ -163,6 +163,9 @@ struct Slot {
 	 * (0: the stream travels as int16) and where its blobs landed in the blob arena */
 	uint64_t pk_chunk_off = 0, pk_chunk_cap = 0;
 	uint32_t pk_ntiles = 0;
+	/* ACM_BATCH_STAGE_BYTEPLANE: where the stream's byte-plane block sits in the blob arena (bytes) and how many rows it may hold;
+	 * pk_ntiles = the whole tiles the pool staged that way */
+	uint64_t mf_off = 0, mf_rows_cap = 0;
 };
 
 /* Blocks a file can possibly hold: the header promises total_values, but arenas are sized by this - a block costs at
@@ -184,6 +187,7 @@ struct Chunk {
 	std::atomic<int> unparsed{ 0 };
 	std::atomic<uint64_t> pk_used{ 0 };     /* ACM_BATCH_STAGE_PACKED: bytes of this chunk's blob region handed out so far */
 	uint64_t pk_chunk_begin = 0, pk_chunk_end = 0;  /* its range of the chunk table (entries) */
+	uint64_t mf_begin = 0, mf_end = 0;              /* ACM_BATCH_STAGE_BYTEPLANE: its range of the blob arena (bytes) */
 	std::atomic<int> back{ 0 };             /* 1 = PCM is in the pinned arena, -1 = the read-back failed */
 	acmhip_plan *plan = nullptr;
 	hipEvent_t ev[5] = {};                  /* h2d begin, h2d end, kernel end (device stream); d2h begin, d2h end (copy stream) */
@@ -487,6 +491,27 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			chunks[c].pk_chunk_end = pk_chunks_total;
 		}
 
+	/* the byte-plane staged form (opt-in, host parsing): every stream of a level the matrix-core build covers gets room for its
+	 * rows plus the two rows of zeros in front */
+	bool stage_mform = (opts.flags & ACM_BATCH_STAGE_BYTEPLANE) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
+			   !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
+	uint64_t mf_total = 0;
+	if (stage_mform) {
+		stage_packed = false;           /* one second form per batch */
+		for (size_t c = 0; c < chunks.size(); c++) {
+			chunks[c].mf_begin = mf_total;
+			for (size_t i = chunks[c].first; i < chunks[c].last; i++) {
+				Slot &s = slots[i];
+				if (!s.ok || acmhip_mform_tile_rows(s.info.level) <= 0)
+					continue;
+				s.mf_off = mf_total;
+				s.mf_rows_cap = s.need_blocks * s.info.rows;
+				mf_total += (acmhip_mform_bytes(s.info.level, s.mf_rows_cap) + 255) & ~255ull;
+			}
+			chunks[c].mf_end = mf_total;
+		}
+	}
+
 	/* AUTO: the device walk takes as long as the longest stream takes one wavefront, the host pool takes total / threads.
 	 * Measured (profiles/r2_parse_probe.txt): a wavefront alone on its SIMD walks at ~1/5 of a host core's parsing rate
 	 * (up to 1024 streams), with four per SIMD at ~1/9 (up to the 32 K streams acm_parse_scan_wave takes), a lane of
@@ -501,7 +526,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		dev_parse = longest > 0 && idx_total / longest >= per_thread * (uint64_t)threads_wanted;
 	}
 	if (dev_parse)
-		stage_packed = false;           /* the device parser stages int16 */
+		stage_packed = stage_mform = false;     /* the device parser stages int16 */
 	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
@@ -635,6 +660,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	} else {
 		stage_packed = false;
 	}
+	if (stage_mform && mf_total) {
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKBLOB, mf_total, (void **)&h_pkblob));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKBLOB, mf_total, (void **)&d_pkblob));
+	} else {
+		stage_mform = false;
+	}
 	if (!keep_on_device && !direct_out)
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_arena_words * sizeof(int16_t), (void **)&h_pcm));
 	BTRY(acmhip_arena_get(dev, ACM_ARENA_D_IDX, idx_total * sizeof(int16_t), (void **)&d_idx));
@@ -715,6 +746,20 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				tc[k].blob_off16 += (uint32_t)((region + at) / 16);
 		s.pk_ntiles = (uint32_t)ntiles;
 	};
+	/* the byte-plane half: the whole tiles of a clean stream, re-ordered from the int16 rows the reader has just written */
+	auto host_mform = [&](size_t i) {
+		Slot &s = slots[i];
+		if (!stage_mform || !s.ok || !s.mf_rows_cap || !s.patches.empty() || items[i].words == 0)
+			return;
+		const int tr = acmhip_mform_tile_rows(s.info.level);
+		const uint64_t full_rows = std::min<uint64_t>((uint64_t)s.info.blocks * s.info.rows, items[i].words >> s.info.level);
+		const uint64_t ntiles = full_rows / (uint64_t)tr;
+		if (ntiles == 0 || ntiles * (uint64_t)tr > s.mf_rows_cap)
+			return;
+		if (acmhip_mform_rows(s.info.level, h_idx + s.idx_off, ntiles * (uint64_t)tr, h_pkblob + s.mf_off) != ACMHIP_OK)
+			return;
+		s.pk_ntiles = (uint32_t)ntiles;
+	};
 	/* the exact host reader, one stream */
 	auto host_stage_int16 = [&](size_t i) {
 		Slot &s = slots[i];
@@ -764,6 +809,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	auto host_stage = [&](size_t i) {
 		host_stage_int16(i);
 		host_pack(i);
+		host_mform(i);
 	};
 
 	/* 2a. device parsing (optional): the streams the device parser takes are copied into the pinned file arena by the pool,
@@ -938,7 +984,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			Slot &s = slots[i];
 			if (!s.ok || items[i].words == 0)
 				continue;
-			packed.push_back(acmhip_packed_stream{ s.pk_chunk_off, s.pk_ntiles, 0 });
+			if (stage_mform)
+				packed.push_back(acmhip_packed_stream{ s.mf_off / 2, s.pk_ntiles, ACMHIP_FORM_BYTEPLANE });
+			else
+				packed.push_back(acmhip_packed_stream{ s.pk_chunk_off, s.pk_ntiles, ACMHIP_FORM_PACKED });
 			acmhip_stream_desc d{};
 			d.idx_off = s.idx_off;
 			d.hdr_off = s.hdr_off;
@@ -962,11 +1011,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 		if (descs.empty())
 			return ACMHIP_OK;
-		if (!stage_packed)
+		if (!stage_packed && !stage_mform)
 			return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		if (r == ACMHIP_OK)
-			r = acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
+			r = stage_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob) : acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
 		return r;
 	};
 	/* chunks made of device-parsed streams only: their plans are cut NOW, from what the headers promise (a stream the
@@ -1180,18 +1229,30 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				tm.samples += items[i].words;
 		if (ch.plan) {
 			HTRY(hipEventRecord(ch.ev[0], st_main));
-			if (!dev_parse && stage_packed) {
-				/* the packed form of the chunk: the used front of its blob region, its chunk-table entries; of the int16 arena only
-				 * what the other kernels read - streams that were not packed, and behind a packed stream's whole tiles its ragged
-				 * tail with the two rows in front of it */
-				const uint64_t region = ch.idx_begin * sizeof(int16_t), region_len = (ch.idx_end - ch.idx_begin) * sizeof(int16_t);
-				const uint64_t used = std::min<uint64_t>(ch.pk_used.load(), region_len);
-				if (used)
-					HTRY(hipMemcpyAsync(d_pkblob + region, h_pkblob + region, used, hipMemcpyHostToDevice, st_main));
-				tm.h2d_bytes += used + (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk) + (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
-				if (ch.pk_chunk_end > ch.pk_chunk_begin)
-					HTRY(hipMemcpyAsync(d_pkchunk + ch.pk_chunk_begin, h_pkchunk + ch.pk_chunk_begin,
-							    (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk), hipMemcpyHostToDevice, st_main));
+			if (!dev_parse && (stage_packed || stage_mform)) {
+				/* the second form of the chunk (packed: the used front of its blob region and its chunk-table entries; byte planes:
+				 * the blocks of the streams that have one); of the int16 arena only what the other kernels read - streams without
+				 * a second form, and behind a stream's whole tiles its ragged tail with the two rows in front of it */
+				if (stage_mform) {
+					for (size_t i = ch.first; i < ch.last; i++) {
+						const Slot &s = slots[i];
+						if (!s.ok || !s.pk_ntiles)
+							continue;
+						const uint64_t bytes = acmhip_mform_bytes(s.info.level, (uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level));
+						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, bytes, hipMemcpyHostToDevice, st_main));
+						tm.h2d_bytes += bytes;
+					}
+					tm.h2d_bytes += (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
+				} else {
+					const uint64_t region = ch.idx_begin * sizeof(int16_t), region_len = (ch.idx_end - ch.idx_begin) * sizeof(int16_t);
+					const uint64_t used = std::min<uint64_t>(ch.pk_used.load(), region_len);
+					if (used)
+						HTRY(hipMemcpyAsync(d_pkblob + region, h_pkblob + region, used, hipMemcpyHostToDevice, st_main));
+					tm.h2d_bytes += used + (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk) + (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
+					if (ch.pk_chunk_end > ch.pk_chunk_begin)
+						HTRY(hipMemcpyAsync(d_pkchunk + ch.pk_chunk_begin, h_pkchunk + ch.pk_chunk_begin,
+								    (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk), hipMemcpyHostToDevice, st_main));
+				}
 				for (size_t i = ch.first; i < ch.last; i++) {
 					const Slot &s = slots[i];
 					if (!s.ok || s.info.blocks == 0)
@@ -1199,7 +1260,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 					const uint64_t cols = s.info.cols, nrows = (uint64_t)s.info.blocks * s.info.rows;
 					uint64_t from_row = 0;
 					if (s.pk_ntiles) {
-						const uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)acmhip_packed_tile_rows(s.info.level);
+						const uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)(stage_mform ? acmhip_mform_tile_rows(s.info.level)
+															  : acmhip_packed_tile_rows(s.info.level));
 						if (rows2 * cols >= items[i].words)
 							continue;               /* nothing behind the whole tiles is emitted */
 						from_row = rows2 >= 2 ? rows2 - 2 : 0;

@@ -1,0 +1,138 @@
+"""The byte-plane staged form (include/acm_hip.h, libacm_amd/csrc/acm_pack.cpp) and the coefficient tables of the matrix-core first
+pass (tools/gen_mfma_tables.py -> libacm_amd/csrc/acm_mfma_tables.inc), on the CPU.
+
+The form is the int16 form's bytes in another order, so the round trip must be exact; the tables are checked against the CPU
+oracle's own juggle cascade (reference decode.c:527-590): three stages over a residue class of the columns, computed as
+A x inputs with the staged bytes exactly as the kernel's matrix instruction sees them, must equal what the oracle leaves in its
+block buffer after stage 2 (sub_count 2, 4, 8)."""
+import re
+
+import numpy as np
+import pytest
+
+from helpers import make_stream
+from libacm_amd import capi
+
+LEVELS = [7, 8, 9, 10, 11, 12]
+
+
+def test_levels_with_a_byteplane_form():
+    L = capi.lib()
+    for level in range(16):
+        tr = L.acmhip_mform_tile_rows(level)
+        if level in LEVELS:
+            assert tr == (16384 if level == 12 else 8192) >> level
+            assert L.acmhip_mform_bytes(level, 10) == 12 * (2 << level)
+        else:
+            assert tr == 0
+            assert L.acmhip_mform_rows(level, None, 0, None) != 0
+
+
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("rows,pwr_max", [(1, 12), (16, 12), (17, 15)])
+def test_round_trip(level, rows, pwr_max):
+    tr = capi.lib().acmhip_mform_tile_rows(level)
+    nblocks = (3 * tr + rows - 1) // rows + 1
+    s = capi.stage_file(make_stream(41000 + level * 100 + rows, level, rows, nblocks, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
+                                    val_max=65535 if pwr_max == 15 else 255))
+    cols = 1 << level
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
+                        nrows=s.info.blocks * rows, row_begin=0)
+    mf = capi.mform_streams(s.idx, [d])
+    nt = mf.streams[0].ntiles
+    assert nt >= 3 and mf.streams[0].form == capi.FORM_BYTEPLANE and mf.streams[0].chunk_off == 0
+    nrows = nt * tr
+    block = mf.data[:(nrows + 2) * cols * 2]
+    # two rows of index 0 in front: low bytes 0x80, high bytes 0
+    front = block[:2 * cols * 2].reshape(-1, 16)
+    assert (front[:, :8] == 0x80).all() and (front[:, 8:] == 0).all()
+    back = capi.mform_unrows(level, block, nrows)
+    assert np.array_equal(back, s.idx[:nrows * cols])
+    # layout: row r, residue c, q -> byte (r + 2) * 2 cols + 16 c + q (low, bit 7 flipped) / + 8 + q (high)
+    sigma = cols // 8
+    rng = np.random.default_rng(level)
+    for _ in range(64):
+        r, c, q = int(rng.integers(nrows)), int(rng.integers(sigma)), int(rng.integers(8))
+        x = int(s.idx[r * cols + c + q * sigma]) & 0xFFFF
+        at = (r + 2) * 2 * cols + 16 * c
+        assert block[at + q] == (x & 0xFF) ^ 0x80 and block[at + 8 + q] == x >> 8
+
+
+def load_tables():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    txt = open(os.path.join(here, "..", "libacm_amd", "csrc", "acm_mfma_tables.inc")).read()
+    out = {}
+    for name, shape in (("ACM_MF_A", (2, 16, 32)), ("ACM_MF_KROW", (2, 4, 16)), ("ACM_MF_BIAS", (2, 2, 16))):
+        body = txt[txt.index(name):]
+        body = body[body.index("=") + 1:body.index(";")]
+        out[name] = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int64).reshape(shape)
+    return out
+
+
+def juggle_stages(x, cols, nstages):
+    """the first nstages stages of juggle_block over rows x cols values (reference decode.c:527-577), written as the strided 3-tap FIR
+    each stage is: over the row-major sequence, with stride s = the stage's sub_len,
+    y[m] = 2 x[m - s] + sigma (x[m - 2 s] + x[m]), sigma = -1 where m // s is odd, zeros in front, "+1" on m % s == 0 after stage 0
+    (decode.c:561-564).  test_fir_restatement_matches_the_oracle pins this to the oracle."""
+    rows = x.shape[0]
+    flat = x.astype(np.int64).reshape(-1)
+    m = np.arange(flat.size)
+    s = cols // 2
+    for st in range(nstages):
+        x1 = np.where(m >= s, flat[np.maximum(m - s, 0)], 0)
+        x2 = np.where(m >= 2 * s, flat[np.maximum(m - 2 * s, 0)], 0)
+        flat = 2 * x1 + np.where((m // s) & 1, -1, 1) * (x2 + flat)
+        if st == 0:
+            flat = flat + (m % s == 0)
+        s //= 2
+    return flat.reshape(rows, cols)
+
+
+def test_fir_restatement_matches_the_oracle():
+    """the stage formula used below is the oracle's: all `level` stages of it reproduce the oracle's PCM of a small stream"""
+    import oracle_api as O
+    level, rows = 7, 5
+    f = make_stream(42000, level, rows, 3, pwr_max=9)
+    s = capi.stage_file(f)
+    cols = 1 << level
+    nrows = s.info.blocks * rows
+    val = np.repeat(s.hdr[:s.info.blocks, 0].astype(np.int64), rows)
+    x = s.idx[:nrows * cols].astype(np.int64).reshape(nrows, cols) * val[:, None]
+    y = juggle_stages(x, cols, level)
+    want = O.Oracle.decode_all(f)[0].astype(np.int64)
+    got = ((y.reshape(-1) & 0xFFFFFFFF) >> level).astype(np.uint16).astype(np.int16).astype(np.int64)
+    assert np.array_equal(got[:want.size], want)
+
+
+@pytest.mark.parametrize("level", [7, 10])
+def test_matrix_tables_reproduce_three_stages(level):
+    """A x (staged bytes) + KROW, times val, + BIAS == stage-2 output of the cascade, for every residue class and row pair of a
+    staged stream (one val over all rows here; the per-row split is the same sum taken row by row)"""
+    t = load_tables()
+    A, KROW, BIAS = t["ACM_MF_A"][0], t["ACM_MF_KROW"][0], t["ACM_MF_BIAS"][0]
+    cols, sigma = 1 << level, (1 << level) // 8
+    rows = 6
+    s = capi.stage_file(make_stream(43000 + level, level, rows, 1, pwr_max=15, val_max=65535))
+    assert s.info.blocks == 1
+    val = int(s.hdr[0, 0])
+    idx = s.idx[:rows * cols].astype(np.int64).reshape(rows, cols)
+    want = juggle_stages(idx * val, cols, 3)
+    block = np.zeros(capi.lib().acmhip_mform_bytes(level, rows), dtype=np.uint8)
+    assert capi.lib().acmhip_mform_rows(level, s.idx.ctypes.data, rows, block.ctypes.data) == 0
+    planes = block.reshape(rows + 2, sigma, 2, 8)
+    lo = planes[:, :, 0, :].view(np.int8).astype(np.int64)         # as the matrix instruction reads them: signed bytes
+    hi = planes[:, :, 1, :].view(np.int8).astype(np.int64)
+    for p in range(rows // 2):
+        for c in range(sigma):
+            blo = lo[2 * p:2 * p + 4, c, :].reshape(32)            # rows 2p-2 .. 2p+1 (block row 0 = stream row -2)
+            bhi = hi[2 * p:2 * p + 4, c, :].reshape(32)
+            d = A @ blo + KROW.sum(axis=0) + ((A @ bhi) << 8)
+            y = d * val + (BIAS[1 if p == 0 else 0] if c == 0 else 0)
+            got = y.reshape(2, 8)                                  # output m = 8 * (row in pair) + q
+            w = want[2 * p:2 * p + 2, c::sigma]
+            assert np.array_equal(got, w), (p, c)
+    # variant 1 = the same with odd outputs negated (what a P stage leaves in LDS)
+    sign = np.where(np.arange(16) & 1, -1, 1)
+    assert np.array_equal(t["ACM_MF_A"][1], A * sign[:, None])
+    assert np.array_equal(t["ACM_MF_KROW"][1], KROW * sign[None, :]) and np.array_equal(t["ACM_MF_BIAS"][1], BIAS * sign[None, :])

@@ -1,0 +1,156 @@
+"""GPU parity of the byte-plane staged form: acm_tile2's matrix-core build (libacm_amd/csrc/acm_kernels.hip, FirstPassM: the first
+three stages of juggle_block, reference decode.c:527-590, as one v_mfma_i32_16x16x32_i8 per row pair and 16 residue classes) fed by
+the host stager (acmhip_mform_rows, acm_pack.cpp) against the CPU oracle, bit-exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import fmt_args, make_stream, oracle_pcm
+from libacm_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = [7, 8, 9, 10, 11, 12]
+
+
+@pytest.fixture
+def force_k2(monkeypatch):
+    monkeypatch.setenv("ACM_K2", "1")
+
+
+def tile_rows(level):
+    return (16384 if level == 12 else 8192) >> level
+
+
+def check(dev, files, fmt=capi.FMT_S16LE, force_chans=0):
+    staged = [capi.stage_file(f, force_chans) for f in files]
+    got, st = capi.synth(dev, staged, fmt=fmt, return_stats=True, mform=True)
+    be, sg = fmt_args(fmt)
+    for k, (f, g) in enumerate(zip(files, got)):
+        want, _ = oracle_pcm(f, force_chans, be, sg)
+        assert g.size == want.size, (k, g.size, want.size)
+        bad = np.nonzero(g != want)[0]
+        assert bad.size == 0, "stream %d: %d/%d samples differ, first at %d (level %d rows %d)" % (
+            k, bad.size, want.size, bad[0], staged[k].info.level, staged[k].info.rows)
+    return st
+
+
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("rows,pwr_max", [(1, 12), (2, 9), (3, 6), (16, 12), (16, 4), (17, 15), (700, 9)])
+def test_byteplane_matrix(dev, force_k2, level, rows, pwr_max):
+    """whole tiles from the byte-plane form, the ragged tail from the int16 arena; block heights that put a val change between the
+    rows of a unit in every possible place (even: between row pairs, odd: inside them, 1: everywhere) and 16-bit indices with
+    16-bit row values (pwr_max 15)"""
+    tr = tile_rows(level)
+    nblocks = max(2, (7 * tr + rows - 1) // rows + 1)
+    f = make_stream(22000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=5, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
+                    val_max=65535 if pwr_max == 15 else 255)
+    st = check(dev, [f])
+    assert st.mform_tiles >= 7 and st.fused_streams == 1 and st.stagewise_streams == 0
+
+
+@pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE])
+def test_byteplane_batch(dev, force_k2, fmt):
+    """many streams in one plan, levels with and without the form side by side: workgroup runs start inside streams (lead-in tiles)
+    and cross stream boundaries; stereo; exact multiples of a tile and short tails"""
+    files = []
+    for i in range(45):
+        lv = 5 + i % 9
+        rows = [16, 5, 33, 1][i % 4]
+        pm = [5, 12, 7, 15][(i // 2) % 4]
+        files.append(make_stream(23000 + i, lv, rows, 2 + (i * 5) % 11 + ((32768 >> lv) * (1 + i % 3)) // rows,
+                                 channels=1 + i % 2, cut=i % 3, pwr_min=min(4, pm), pwr_max=pm, val_max=65535 if i % 5 == 0 else 255))
+    st = check(dev, files, fmt=fmt)
+    assert 0 < st.mform_tiles < st.tiles
+
+
+def test_byteplane_every_filler_code(dev, force_k2):
+    """every valid filler code in its own stream (26 of them: 0, 3-16 linear, the k / t codes), levels 7-12"""
+    valid = [0] + list(range(3, 17)) + [17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29]
+    files = []
+    for j, code in enumerate(valid):
+        lv = 7 + j % 6
+        files.append(make_stream(24000 + j, lv, 16, 3 * tile_rows(lv) // 16 + 2, mix=2, single_code=code, pwr_min=15 if 3 <= code <= 16 else 4,
+                                 pwr_max=15 if 3 <= code <= 16 else 12))
+    check(dev, files)
+
+
+def test_byteplane_extreme_indices(dev, force_k2):
+    """the widest linear filler with the largest row values: indices over the whole int16 range (the high byte plane at -128 and 127,
+    the low one at both ends), val = 65535"""
+    files = [make_stream(24500 + lv, lv, 16, 4 * tile_rows(lv) // 16 + 1, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535) for lv in LEVELS]
+    staged = [capi.stage_file(f) for f in files]
+    assert max(int(s.idx.max()) for s in staged) > 32000 and min(int(s.idx.min()) for s in staged) < -32000
+    check(dev, files)
+
+
+def test_byteplane_streams_with_h1_patches_keep_the_int16_form(dev, force_k2):
+    files = [make_stream(25000, 9, 16, 12, pwr_max=12),
+             make_stream(25001, 9, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6),
+             make_stream(25002, 11, 16, 40)]
+    staged = [capi.stage_file(f) for f in files]
+    assert staged[1].patches is not None and len(staged[1].patches) > 0
+    st = check(dev, files)
+    assert st.mform_tiles == (12 * 16 // 16) + (40 * 16 // 4)
+
+
+def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
+    """acmhip_plan_bind_mform(NULL) sends the same plan back to the int16 arena: same PCM either way"""
+    files = [make_stream(26000 + i, 7 + i % 6, 16, 30 + 7 * i, cut=i) for i in range(9)]
+    staged = [capi.stage_file(f) for f in files]
+    ar = capi.Arena(staged)
+    mf = capi.mform_streams(ar.idx, ar.descs)
+    d_idx, d_hdr, d_pcm = dev.malloc(ar.idx.nbytes), dev.malloc(ar.hdr.nbytes), dev.malloc(ar.pcm_words * 2)
+    d_mf = mf.upload(dev)
+    dev.upload(d_idx, ar.idx)
+    dev.upload(d_hdr, ar.hdr)
+    plan = capi.Plan(dev, ar.descs, packed=mf.streams)
+    assert plan.stats().mform_tiles > 0
+    outs = []
+    for bind in (d_mf, None, d_mf):
+        plan.bind_mform(bind)
+        dev.upload(d_pcm, np.zeros(ar.pcm_words, dtype=np.uint16))
+        plan.launch(d_idx, d_hdr, d_pcm)
+        o = np.zeros(ar.pcm_words, dtype=np.uint16)
+        dev.download(o, d_pcm)
+        outs.append(o)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    for f, (_, _, po, _, ne) in zip(files, ar.layout):
+        assert np.array_equal(outs[0][po:po + ne], oracle_pcm(f)[0])
+    plan.destroy()
+    for p in (d_idx, d_hdr, d_pcm, d_mf):
+        dev.free(p)
+
+
+@pytest.mark.parametrize("prestage", [False, True])
+def test_batch_decode_stages_byteplanes(dev, prestage):
+    """acm_batch_decode with ACM_BATCH_STAGE_BYTEPLANE: the host pool re-orders the whole tiles of every clean stream of a level
+    that has the form, the upload carries that and the int16 rows of the ragged tails only - same PCM and statuses as the oracle
+    for clean, ragged, stereo, truncated, H1-patched, tiny and non-ACM files of every level"""
+    import oracle_api as O
+    lv = [7, 9, 5, 8, 11, 6, 13, 10, 12]
+    files = [make_stream(27000 + i, lv[i % 9], [16, 3, 1, 33][i % 4], 3 + (i * 7) % 23 + (16384 >> lv[i % 9]) // 4,
+                         channels=1 + i % 2, cut=i % 5, pwr_max=[12, 6, 15][i % 3], val_max=65535 if i % 3 == 2 else 255) for i in range(63)]
+    files[5] = files[5][:len(files[5]) * 2 // 3]
+    files[11] = b"RIFFnope"
+    files[17] = make_stream(27990, 7, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    files[23] = make_stream(27991, 9, 16, 1)                 # one block = one tile exactly: nothing travels as int16
+    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage)
+    res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=True)
+    assert tm0.packed_streams == 0 and tm.packed_streams >= 30, (tm0.packed_streams, tm.packed_streams)
+    assert tm.h2d_bytes <= 1.3 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
+    for k, f in enumerate(files):
+        o = O.Oracle(f)
+        if o.err < 0:
+            assert res[k][0] == o.err and res[k][1].size == 0, k
+            continue
+        want, wst = oracle_pcm(f)
+        # the batch status is what stopped the parser; an acm_read_loop() caller may see that error swallowed (test_gpu_parity.py)
+        assert (res[k][0] == wst or (res[k][0] < 0 and wst <= 0)) and np.array_equal(res[k][1], want), k
+        assert plain[k][0] == res[k][0] and np.array_equal(plain[k][1], want), k
+    # the device parser stages int16: the flag is ignored there
+    res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    assert tm.packed_streams == 0
+    for k, f in enumerate(files):
+        if O.Oracle(f).err >= 0:
+            assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
