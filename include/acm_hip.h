@@ -216,6 +216,7 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  * ragged tail of a stream stays int16 (as with the packed form).
  * ---------------------------------------------------------------------- */
 int  acmhip_mform_tile_rows(uint32_t level);     /* rows per tile of the matrix-core build, 0 if the level has none */
+int  acmhip_mform_group(uint32_t level);         /* columns of a residue class kept side by side: 8 (a three-stage first pass) or 16 (four) */
 /* bytes of a block holding nrows rows (incl. the two rows of zeros in front) */
 uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);
 /* host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them) -> out[acmhip_mform_bytes(level, nrows)] */

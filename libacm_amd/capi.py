@@ -86,7 +86,7 @@ ACMHIP_SYMBOLS = [
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
-    "acmhip_mform_tile_rows", "acmhip_mform_bytes", "acmhip_mform_rows", "acmhip_mform_unrows", "acmhip_plan_bind_mform",
+    "acmhip_mform_tile_rows", "acmhip_mform_group", "acmhip_mform_bytes", "acmhip_mform_rows", "acmhip_mform_unrows", "acmhip_plan_bind_mform",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -153,6 +153,7 @@ def lib():
     L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(PackedStream), C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_bind_packed.argtypes = [vp, vp, vp]
     L.acmhip_mform_tile_rows.argtypes = [C.c_uint32]
+    L.acmhip_mform_group.argtypes = [C.c_uint32]
     L.acmhip_mform_bytes.argtypes = [C.c_uint32, C.c_uint64]
     L.acmhip_mform_bytes.restype = C.c_uint64
     L.acmhip_mform_rows.argtypes = [C.c_uint32, vp, C.c_uint64, vp]

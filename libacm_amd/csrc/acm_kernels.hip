@@ -1285,52 +1285,74 @@ typedef int32_t v4i_t __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 #include "acm_mfma_tables.inc"
 
-template <class C>
+/* G = 3: v_mfma_i32_16x16x32_i8 (8 operand bytes per lane); G = 4: the first FOUR stages, 32 outputs from 64 inputs per residue class and row
+ * pair: two v_mfma_i32_16x16x64_i8 (16 operand bytes per lane) per byte plane, one per row of the pair; a staged row then holds 16 low and
+ * 16 high bytes per residue c < cols/16.  (Five stages would need 128 inputs per output and sums beyond the 24-bit multiplier.) */
+template <int G> struct MfmaTables;
+template <> struct MfmaTables<3> {
+	static __device__ __forceinline__ int a(int v, int m, int k) { return ACM_MF_A3[v][m][k]; }
+	static __device__ __forceinline__ int krow(int v, int r, int m) { return ACM_MF_KROW3[v][r][m]; }
+	static __device__ __forceinline__ int bias(int v, int f, int m) { return ACM_MF_BIAS3[v][f][m]; }
+};
+template <> struct MfmaTables<4> {
+	static __device__ __forceinline__ int a(int v, int m, int k) { return ACM_MF_A4[v][m][k]; }
+	static __device__ __forceinline__ int krow(int v, int r, int m) { return ACM_MF_KROW4[v][r][m]; }
+	static __device__ __forceinline__ int bias(int v, int f, int m) { return ACM_MF_BIAS4[v][f][m]; }
+};
+
+template <class C, int G_>
 struct FirstPassM {
 	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS, TR = C::TR;
-	static constexpr int G = 3, U = 8, SIGMA = COLS / U;
+	static constexpr int G = G_, QN = 1 << G, SIGMA = COLS / QN;    /* QN columns of a residue class per row */
+	static_assert(G == 3 || G == 4, "one matrix instruction spans the four input rows: 4 x 2^G = its K");
+	static constexpr int NM = 2 * QN / 16;                  /* matrix instructions per unit and byte plane: 16 outputs each (G = 4: one per row of the pair) */
+	static constexpr int LB = QN;                           /* operand bytes per lane: lane l feeds input row l / 16, all its QN columns */
 	static constexpr int NGRP = SIGMA / 16;                 /* groups of 16 residues per row pair */
 	static constexpr int NW = NT / 64;
 	static constexpr int NUNIT = (TR / 2) * NGRP;
 	static constexpr int NU = NUNIT / NW;                   /* units per wave and tile */
-	static constexpr int NRAW = NU * 4;
+	static constexpr int VPU = 2 * LB / 16;                 /* 16-byte loads per unit and lane: low bytes, high bytes (G = 3: both in one) */
+	static constexpr int NRAW = NU * VPU * 4;
 	static_assert(SIGMA % 16 == 0 && NU * NW == NUNIT && NU >= 1, "whole units per wave");
 	/* a wave's units are consecutive in (row pair, group) order: several pairs per wave, or several waves per pair */
 	static constexpr bool MANYG = NGRP > NU;
 	static_assert(MANYG ? NGRP % NU == 0 : NU % NGRP == 0, "units of a wave are whole row pairs, or a whole fraction of one");
 	static constexpr int WPP = MANYG ? NGRP / NU : 1;       /* waves per row pair */
 	static constexpr int ROWB = COLS * 2;                   /* staged bytes per row */
+	static constexpr int RESB = 2 * QN;                     /* staged bytes per row and residue */
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
 	static constexpr bool SIGNED_ROWVAL = false;            /* rowval = val << SHIFT for every row; rows in front of a stream repeat row 0's */
+	using T = MfmaTables<G>;
+	typedef std::conditional_t<G == 3, uint64_t, v4i_t> Operand;
 
-	struct Raw { v4u_t r[NU]; };
+	struct Raw { v4u_t r[NU * VPU]; };
 	/* per-lane operands that never change, parked in LDS between tiles (registers are what the LDS passes are short of) */
 	struct Tables {
-		uint64_t a[64];             /* lane's 8 coefficients: output l%16, inputs of row l/16 */
-		v4i_t kc[4];                /* accumulator input of outputs 4*rs .. +3: 128 x the coefficient sums of all four rows */
-		v4i_t krow[4][4];           /* [input row][rs]: the same for one input row */
-		v4i_t khalf[2][4];          /* [rows in front / the pair itself][rs] */
-		v4i_t bias[2][5];           /* [rows in front missing][rs, 4 = lanes that do not own residue 0]: the "+1" response, scaled */
+		Operand a[NM][64];          /* lane's coefficients for output tile mt: output 16 mt + l%16, inputs of row l/16 */
+		v4i_t kc[NM][4];            /* [mt][rs] accumulator input of outputs 16 mt + 4 rs .. +3: 128 x the coefficient sums of all four rows */
+		v4i_t krow[4][NM][4];       /* [input row][mt][rs]: the same for one input row */
+		v4i_t khalf[2][NM][4];      /* [rows in front / the pair itself][mt][rs] */
+		v4i_t bias[2][NM][5];       /* [rows in front missing][mt][rs, 4 = lanes that do not own residue 0]: the "+1" response, scaled */
 	};
 
 	static constexpr int pair_of(int k) { return MANYG ? 0 : k / NGRP; }                    /* relative to the wave's first row pair */
 	static constexpr int grp_of(int k) { return MANYG ? k : k % NGRP; }                     /* relative to the wave's first group */
-	static constexpr bool first_of_pair(int k) { return MANYG ? k == 0 : k % NGRP == 0; }
 	static __device__ __forceinline__ int pair0(const int tid) { return MANYG ? (tid >> 6) / WPP : (tid >> 6) * (NU / (MANYG ? 1 : NGRP)); }
 	static __device__ __forceinline__ int grp0(const int tid) { return MANYG ? ((tid >> 6) % WPP) * NU : 0; }
 
-	/* byte offset of this lane's first 16 staged bytes relative to tile row -2 */
+	/* byte offset of this lane's first staged bytes relative to tile row -2 */
 	static __device__ __forceinline__ uint32_t lane_offset(const int tid)
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
-		return (uint32_t)((2 * pair0(tid) + rs) * ROWB + (grp0(tid) * 16 + n) * 16);
+		return (uint32_t)((2 * pair0(tid) + rs) * ROWB + (grp0(tid) * 16 + n) * RESB);
 	}
 	/* the two rows in front of a stream exist in this form (two rows of zeros, written by the stager): no lane reads anywhere else */
 	static __device__ __forceinline__ bool fresh_lane(const int) { return false; }
 	template <int K>
 	static __device__ __forceinline__ void load_one(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t)
 	{
-		constexpr int off = pair_of(K) * 2 * ROWB + grp_of(K) * 256;
+		constexpr int unit = K / VPU, part = K % VPU;
+		constexpr int off = pair_of(unit) * 2 * ROWB + grp_of(unit) * 16 * RESB + part * 16;
 		static_assert(off < 4096, "12-bit immediate");
 		asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(raw.r[K]) : "v"(voff), "s"(base), "n"(off) : "memory");
 	}
@@ -1341,7 +1363,7 @@ struct FirstPassM {
 	}
 	static __device__ __forceinline__ void load(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
 	{
-		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NU>{});
+		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NU * VPU>{});
 	}
 
 	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid)
@@ -1349,41 +1371,49 @@ struct FirstPassM {
 		constexpr int32_t ONE = 1 << OutScale<L>::SHIFT;
 		if (tid < 64) {
 			const int rs = tid >> 4, m = tid & 15;
-			uint64_t a = 0;
-			for (int j = 0; j < 8; j++)
-				a |= (uint64_t)(uint8_t)ACM_MF_A[VARIANT][m][8 * rs + j] << (8 * j);
-			t.a[tid] = a;
+			for (int mt = 0; mt < NM; mt++) {
+				uint32_t w[4] = { 0, 0, 0, 0 };
+				for (int j = 0; j < LB; j++)
+					w[j / 4] |= (uint32_t)(uint8_t)T::a(VARIANT, 16 * mt + m, LB * rs + j) << (8 * (j % 4));
+				if constexpr (G == 3)
+					t.a[mt][tid] = ((uint64_t)w[1] << 32) | w[0];
+				else
+					t.a[mt][tid] = v4i_t{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
+			}
 		}
-		if (tid < 4) {
-			const int rs = tid;
+		if (tid < 4 * NM) {
+			const int rs = tid & 3, mt = tid >> 2;
 			v4i_t kc = { 0, 0, 0, 0 };
 			for (int r = 0; r < 4; r++) {
 				v4i_t kr;
 				for (int i = 0; i < 4; i++)
-					kr[i] = ACM_MF_KROW[VARIANT][r][4 * rs + i];
-				t.krow[r][rs] = kr;
+					kr[i] = T::krow(VARIANT, r, 16 * mt + 4 * rs + i);
+				t.krow[r][mt][rs] = kr;
 				kc += kr;
 				if (r == 1)
-					t.khalf[0][rs] = kc;
+					t.khalf[0][mt][rs] = kc;
 			}
-			t.kc[rs] = kc;
-			t.khalf[1][rs] = kc - t.khalf[0][rs];
+			t.kc[mt][rs] = kc;
+			t.khalf[1][mt][rs] = kc - t.khalf[0][mt][rs];
 			for (int f = 0; f < 2; f++) {
 				v4i_t b;
 				for (int i = 0; i < 4; i++)
-					b[i] = ACM_MF_BIAS[VARIANT][f][4 * rs + i] * ONE;
-				t.bias[f][rs] = b;
+					b[i] = T::bias(VARIANT, f, 16 * mt + 4 * rs + i) * ONE;
+				t.bias[f][mt][rs] = b;
 			}
 		}
-		if (tid < 2)
-			t.bias[tid][4] = v4i_t{ 0, 0, 0, 0 };
+		if (tid < 2 * NM)
+			t.bias[tid & 1][tid >> 1][4] = v4i_t{ 0, 0, 0, 0 };
 	}
 
-	static __device__ __forceinline__ v4i_t mfma(const uint64_t a, const uint64_t b, const v4i_t c)
+	static __device__ __forceinline__ v4i_t mfma(const Operand a, const Operand b, const v4i_t c)
 	{
-		return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+		if constexpr (G == 3)
+			return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+		else
+			return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
 	}
-	/* y (+)= c * val for the lane's four outputs: |c| < 2^22 (48 x 32768 at most) and val << SHIFT < 2^23, so the 24-bit multiplier is
+	/* y (+)= c * val for the lane's four outputs: |c| < 2^23 (162 x 32768 at most) and val << SHIFT < 2^23, so the 24-bit multiplier is
 	 * exact mod 2^32.  One asm statement per four (see mul_idx_val_x4); its inputs are VALU results, never the matrix core's own registers
 	 * (the compiler does not look inside asm for the wait states those need). */
 	template <bool ACC>
@@ -1407,53 +1437,81 @@ struct FirstPassM {
 			c[i] = (int32_t)(((uint32_t)e[i] << 8) + (uint32_t)d[i]);
 		return c;
 	}
+	static __device__ __forceinline__ Operand masked(const Operand a, const bool keep)
+	{
+		if constexpr (G == 3)
+			return keep ? a : 0ull;
+		else
+			return keep ? a : v4i_t{ 0, 0, 0, 0 };
+	}
 
 	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put two rows of zeros there) */
 	static constexpr int UPP = MANYG ? NU : NGRP;           /* units of one row pair in a wave */
 	static constexpr int NPW = NU / UPP;                    /* row pairs per wave */
 	template <int PP, int... Js>
-	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int rs,
-							const bool owns0, const uint64_t a, const Tables &t, std::integer_sequence<int, Js...>)
+	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int lane,
+							const bool owns0, const Tables &t, std::integer_sequence<int, Js...>)
 	{
 		constexpr int PS = C::PS;
+		const int rs = lane >> 4;
 		const v4i_t zero = { 0, 0, 0, 0 };
 		const int32_t va = __builtin_amdgcn_readfirstlane(rv[0]), vb = __builtin_amdgcn_readfirstlane(rv[1]);      /* rows 2P-2, 2P-1 */
 		const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]), vd = __builtin_amdgcn_readfirstlane(rv[3]);      /* rows 2P, 2P+1 */
+		auto lo = [&](int k) -> Operand {
+			if constexpr (G == 3)
+				return ((uint64_t)raw.r[k].y << 32) | raw.r[k].x;
+			else
+				return (v4i_t)raw.r[2 * k];
+		};
+		auto hi = [&](int k) -> Operand {
+			if constexpr (G == 3)
+				return ((uint64_t)raw.r[k].w << 32) | raw.r[k].z;
+			else
+				return (v4i_t)raw.r[2 * k + 1];
+		};
 		/* the "+1" only reaches the lane that owns residue 0, in the unit of group 0 (the pair's first unit, if this wave has it) */
-		const v4i_t yb = t.bias[nothing_in_front ? 1 : 0][owns0 ? rs : 4];
-		auto lo = [&](int k) { return ((uint64_t)raw.r[k].y << 32) | raw.r[k].x; };
-		auto hi = [&](int k) { return ((uint64_t)raw.r[k].w << 32) | raw.r[k].z; };
-		auto store = [&](int k, const v4i_t y) {
+		auto bias = [&](int mt) { return t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4]; };
+		/* output 16 mt + 4 rs + i of the unit: row (16 mt + 4 rs) / QN of the pair, column q = (16 mt + 4 rs) % QN + i of the residue */
+		auto store = [&](int k, int mt, const v4i_t y) {
+			constexpr int per_row = QN / 16;                        /* output tiles per row of the pair: 1 (G = 4), a half (G = 3: one tile = both rows) */
 			uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
+			if (per_row >= 1)
+				o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % (per_row > 0 ? per_row : 1)) * 16 * SIGMA + (((mt % (per_row > 0 ? per_row : 1)) * 16 * SIGMA) >> PS));
 #pragma unroll
 			for (int i = 0; i < 4; i++)
 				o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
 		};
 		if (va == vb && vb == vc && vc == vd) {
 			/* one val over all four rows (the usual case): the multiply moves behind the matrix */
-			const v4i_t kc = t.kc[rs];
 			auto unit = [&](auto jj) {
 				constexpr int k = PP * UPP + decltype(jj)::value;
 				constexpr bool with_bias = grp_of(k) == 0;
-				const v4i_t c = join(mfma(a, lo(k), kc), mfma(a, hi(k), zero));
-				v4i_t y = yb;
-				scale4<with_bias>(y, c, vc);
-				store(k, y);
+#pragma unroll
+				for (int mt = 0; mt < NM; mt++) {
+					const Operand a = t.a[mt][lane];
+					const v4i_t c = join(mfma(a, lo(k), t.kc[mt][rs]), mfma(a, hi(k), zero));
+					v4i_t y = with_bias ? bias(mt) : zero;
+					scale4<with_bias>(y, c, vc);
+					store(k, mt, y);
+				}
 			};
 			(unit(std::integral_constant<int, Js>{}), ...);
 		} else if (va == vb && vc == vd) {
 			/* a block boundary between the pair and the rows in front of it: the matrix once per half */
-			const uint64_t a_front = rs < 2 ? a : 0ull, a_pair = rs < 2 ? 0ull : a;
-			const v4i_t k_front = t.khalf[0][rs], k_pair = t.khalf[1][rs];
 			auto unit = [&](auto jj) {
 				constexpr int k = PP * UPP + decltype(jj)::value;
 				constexpr bool with_bias = grp_of(k) == 0;
-				const v4i_t c1 = join(mfma(a_front, lo(k), k_front), mfma(a_front, hi(k), zero));
-				const v4i_t c2 = join(mfma(a_pair, lo(k), k_pair), mfma(a_pair, hi(k), zero));
-				v4i_t y = yb;
-				scale4<with_bias>(y, c1, va);
-				scale4<true>(y, c2, vc);
-				store(k, y);
+#pragma unroll
+				for (int mt = 0; mt < NM; mt++) {
+					const Operand a = t.a[mt][lane];
+					const Operand a_front = masked(a, rs < 2), a_pair = masked(a, rs >= 2);
+					const v4i_t c1 = join(mfma(a_front, lo(k), t.khalf[0][mt][rs]), mfma(a_front, hi(k), zero));
+					const v4i_t c2 = join(mfma(a_pair, lo(k), t.khalf[1][mt][rs]), mfma(a_pair, hi(k), zero));
+					v4i_t y = with_bias ? bias(mt) : zero;
+					scale4<with_bias>(y, c1, va);
+					scale4<true>(y, c2, vc);
+					store(k, mt, y);
+				}
 			};
 			(unit(std::integral_constant<int, Js>{}), ...);
 		} else {
@@ -1461,35 +1519,47 @@ struct FirstPassM {
 			auto unit = [&](auto jj) {
 				constexpr int k = PP * UPP + decltype(jj)::value;
 				constexpr bool with_bias = grp_of(k) == 0;
-				v4i_t y = with_bias ? yb : zero;
 #pragma unroll 1
-				for (int r = 0; r < 4; r++) {
-					const uint64_t ar = (rs == r) ? a : 0ull;
-					const v4i_t c = join(mfma(ar, lo(k), t.krow[r][rs]), mfma(ar, hi(k), zero));
-					scale4<true>(y, c, r == 0 ? va : (r == 1 ? vb : (r == 2 ? vc : vd)));
+				for (int mt = 0; mt < NM; mt++) {
+					const Operand a = t.a[mt][lane];
+					v4i_t y = with_bias ? bias(mt) : zero;
+#pragma unroll 1
+					for (int r = 0; r < 4; r++) {
+						const Operand ar = masked(a, rs == r);
+						const v4i_t c = join(mfma(ar, lo(k), t.krow[r][mt][rs]), mfma(ar, hi(k), zero));
+						scale4<true>(y, c, r == 0 ? va : (r == 1 ? vb : (r == 2 ? vc : vd)));
+					}
+					/* (mt is a run-time value here: the same address arithmetic as store(), spelled out) */
+					constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;
+					uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
+					if (QN >= 16)
+						o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
+#pragma unroll
+					for (int i = 0; i < 4; i++)
+						o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
 				}
-				store(k, y);
 			};
 			(unit(std::integral_constant<int, Js>{}), ...);
 		}
 	}
 	template <int... PPs>
-	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int rs, const bool owns0,
-							 const uint64_t a, const Tables &t, std::integer_sequence<int, PPs...>)
+	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int lane, const bool owns0,
+							 const Tables &t, std::integer_sequence<int, PPs...>)
 	{
-		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, rs, owns0, a, t, std::make_integer_sequence<int, UPP>{}), ...);
+		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, std::make_integer_sequence<int, UPP>{}), ...);
 	}
 	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t)
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
 		const int p0 = pair0(tid), g0 = grp0(tid);
 		const bool owns0 = (n == 0) && (g0 == 0);                       /* residue 0 sits in group 0 */
-		const uint64_t a = t.a[lane];
-		/* LDS place of output 4*rs of the lane's residue in the wave's first unit */
+		/* LDS place of output 4*rs of the lane's residue in the wave's first unit: outputs 4 rs .. of a 16-output tile are columns
+		 * q = 4 rs .. (+ 16 per further tile of the same row); G = 3: rs >= 2 is the pair's second row (q = 4 (rs - 2) ..) */
 		constexpr int PS = C::PS;
-		uint32_t *const o0 = tile + lds_at<PS>(2 * p0 * COLS + g0 * 16) + n + (4 * rs * SIGMA + ((4 * rs * SIGMA) >> PS));
+		const int q_lane = (4 * rs) % QN, row_lane = (4 * rs) / QN;
+		uint32_t *const o0 = tile + lds_at<PS>(2 * p0 * COLS + g0 * 16) + n + row_lane * (COLS + (COLS >> PS)) + (q_lane * SIGMA + ((q_lane * SIGMA) >> PS));
 		const bool missing = fresh_stream && __builtin_amdgcn_readfirstlane(p0) == 0;     /* the wave's first row pair has nothing in front of it */
-		run_pairs(raw, o0, rowval + 2 * p0, missing, rs, owns0, a, t, std::make_integer_sequence<int, NPW>{});
+		run_pairs(raw, o0, rowval + 2 * p0, missing, lane, owns0, t, std::make_integer_sequence<int, NPW>{});
 	}
 };
 
@@ -1525,8 +1595,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	  int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
-	using FP = std::conditional_t<MFORM, FirstPassM<C>, FirstPass2<C, G0, 2, ABL>>;
-	static_assert(!MFORM || G0 == 3, "the coefficient tables are those of a three-stage first pass");
+	using FP = std::conditional_t<MFORM, FirstPassM<C, (MFORM ? G0 : 3)>, FirstPass2<C, G0, 2, ABL>>;
+	static_assert(!MFORM || G0 == 3 || G0 == 4, "coefficient tables exist for a first pass of three or four stages");
 	constexpr bool NEG_ODD_ROWS = FP::SIGNED_ROWVAL && StageKind<L, 0>::N;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
@@ -1740,14 +1810,27 @@ constexpr Tile2Entry entry_k2mw()
 {
 	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, true, Gs...>, C::NT, C::TR, WPC };
 }
-const Tile2Entry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
-	entry_k2m<TileCfg<7, 256, 8192>, 3, 2, 2>(),
-	entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(),
-	entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(),
-	entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(),
-	entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(),
-	entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(),
+/* [level][first pass of three / four stages]; the staged form differs between the two (8 or 16 columns of a residue class side by side),
+ * so the choice is made once per process: the measured default below, or ACM_K2M_G0=3|4 (experiments) */
+struct Tile2MEntry { Tile2Entry e; int g0; };
+const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
+	{ { entry_k2m<TileCfg<7, 256, 8192>, 3, 2, 2>(), 3 }, { Tile2Entry{ nullptr, 0, 0, 0 }, 0 } },        /* 8 residue classes of stride 8: less than one operand tile */
+	{ { entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<8, 256, 8192>, 4, 2, 2>(), 4 } },
+	{ { entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(), 3 }, { entry_k2m<TileCfg<9, 256, 8192>, 4, 3, 2>(), 4 } },
+	{ { entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(), 3 }, { entry_k2m<TileCfg<10, 256, 8192>, 4, 3, 3>(), 4 } },
+	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<11, 256, 8192>, 4, 3, 2, 2>(), 4 } },
+	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { entry_k2mw<TileCfg<12, 512, 16384>, 2, 4, 3, 3, 2>(), 4 } },
 };
+/* measured (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box): level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12
+ * four stages +5.5 / +6.6 / +5 % (one LDS pass, or one of its stages, less) */
+constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4 };
+inline const Tile2MEntry &tile2m_entry(uint32_t level)
+{
+	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;
+	const Tile2MEntry *row = g_tile2m[level - ACM_K2M_MIN_LEVEL];
+	const int want = forced ? forced : g_tile2m_default[level - ACM_K2M_MIN_LEVEL];
+	return (want == 4 && row[1].g0 == 4) ? row[1] : row[0];
+}
 
 // ---------------------------------------------------------------------------
 // K2P: the lean tile kernel on the packed staged form
@@ -2256,7 +2339,14 @@ extern "C" int acmk_tile2m_rows(uint32_t level)
 {
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
 		return 0;
-	return g_tile2m[level - ACM_K2M_MIN_LEVEL].tile_rows;
+	return tile2m_entry(level).e.tile_rows;
+}
+
+extern "C" int acmk_tile2m_stages(uint32_t level)
+{
+	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
+		return 0;
+	return tile2m_entry(level).g0;
 }
 
 extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_blkhdr *d_hdr,
@@ -2268,7 +2358,7 @@ extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_til
 		return -1;
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
 		return -1;
-	const Tile2Entry &e = g_tile2m[level - ACM_K2M_MIN_LEVEL];
+	const Tile2Entry &e = tile2m_entry(level).e;
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;

@@ -243,25 +243,32 @@ extern "C" uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows)
 	return (nrows + 2) * (2ull << level);
 }
 
+extern "C" int acmhip_mform_group(uint32_t level)
+{
+	const int g = acmk_tile2m_stages(level);
+	return g ? 1 << g : 0;
+}
+
 extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out)
 {
-	if (!acmk_tile2m_rows(level) || (!idx && nrows) || !out)
+	const size_t qn = (size_t)acmhip_mform_group(level);
+	if (!qn || (!idx && nrows) || !out)
 		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / 8, rowb = cols * 2;
+	const size_t cols = (size_t)1 << level, sigma = cols / qn, rowb = cols * 2;
 	/* the two rows in front of the stream: index 0 everywhere */
 	for (size_t c = 0; c < 2 * sigma; c++) {
-		memset(out + c * 16, 0x80, 8);
-		memset(out + c * 16 + 8, 0x00, 8);
+		memset(out + c * 2 * qn, 0x80, qn);
+		memset(out + c * 2 * qn + qn, 0x00, qn);
 	}
 	for (uint64_t r = 0; r < nrows; r++) {
 		const int16_t *src = idx + r * cols;
 		uint8_t *dst = out + (r + 2) * rowb;
 		for (size_t c = 0; c < sigma; c++) {
-			uint8_t *d = dst + c * 16;
-			for (size_t q = 0; q < 8; q++) {
+			uint8_t *d = dst + c * 2 * qn;
+			for (size_t q = 0; q < qn; q++) {
 				const uint16_t x = (uint16_t)src[c + q * sigma];
 				d[q] = (uint8_t)(x ^ 0x80u);
-				d[8 + q] = (uint8_t)(x >> 8);
+				d[qn + q] = (uint8_t)(x >> 8);
 			}
 		}
 	}
@@ -270,19 +277,20 @@ extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nr
 
 extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *block, uint64_t nrows, int16_t *idx)
 {
-	if (!acmk_tile2m_rows(level) || !block || (!idx && nrows))
+	const size_t qn = (size_t)acmhip_mform_group(level);
+	if (!qn || !block || (!idx && nrows))
 		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / 8, rowb = cols * 2;
+	const size_t cols = (size_t)1 << level, sigma = cols / qn, rowb = cols * 2;
 	for (size_t c = 0; c < 2 * sigma; c++)
-		for (size_t q = 0; q < 8; q++)
-			if (block[c * 16 + q] != 0x80 || block[c * 16 + 8 + q] != 0)
+		for (size_t q = 0; q < qn; q++)
+			if (block[c * 2 * qn + q] != 0x80 || block[c * 2 * qn + qn + q] != 0)
 				return ACMHIP_ERR_ARG;
 	for (uint64_t r = 0; r < nrows; r++) {
 		const uint8_t *src = block + (r + 2) * rowb;
 		int16_t *dst = idx + r * cols;
 		for (size_t c = 0; c < sigma; c++)
-			for (size_t q = 0; q < 8; q++)
-				dst[c + q * sigma] = (int16_t)(uint16_t)((src[c * 16 + q] ^ 0x80u) | ((unsigned)src[c * 16 + 8 + q] << 8));
+			for (size_t q = 0; q < qn; q++)
+				dst[c + q * sigma] = (int16_t)(uint16_t)((src[c * 2 * qn + q] ^ 0x80u) | ((unsigned)src[c * 2 * qn + qn + q] << 8));
 	}
 	return ACMHIP_OK;
 }

@@ -23,8 +23,9 @@ def test_levels_with_a_byteplane_form():
         if level in LEVELS:
             assert tr == (16384 if level == 12 else 8192) >> level
             assert L.acmhip_mform_bytes(level, 10) == 12 * (2 << level)
+            assert L.acmhip_mform_group(level) in (8, 16)
         else:
-            assert tr == 0
+            assert tr == 0 and L.acmhip_mform_group(level) == 0
             assert L.acmhip_mform_rows(level, None, 0, None) != 0
 
 
@@ -44,27 +45,29 @@ def test_round_trip(level, rows, pwr_max):
     nrows = nt * tr
     block = mf.data[:(nrows + 2) * cols * 2]
     # two rows of index 0 in front: low bytes 0x80, high bytes 0
-    front = block[:2 * cols * 2].reshape(-1, 16)
-    assert (front[:, :8] == 0x80).all() and (front[:, 8:] == 0).all()
+    qn = capi.lib().acmhip_mform_group(level)            # columns of a residue class side by side: 8 or 16
+    front = block[:2 * cols * 2].reshape(-1, 2 * qn)
+    assert (front[:, :qn] == 0x80).all() and (front[:, qn:] == 0).all()
     back = capi.mform_unrows(level, block, nrows)
     assert np.array_equal(back, s.idx[:nrows * cols])
-    # layout: row r, residue c, q -> byte (r + 2) * 2 cols + 16 c + q (low, bit 7 flipped) / + 8 + q (high)
-    sigma = cols // 8
+    # layout: row r, residue c, q -> byte (r + 2) * 2 cols + 2 qn c + q (low, bit 7 flipped) / + qn + q (high)
+    sigma = cols // qn
     rng = np.random.default_rng(level)
     for _ in range(64):
-        r, c, q = int(rng.integers(nrows)), int(rng.integers(sigma)), int(rng.integers(8))
+        r, c, q = int(rng.integers(nrows)), int(rng.integers(sigma)), int(rng.integers(qn))
         x = int(s.idx[r * cols + c + q * sigma]) & 0xFFFF
-        at = (r + 2) * 2 * cols + 16 * c
-        assert block[at + q] == (x & 0xFF) ^ 0x80 and block[at + 8 + q] == x >> 8
+        at = (r + 2) * 2 * cols + 2 * qn * c
+        assert block[at + q] == (x & 0xFF) ^ 0x80 and block[at + qn + q] == x >> 8
 
 
-def load_tables():
+def load_tables(G):
     import os
     here = os.path.dirname(os.path.abspath(__file__))
     txt = open(os.path.join(here, "..", "libacm_amd", "csrc", "acm_mfma_tables.inc")).read()
     out = {}
-    for name, shape in (("ACM_MF_A", (2, 16, 32)), ("ACM_MF_KROW", (2, 4, 16)), ("ACM_MF_BIAS", (2, 2, 16))):
-        body = txt[txt.index(name):]
+    B = 2 << G
+    for name, shape in (("A", (2, B, 2 * B)), ("KROW", (2, 4, B)), ("BIAS", (2, 2, B))):
+        body = txt[txt.index("ACM_MF_%s%d[" % (name, G)):]
         body = body[body.index("=") + 1:body.index(";")]
         out[name] = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int64).reshape(shape)
     return out
@@ -105,34 +108,37 @@ def test_fir_restatement_matches_the_oracle():
     assert np.array_equal(got[:want.size], want)
 
 
-@pytest.mark.parametrize("level", [7, 10])
-def test_matrix_tables_reproduce_three_stages(level):
-    """A x (staged bytes) + KROW, times val, + BIAS == stage-2 output of the cascade, for every residue class and row pair of a
-    staged stream (one val over all rows here; the per-row split is the same sum taken row by row)"""
-    t = load_tables()
-    A, KROW, BIAS = t["ACM_MF_A"][0], t["ACM_MF_KROW"][0], t["ACM_MF_BIAS"][0]
-    cols, sigma = 1 << level, (1 << level) // 8
+@pytest.mark.parametrize("G", [3, 4])
+@pytest.mark.parametrize("level", [8, 10])
+def test_matrix_tables_reproduce_the_first_stages(level, G):
+    """A x (index bytes) + KROW, times val, + BIAS == output of stage G - 1 of the cascade, for every residue class and row pair of a
+    staged stream (one val over all rows here; the per-row split is the same sum taken row by row).  The bytes are what the kernel's
+    matrix instruction reads: low byte minus 128 and high byte, both signed."""
+    t = load_tables(G)
+    A, KROW, BIAS = t["A"][0], t["KROW"][0], t["BIAS"][0]
+    qn = 1 << G
+    cols, sigma = 1 << level, (1 << level) // qn
     rows = 6
     s = capi.stage_file(make_stream(43000 + level, level, rows, 1, pwr_max=15, val_max=65535))
     assert s.info.blocks == 1
     val = int(s.hdr[0, 0])
     idx = s.idx[:rows * cols].astype(np.int64).reshape(rows, cols)
-    want = juggle_stages(idx * val, cols, 3)
-    block = np.zeros(capi.lib().acmhip_mform_bytes(level, rows), dtype=np.uint8)
-    assert capi.lib().acmhip_mform_rows(level, s.idx.ctypes.data, rows, block.ctypes.data) == 0
-    planes = block.reshape(rows + 2, sigma, 2, 8)
-    lo = planes[:, :, 0, :].view(np.int8).astype(np.int64)         # as the matrix instruction reads them: signed bytes
-    hi = planes[:, :, 1, :].view(np.int8).astype(np.int64)
+    want = juggle_stages(idx * val, cols, G)
+    padded = np.concatenate([np.zeros((2, cols), dtype=np.int64), idx])          # two rows of index 0 in front of the stream
+    lo = ((padded & 0xFF) ^ 0x80).astype(np.uint8).view(np.int8).astype(np.int64)
+    hi = (padded >> 8).astype(np.int64)
+    assert np.array_equal(lo + 128 + 256 * hi, padded)
     for p in range(rows // 2):
         for c in range(sigma):
-            blo = lo[2 * p:2 * p + 4, c, :].reshape(32)            # rows 2p-2 .. 2p+1 (block row 0 = stream row -2)
-            bhi = hi[2 * p:2 * p + 4, c, :].reshape(32)
+            blo = lo[2 * p:2 * p + 4, c::sigma].reshape(4 * qn)                    # rows 2p-2 .. 2p+1, the residue's qn columns each
+            bhi = hi[2 * p:2 * p + 4, c::sigma].reshape(4 * qn)
             d = A @ blo + KROW.sum(axis=0) + ((A @ bhi) << 8)
+            assert np.abs(d).max() < 1 << 23                                       # the kernel multiplies with the 24-bit multiplier
             y = d * val + (BIAS[1 if p == 0 else 0] if c == 0 else 0)
-            got = y.reshape(2, 8)                                  # output m = 8 * (row in pair) + q
+            got = y.reshape(2, qn)                                                 # output m = qn * (row in pair) + q
             w = want[2 * p:2 * p + 2, c::sigma]
             assert np.array_equal(got, w), (p, c)
     # variant 1 = the same with odd outputs negated (what a P stage leaves in LDS)
-    sign = np.where(np.arange(16) & 1, -1, 1)
-    assert np.array_equal(t["ACM_MF_A"][1], A * sign[:, None])
-    assert np.array_equal(t["ACM_MF_KROW"][1], KROW * sign[None, :]) and np.array_equal(t["ACM_MF_BIAS"][1], BIAS * sign[None, :])
+    sign = np.where(np.arange(2 * qn) & 1, -1, 1)
+    assert np.array_equal(t["A"][1], A * sign[:, None])
+    assert np.array_equal(t["KROW"][1], KROW * sign[None, :]) and np.array_equal(t["BIAS"][1], BIAS * sign[None, :])

@@ -154,3 +154,36 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
     for k, f in enumerate(files):
         if O.Oracle(f).err >= 0:
             assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
+
+
+@pytest.mark.parametrize("g0", [3, 4])
+def test_byteplane_both_first_pass_depths(g0):
+    """every level has its measured default (three or four stages on the matrix cores); ACM_K2M_G0 forces the other build and the
+    form that goes with it, read once per process - so this runs in a child: parity with the oracle over levels 7-12, even, odd
+    and single block heights, 16-bit indices"""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from helpers import make_stream, oracle_pcm
+from libacm_amd import capi
+dev = capi.Device(0)
+bad = 0
+for level in range(7, 13):
+    assert capi.lib().acmhip_mform_group(level) == (16 if %d == 4 and level >= 8 else 8)
+    tr = capi.lib().acmhip_mform_tile_rows(level)
+    for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
+        f = make_stream(28000 + level * 100 + rows, level, rows, (5 * tr + rows - 1) // rows + 1, cut=3, pwr_min=min(4, pm), pwr_max=pm,
+                        val_max=65535 if pm == 15 else 255)
+        got, st = capi.synth(dev, [capi.stage_file(f)], return_stats=True, mform=True)
+        assert st.mform_tiles >= 5
+        bad += not np.array_equal(got[0], oracle_pcm(f)[0])
+print("BAD", bad)
+sys.exit(1 if bad else 0)
+""" % (os.path.dirname(os.path.abspath(__file__)), g0)
+    env = dict(os.environ, ACM_K2M_G0=str(g0), ACM_K2="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
