@@ -1260,8 +1260,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 					const uint64_t cols = s.info.cols, nrows = (uint64_t)s.info.blocks * s.info.rows;
 					uint64_t from_row = 0;
 					if (s.pk_ntiles) {
-						const uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)(stage_mform ? acmhip_mform_tile_rows(s.info.level)
-															  : acmhip_packed_tile_rows(s.info.level));
+						/* what the plan takes from the second form: whole tiles of the lean kernel's own height (a byte-plane tile may
+						 * be a fraction of one) */
+						uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)(stage_mform ? acmhip_mform_tile_rows(s.info.level)
+														    : acmhip_packed_tile_rows(s.info.level));
+						if (stage_mform && acmk_tile2_rows(s.info.level) > 0)
+							rows2 = rows2 / (uint64_t)acmk_tile2_rows(s.info.level) * (uint64_t)acmk_tile2_rows(s.info.level);
 						if (rows2 * cols >= items[i].words)
 							continue;               /* nothing behind the whole tiles is emitted */
 						from_row = rows2 >= 2 ? rows2 - 2 : 0;

@@ -80,7 +80,7 @@ struct LevelGroup {
 	uint32_t ntiles2p = 0;
 	/* the same for streams that came with a byte-plane form (acm_tile2's matrix-core build) */
 	AcmTile2 *d_tiles2m = nullptr, *d_tiles2m_plain = nullptr;
-	uint32_t ntiles2m = 0;
+	uint32_t ntiles2m = 0, ntiles2m_plain = 0;      /* the matrix-core build may cut the same rows into smaller tiles */
 	AcmTile *d_tiles_extra = nullptr;   /* halo-flavour tiles that must not join a carry run (clean tiles of patched streams) */
 	uint32_t ntiles_extra = 0;
 	uint32_t *d_list = nullptr;
@@ -496,6 +496,44 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	for (auto &v : patch_rows)
 		std::sort(v.begin(), v.end());
 	std::vector<std::vector<AcmTile2>> tiles2(16), tiles2p(16), tiles2p_plain(16), tiles2m(16), tiles2m_plain(16);
+	/* rows [0, rows2) of stream i as records of the lean tile kernel (T2 rows each), and, where the stream came with a second staged form,
+	 * once more as records of the build that reads it */
+	auto cut_lean = [&](size_t i, uint64_t rows2, uint32_t T2) -> int {
+		const acmhip_stream_desc &s = streams[i];
+		const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
+		if (packed && packed[i].ntiles && packed[i].form > ACMHIP_FORM_BYTEPLANE) {
+			set_err("stream %zu: staged form %u", i, packed[i].form);
+			return ACMHIP_ERR_ARG;
+		}
+		const bool pk = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_PACKED && acmk_tile2p_rows(s.level) == (int)T2;
+		/* the matrix-core build may cut the same rows into smaller tiles (its rows in front cost nothing): T2M divides T2 */
+		const uint32_t T2M = (uint32_t)acmk_tile2m_rows(s.level);
+		const bool mf = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_BYTEPLANE && T2M && T2 % T2M == 0;
+		if ((pk && packed[i].ntiles < rows2 / T2) || (mf && packed[i].ntiles < rows2 / T2M)) {
+			set_err("stream %zu: %u tiles in its second staged form, %llu whole tiles to decode", i, packed[i].ntiles,
+				(unsigned long long)(rows2 / (mf ? T2M : T2)));
+			return ACMHIP_ERR_ARG;
+		}
+		std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : mf ? tiles2m_plain[s.level] : tiles2[s.level];
+		for (uint64_t r = 0; r < rows2; r += T2) {
+			const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
+			plain.push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
+						  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
+						  r == 0 ? ACM_TILE_FRESH : 0u });
+			if (pk)
+				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
+								     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
+								     r == 0 ? ACM_TILE_FRESH : 0u });
+			/* the byte-plane block holds the same rows at the same spacing, two rows of zeros in front */
+			for (uint64_t rm = r; mf && rm < r + T2; rm += T2M) {
+				const uint64_t rhm = rm >= 2 ? rm - 2 : 0;
+				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + ((rm + 2) << s.level), s.pcm_off + (rm << s.level),
+								     (uint32_t)(s.hdr_off + rhm / s.rows), (uint32_t)(rhm % s.rows), magic,
+								     rm == 0 ? ACM_TILE_FRESH : 0u });
+			}
+		}
+		return ACMHIP_OK;
+	};
 	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
 	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
@@ -598,35 +636,9 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			if (k2_allowed && T2 && s.row_begin == 0) {
 				const uint64_t full_rows = std::min<uint64_t>(s.nrows, s.n_emit >> s.level);
 				rows2 = full_rows / T2 * T2;
-				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
-				/* a stream that came with its packed form: the same tiles once more as records of the packed build */
-				if (packed && packed[i].ntiles && packed[i].form > ACMHIP_FORM_BYTEPLANE) {
-					set_err("stream %zu: staged form %u", i, packed[i].form);
-					return ACMHIP_ERR_ARG;
-				}
-				const bool pk = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_PACKED && acmk_tile2p_rows(s.level) == (int)T2;
-				const bool mf = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_BYTEPLANE && acmk_tile2m_rows(s.level) == (int)T2;
-				if ((pk || mf) && packed[i].ntiles < rows2 / T2) {
-					set_err("stream %zu: %u tiles in its second staged form, %llu whole tiles to decode", i, packed[i].ntiles,
-						(unsigned long long)(rows2 / T2));
-					return ACMHIP_ERR_ARG;
-				}
-				std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : mf ? tiles2m_plain[s.level] : tiles2[s.level];
-				for (uint64_t r = 0; r < rows2; r += T2) {
-					const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
-					plain.push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
-								  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-								  r == 0 ? ACM_TILE_FRESH : 0u });
-					if (pk)
-						tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
-										     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
-										     r == 0 ? ACM_TILE_FRESH : 0u });
-					/* the byte-plane block holds the same rows at the same spacing, two rows of zeros in front */
-					if (mf)
-						tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + ((r + 2) << s.level), s.pcm_off + (r << s.level),
-										     (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-										     r == 0 ? ACM_TILE_FRESH : 0u });
-				}
+				const int cr = cut_lean(i, rows2, T2);
+				if (cr != ACMHIP_OK)
+					return cr;
 			}
 			for (uint64_t r = rows2; r < emit_rows; r += T)
 				tiles_rest[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), 0u, 0u });
@@ -654,13 +666,9 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				 * stream (a pseudo stream behind the n real ones) for the prefix + plane pair */
 				const uint32_t T2 = (uint32_t)acmk_tile2_rows(s.level);
 				const uint64_t rows2 = std::min<uint64_t>(s.nrows, s.n_emit >> s.level) / T2 * T2;
-				const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
-				for (uint64_t r = 0; r < rows2; r += T2) {
-					const uint64_t rh = r >= 2 ? r - 2 : 0;
-					tiles2[s.level].push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
-									    (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-									    r == 0 ? ACM_TILE_FRESH : 0u });
-				}
+				const int cr = cut_lean(i, rows2, T2);
+				if (cr != ACMHIP_OK)
+					return cr;
 				if (rows2 > 0) {
 					src.pcm_off = s.pcm_off + (rows2 << s.level);
 					src.n_emit = s.n_emit - (rows2 << s.level);
@@ -809,6 +817,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				if (rc == ACMHIP_OK && !tiles2m[lv].empty()) {
 					g.ntiles2m = (uint32_t)tiles2m[lv].size();
 					rc = to_device(pl, tiles2m[lv], &g.d_tiles2m);
+					g.ntiles2m_plain = (uint32_t)tiles2m_plain[lv].size();
 					if (rc == ACMHIP_OK)
 						rc = to_device(pl, tiles2m_plain[lv], &g.d_tiles2m_plain);
 					st.tiles += g.ntiles2m;
@@ -936,7 +945,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		if (pl->mform)
 			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		else
-			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m_plain, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}

@@ -933,7 +933,13 @@ __device__ __forceinline__ void phase_prio()
 	if constexpr (ON)
 		__builtin_amdgcn_s_setprio(P);
 }
-constexpr int PRIO_IDLE = 0, PRIO_FIRST_PASS = 2, PRIO_LDS_PASSES = 3;
+#ifndef ACM_PRIO_FIRST
+#define ACM_PRIO_FIRST 2
+#endif
+#ifndef ACM_PRIO_LDS
+#define ACM_PRIO_LDS 3
+#endif
+constexpr int PRIO_IDLE = 0, PRIO_FIRST_PASS = ACM_PRIO_FIRST, PRIO_LDS_PASSES = ACM_PRIO_LDS;
 
 /*
  * Persistent workgroups: workgroup w handles tiles w, w + gridDim.x, ...  While the LDS passes of tile n
@@ -1810,6 +1816,12 @@ constexpr Tile2Entry entry_k2mw()
 {
 	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, true, Gs...>, C::NT, C::TR, WPC };
 }
+#ifndef ACM_K2M_L12
+#define ACM_K2M_L12 entry_k2mw<TileCfg<12, 512, 16384>, 2, 4, 3, 3, 2>(), 4
+#endif
+#ifndef ACM_K2M_L13
+#define ACM_K2M_L13 entry_k2mw<TileCfg<13, 512, 16384>, 2, 4, 3, 3, 3>(), 4
+#endif
 /* [level][first pass of three / four stages]; the staged form differs between the two (8 or 16 columns of a residue class side by side),
  * so the choice is made once per process: the measured default below, or ACM_K2M_G0=3|4 (experiments) */
 struct Tile2MEntry { Tile2Entry e; int g0; };
@@ -1819,17 +1831,21 @@ const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 	{ { entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(), 3 }, { entry_k2m<TileCfg<9, 256, 8192>, 4, 3, 2>(), 4 } },
 	{ { entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(), 3 }, { entry_k2m<TileCfg<10, 256, 8192>, 4, 3, 3>(), 4 } },
 	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<11, 256, 8192>, 4, 3, 2, 2>(), 4 } },
-	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { entry_k2mw<TileCfg<12, 512, 16384>, 2, 4, 3, 3, 2>(), 4 } },
+	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { ACM_K2M_L12 } },
+	/* level 13: the vector-ALU build needs 128 KB tiles (its first pass re-runs two rows per segment); here the rows in front cost a second
+	 * read through L2 and nothing else, so a tile may be one row pair.  (Level 14: a row pair is 128 KB, sixteen waves of 128 registers -
+	 * the build spills six of them; it stays with the vector-ALU build.) */
+	{ { Tile2Entry{ nullptr, 0, 0, 0 }, 0 }, { ACM_K2M_L13 } },
 };
 /* measured (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box): level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12
  * four stages +5.5 / +6.6 / +5 % (one LDS pass, or one of its stages, less) */
-constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4 };
+constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4 };
 inline const Tile2MEntry &tile2m_entry(uint32_t level)
 {
 	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;
 	const Tile2MEntry *row = g_tile2m[level - ACM_K2M_MIN_LEVEL];
 	const int want = forced ? forced : g_tile2m_default[level - ACM_K2M_MIN_LEVEL];
-	return (want == 4 && row[1].g0 == 4) ? row[1] : row[0];
+	return ((want == 4 || row[0].g0 == 0) && row[1].g0 == 4) ? row[1] : row[0];
 }
 
 // ---------------------------------------------------------------------------

@@ -34,11 +34,13 @@ def bind(path):
     L.acmhip_plan_create.argtypes = [vp, C.POINTER(capi.StreamDesc), sz, C.POINTER(capi.Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_launch.argtypes = [vp, vp, vp, vp, C.c_uint]
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
+    L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(capi.StreamDesc), sz, C.POINTER(capi.PackedStream), C.POINTER(capi.Patch), sz, C.c_uint, C.POINTER(vp)]
+    L.acmhip_plan_bind_mform.argtypes = [vp, vp]
     return L
 
 
 class Variant:
-    def __init__(self, path, descs):
+    def __init__(self, path, descs, mform=None, d_mform=None):
         from libacm_amd import capi
         path, _, env = path.partition("@")            # lib.so@ACM_K2_ABL=17: environment set around this library's launches
         self.env = dict(kv.split("=", 1) for kv in env.split(",") if kv)
@@ -50,7 +52,14 @@ class Variant:
             raise SystemExit("%s: device_open %d" % (path, rc))
         arr = (capi.StreamDesc * len(descs))(*descs)
         self.plan = C.c_void_p()
-        rc = self.L.acmhip_plan_create(self.dev, arr, len(descs), None, 0, 0, C.byref(self.plan))
+        if mform is not None:
+            # --form byteplane: the same byte-plane arena for every library (they must agree on the form's group size)
+            # (a library whose byte-plane tiles are smaller than the stager's counts more of them over the same rows)
+            pk = (capi.PackedStream * len(descs))(*[capi.PackedStream(m.chunk_off, m.ntiles * 8, m.form) for m in mform])
+            rc = self.L.acmhip_plan_create_packed(self.dev, arr, len(descs), pk, None, 0, 0, C.byref(self.plan))
+            rc = rc or self.L.acmhip_plan_bind_mform(self.plan, d_mform)
+        else:
+            rc = self.L.acmhip_plan_create(self.dev, arr, len(descs), None, 0, 0, C.byref(self.plan))
         if rc:
             raise SystemExit("%s: plan_create %d %s" % (path, rc, self.L.acmhip_last_error()))
         self.ms = []
@@ -88,6 +97,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--allow-wrong", default="")
+    ap.add_argument("--form", choices=["int16", "byteplane"], default="int16")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     from libacm_amd import capi, workload
@@ -95,7 +105,12 @@ def main():
     b = workload.build_uniform(a.streams, a.level, a.rows, a.blocks, channels=a.channels, threads=max(4, min(64, workload.usable_cpus())))
     bufs = b.upload(dev)
     allow = set(x for x in a.allow_wrong.split(",") if x)
-    vs = [Variant(p, b.descs) for p in a.libs]
+    mf = d_mf = None
+    if a.form == "byteplane":
+        mfa = capi.mform_streams(b.idx, b.descs, threads=max(4, min(64, workload.usable_cpus())))
+        d_mf = mfa.upload(dev)
+        mf = mfa.streams
+    vs = [Variant(p, b.descs, mf, d_mf) for p in a.libs]
     host = np.empty(b.pcm_words, dtype=np.uint16)
     ref = None
     for v in vs:

@@ -10,7 +10,7 @@ from libacm_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-LEVELS = [7, 8, 9, 10, 11, 12]
+LEVELS = [7, 8, 9, 10, 11, 12, 13]
 
 
 @pytest.fixture
@@ -19,7 +19,7 @@ def force_k2(monkeypatch):
 
 
 def tile_rows(level):
-    return (16384 if level == 12 else 8192) >> level
+    return capi.lib().acmhip_mform_tile_rows(level)
 
 
 def check(dev, files, fmt=capi.FMT_S16LE, force_chans=0):
@@ -41,7 +41,7 @@ def test_byteplane_matrix(dev, force_k2, level, rows, pwr_max):
     """whole tiles from the byte-plane form, the ragged tail from the int16 arena; block heights that put a val change between the
     rows of a unit in every possible place (even: between row pairs, odd: inside them, 1: everywhere) and 16-bit indices with
     16-bit row values (pwr_max 15)"""
-    tr = tile_rows(level)
+    tr = max(tile_rows(level), 4)                 # (level 13: the plan takes whole tiles of the vector-ALU build's height, two byte-plane tiles each)
     nblocks = max(2, (7 * tr + rows - 1) // rows + 1)
     f = make_stream(22000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=5, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
                     val_max=65535 if pwr_max == 15 else 255)
@@ -69,7 +69,7 @@ def test_byteplane_every_filler_code(dev, force_k2):
     valid = [0] + list(range(3, 17)) + [17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29]
     files = []
     for j, code in enumerate(valid):
-        lv = 7 + j % 6
+        lv = 7 + j % 7
         files.append(make_stream(24000 + j, lv, 16, 3 * tile_rows(lv) // 16 + 2, mix=2, single_code=code, pwr_min=15 if 3 <= code <= 16 else 4,
                                  pwr_max=15 if 3 <= code <= 16 else 12))
     check(dev, files)
@@ -172,9 +172,9 @@ from helpers import make_stream, oracle_pcm
 from libacm_amd import capi
 dev = capi.Device(0)
 bad = 0
-for level in range(7, 13):
-    assert capi.lib().acmhip_mform_group(level) == (16 if %d == 4 and level >= 8 else 8)
-    tr = capi.lib().acmhip_mform_tile_rows(level)
+for level in range(7, 14):
+    assert capi.lib().acmhip_mform_group(level) == (16 if (%d == 4 and level >= 8) or level >= 13 else 8)
+    tr = max(capi.lib().acmhip_mform_tile_rows(level), 4)
     for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
         f = make_stream(28000 + level * 100 + rows, level, rows, (5 * tr + rows - 1) // rows + 1, cut=3, pwr_min=min(4, pm), pwr_max=pm,
                         val_max=65535 if pm == 15 else 255)

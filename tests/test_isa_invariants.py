@@ -179,12 +179,12 @@ def test_parse_walk_owns_m0(tmp_path):
 
 def test_phase_priorities_are_in_the_tile_loop(kernel_asm):
     """acm_tile2 raises the wave priority for the LDS passes above the first pass (acm_kernels.hip: phase_prio): every
-    build with >= 2 workgroups per CU sets three different levels per iteration; the level-13 and level-14 builds (one
+    build with >= 2 workgroups per CU sets three different levels per iteration; the 1024-thread builds of levels 13 and 14 (one
     sixteen-wave workgroup per CU: every wave of a SIMD is in the same phase) set none"""
     n = 0
     for name, lines in tile2_bodies(kernel_asm):
         prios = [l.split()[1] for l in lines if l.strip().startswith("s_setprio")]
-        if "TileCfgILi13E" in name or "TileCfgILi14E" in name:
+        if "TileCfgILi13ELi1024E" in name or "TileCfgILi14ELi1024E" in name:
             assert prios == [], (name[:60], prios)
         else:
             assert set(prios) == {"0", "2", "3"}, (name[:60], prios)
