@@ -1816,6 +1816,9 @@ constexpr Tile2Entry entry_k2mw()
 {
 	return Tile2Entry{ acm_tile2<C, WPC * C::NT / 256, 0, true, Gs...>, C::NT, C::TR, WPC };
 }
+#ifndef ACM_K2M_L11
+#define ACM_K2M_L11 entry_k2m<TileCfg<11, 256, 8192>, 4, 3, 2, 2>(), 4
+#endif
 #ifndef ACM_K2M_L12
 #define ACM_K2M_L12 entry_k2mw<TileCfg<12, 512, 16384>, 2, 4, 3, 3, 2>(), 4
 #endif
@@ -1830,7 +1833,7 @@ const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 	{ { entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<8, 256, 8192>, 4, 2, 2>(), 4 } },
 	{ { entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(), 3 }, { entry_k2m<TileCfg<9, 256, 8192>, 4, 3, 2>(), 4 } },
 	{ { entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(), 3 }, { entry_k2m<TileCfg<10, 256, 8192>, 4, 3, 3>(), 4 } },
-	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<11, 256, 8192>, 4, 3, 2, 2>(), 4 } },
+	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { ACM_K2M_L11 } },
 	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { ACM_K2M_L12 } },
 	/* level 13: the vector-ALU build needs 128 KB tiles (its first pass re-runs two rows per segment); here the rows in front cost a second
 	 * read through L2 and nothing else, so a tile may be one row pair.  (Level 14: a row pair is 128 KB, sixteen waves of 128 registers -

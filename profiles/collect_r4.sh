@@ -1,9 +1,10 @@
 #!/bin/bash
-# After `gpurun -- 'profiles/run_profile.sh r4_level9; profiles/run_profile.sh r4_level9_packed --packed; ...'` (tags below):
+# After `gpurun -- 'profiles/run_profile.sh r4_level9; profiles/run_profile.sh r4_level9_int16 --form int16; ...'` (tags below):
 # copy the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked) and rebuild r4_traffic.json.
+# Tags without a suffix are bench.py's default staged form for their level (the byte-plane form, levels 7-13).
 set -e
 cd "$(dirname "$0")/.."
-for t in r4_level9 r4_level9_packed r4_level7 r4_level7_packed r4_level11 r4_config5; do
+for t in r4_level9 r4_level9_int16 r4_level9_packed r4_level7 r4_level7_int16 r4_level11 r4_level11_int16 r4_config5; do
   src=gpurun_out/prof_$t
   [ -d $src ] || continue
   cp $src/summary.txt profiles/${t}_summary.txt
@@ -11,6 +12,8 @@ for t in r4_level9 r4_level9_packed r4_level7 r4_level7_packed r4_level11 r4_con
   cp $src/bench_trace.json profiles/${t}_bench_profiled.json
   cp $src/bench_unprofiled.json profiles/${t}_bench.json
 done
-python3 profiles/traffic_json.py level9_1024x250blocks_rows16=profiles/r4_level9_summary.txt level9_1024x250blocks_rows16_packed=profiles/r4_level9_packed_summary.txt \
-  level7_1024x1000blocks_rows16=profiles/r4_level7_summary.txt level7_1024x1000blocks_rows16_packed=profiles/r4_level7_packed_summary.txt \
-  level11_1024x16blocks_rows64=profiles/r4_level11_summary.txt level11_65536x2blocks_rows64_ch2=profiles/r4_config5_summary.txt
+python3 profiles/traffic_json.py level9_1024x250blocks_rows16_byteplane=profiles/r4_level9_summary.txt level9_1024x250blocks_rows16=profiles/r4_level9_int16_summary.txt \
+  level9_1024x250blocks_rows16_packed=profiles/r4_level9_packed_summary.txt \
+  level7_1024x1000blocks_rows16_byteplane=profiles/r4_level7_summary.txt level7_1024x1000blocks_rows16=profiles/r4_level7_int16_summary.txt \
+  level11_1024x16blocks_rows64_byteplane=profiles/r4_level11_summary.txt level11_1024x16blocks_rows64=profiles/r4_level11_int16_summary.txt \
+  level11_65536x2blocks_rows64_ch2_byteplane=profiles/r4_config5_summary.txt
