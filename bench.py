@@ -429,6 +429,7 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
     if capi.lib().acmhip_mform_tile_rows(level) > 0:
         mf = capi.mform_streams(b.idx, b.descs, threads=workload.usable_cpus())
         d_mf = mf.upload(dev)
+        bps = round(mf.nbytes / b.samples, 3)
         mf.data = None                  # the host copy has done its job (configs[4]: 34 GB)
     plan = capi.Plan(dev, b.descs, packed=mf.streams if mf else None)
     tiles = plan.stats().tiles
@@ -461,10 +462,11 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
     out = {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "channels": channels, "steps": steps, "tiles": int(tiles)}
     int16 = timed(plan)
     if mf is not None:
-        plan.bind_mform(d_mf)
-        out.update(timed(plan), staged_form="byteplane")
+        plan.bind_mform(*d_mf)
+        out.update(timed(plan), staged_form="byteplane", staged_bytes_per_sample=bps)
         out["int16_form"] = int16
-        dev.free(d_mf)
+        for p_ in d_mf:
+            dev.free(p_)
     else:
         out.update(int16, staged_form="int16")
     plan.destroy()
@@ -577,7 +579,7 @@ def main():
         if pk:
             plan.bind_packed(*pk_ptrs)
         elif mf:
-            plan.bind_mform(d_mf)
+            plan.bind_mform(*d_mf)
     bind_headline_form()
     stats = plan.stats()
 
@@ -626,7 +628,7 @@ def main():
         if args.form != "int16":
             # the headline's own plan with nothing bound reads the int16 arena (same tiles, acm_tile2's vector-ALU build)
             plan.bind_packed(None, None)
-            plan.bind_mform(None)
+            plan.bind_mform(None, None)
             time_form("int16 index per sample", plan, {})
             bind_headline_form()
         if args.form != "byteplane" and args.workload == "uniform" and capi.lib().acmhip_mform_tile_rows(args.level) > 0:
@@ -635,10 +637,12 @@ def main():
             tm_ = time.perf_counter() - t0
             d2 = mf2.upload(dev)
             p2 = capi.Plan(dev, batch.descs, packed=mf2.streams)
-            p2.bind_mform(d2)
-            time_form("byteplane (the int16 form's bytes in matrix-core operand order)", p2, {"host_reorder_seconds": round(tm_, 2)})
+            p2.bind_mform(*d2)
+            time_form("byteplane (row pairs at 4 / 8 / 16 bits per index, in matrix-core operand order)", p2,
+                      {"host_reorder_seconds": round(tm_, 2), "staged_bytes_per_sample": round(mf2.nbytes / batch.samples, 3)})
             p2.destroy()
-            dev.free(d2)
+            for p_ in d2:
+                dev.free(p_)
             del mf2
         if args.form != "packed" and not args.no_packed and args.workload == "uniform" and capi.packed_tile_rows(args.level) > 0 and world == 1:
             t0 = time.perf_counter()
@@ -774,9 +778,12 @@ def main():
                    "staged_form": ("packed: width class per column pair and 16-row group + residuals at 0/4/8/16 bits (%.3f B/sample), "
                                    "{val, pwr} per block; written by the host stager (acmhip_pack_tiles)" % (pk.nbytes / batch.samples))
                                   if pk else
-                                  ("byteplane: the int16 index of every sample as a low and a high byte, per row in groups of 8 columns a residue "
-                                   "class apart (2 B/sample, the order the matrix cores read operands in) + {val, pwr} per block; written by the "
-                                   "host stager (acm_stage_file + acmhip_mform_rows, %.2f s for this batch)" % t_mform) if mf else
+                                  ("byteplane: every row pair's indices at the narrowest of 4 / 8 / 16 bits that holds them (%.3f B/sample here; "
+                                   "pairs at 4 / 8 / 16 bits: %d / %d / %d), per row in groups of %s columns a residue class apart (the order the "
+                                   "matrix cores read operands in) + a 4-byte entry per pair + {val, pwr} per block; written by the host stager "
+                                   "(acm_stage_file + acmhip_mform_rows, %.2f s for this batch)" % (
+                                       (mf.nbytes / batch.samples,) + tuple(int(x) for x in mf.class_counts()[1:4]) +
+                                       ("8 or 16" if args.workload == "corpus" else str(capi.lib().acmhip_mform_group(args.level)), t_mform))) if mf else
                                   "int16 index per sample + {val, pwr} per block, written by the host stager (acm_stage_file)",
                    "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

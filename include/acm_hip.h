@@ -166,8 +166,8 @@ typedef struct acmhip_packed_chunk {
 /* beside acmhip_stream_desc i: rows [0, ntiles * tile_rows) of the stream are staged in packed form as well */
 typedef struct acmhip_packed_stream {
 	uint64_t chunk_off;      /* ACMHIP_FORM_PACKED: the chunk-table entry the stream's first tile starts at (tile k: chunk_off + k * slots
-				  * of its level);  ACMHIP_FORM_BYTEPLANE: where the stream's byte-plane block (acmhip_mform_rows) starts in
-				  * the byte-plane arena, in 2-byte units */
+				  * of its level);  ACMHIP_FORM_BYTEPLANE: the pair-table entry of the pair of zeros in front of the stream
+				  * (acmhip_mform_rows) */
 	uint32_t ntiles;         /* 0: this stream has no second staged form */
 	uint32_t form;           /* ACMHIP_FORM_* */
 } acmhip_packed_stream;
@@ -199,32 +199,47 @@ int  acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream_desc *str
 int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob);
 
 /* ------------------------------------------------------------------------
- * Byte-plane staged form: the int16 form's two bytes per sample, in the order the matrix cores take them.
+ * Byte-plane staged form: the staged indices in the order the matrix cores take them, every row pair at the narrowest of
+ * 4 / 8 / 16 bits per index that holds it.
  *
- * The first three stages of the cascade (decode.c:527-590) are linear; over one residue class of the columns (columns
- * c + q * cols/8, q = 0..7) they are one banded 16 x 32 integer matrix per row pair, and a level whose lean-kernel
- * build starts with a three-stage pass (acmhip_mform_tile_rows(level) != 0) has a build that runs that matrix on
- * v_mfma_i32_16x16x32_i8 instead of the vector ALU.  Its B operand wants, per row and per residue c < cols/8, the
- * eight low bytes of the indices of columns c, c + cols/8, ... (stored minus 128, i.e. with bit 7 flipped, so that they
- * are signed bytes; the kernel adds the 128 back through the accumulator) followed by their eight high bytes:
+ * The first stages of the cascade (decode.c:527-590) are linear; over one residue class of the columns (columns
+ * c + q * cols/G, q < G, G = acmhip_mform_group(level) = 8 or 16) the first three / four of them are one banded integer
+ * matrix per row pair, and a level whose lean-kernel build starts that way (acmhip_mform_tile_rows(level) != 0) has a
+ * build that runs the matrix on v_mfma_i32_16x16x32_i8 / 16x16x64_i8 instead of the vector ALU: its operands are the
+ * staged indices themselves (the multiply by the block's val moves behind the matrix), as bytes.  A block's indices lie
+ * in [-2^pwr, 2^pwr) (decode.c:592-600: the amplitude table has 2^(pwr+1) entries), so quiet blocks need fewer bits:
  *
- *   block of a stream = 2 rows of zeros (what the cascade sees in front of row 0), then its rows;
- *   row               = cols/8 residues x 16 bytes: lo(c), lo(c + cols/8), ... lo(c + 7 cols/8), hi(c), ... hi(c + 7 cols/8)
- *                       with lo(x) = (idx[x] & 0xff) ^ 0x80, hi(x) = idx[x] >> 8
+ *   stream -> a pair of zero rows (what the cascade sees in front of row 0), then its row pairs (rows 2P, 2P + 1), each at
+ *             its own width class; acmhip_mform_pair k of the stream = where pair k - 1 starts (16-byte units from the
+ *             arena's base) << 2 | class;
+ *   pair   -> its two rows, each row = cols/G residues c, each residue = the G indices of columns c, c + cols/G, ...:
+ *             ACMHIP_BP_WORD    G low bytes ((idx & 0xff) ^ 0x80: signed bytes, the kernel adds the 128 back through the
+ *                               accumulator), then G high bytes (idx >> 8)
+ *             ACMHIP_BP_BYTE    G bytes (idx itself; every index of the pair in [-128, 127])
+ *             ACMHIP_BP_NIBBLE  G / 2 bytes (every index in [-8, 7]): per dword eight indices plus 8 each, index 8 j + i in
+ *                               nibble 2 i, index 8 j + 4 + i in nibble 2 i + 1 (i < 4)
  *
- * Same size as the int16 form (plus the two rows), same tiles, same records; only whole tiles are staged this way, the
- * ragged tail of a stream stays int16 (as with the packed form).
+ * Only whole tiles are staged this way, the ragged tail of a stream stays int16 (as with the packed form).
  * ---------------------------------------------------------------------- */
+typedef uint32_t acmhip_mform_pair;
+#define ACMHIP_BP_NIBBLE 1u
+#define ACMHIP_BP_BYTE   2u
+#define ACMHIP_BP_WORD   3u
 int  acmhip_mform_tile_rows(uint32_t level);     /* rows per tile of the matrix-core build, 0 if the level has none */
 int  acmhip_mform_group(uint32_t level);         /* columns of a residue class kept side by side: 8 (a three-stage first pass) or 16 (four) */
-/* bytes of a block holding nrows rows (incl. the two rows of zeros in front) */
-uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);
-/* host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them) -> out[acmhip_mform_bytes(level, nrows)] */
-int  acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out);
-/* the inverse, for tests and tools */
-int  acmhip_mform_unrows(uint32_t level, const uint8_t *block, uint64_t nrows, int16_t *idx);
-/* device arena the byte-plane tiles of this plan are read from by every later launch (NULL: back to the int16 form) */
-int  acmhip_plan_bind_mform(acmhip_plan *plan, const uint8_t *d_mform);
+uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);     /* upper bound of the bytes nrows rows take (incl. the pair in front and read slack) */
+uint64_t acmhip_mform_pairs(uint64_t nrows);                     /* pair-table entries of nrows rows: nrows / 2 + 1 */
+/*
+ * Host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them; nrows even) -> out[0 .. *bytes_used) and
+ * pairs[0 .. nrows / 2].  blob_base: where out[0] will sit in the batch's arena (bytes, multiple of 16, < 16 GB); the
+ * offsets written are absolute.
+ */
+int  acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,
+		       uint64_t *bytes_used);
+/* the inverse, for tests and tools (blob = the arena's base) */
+int  acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const acmhip_mform_pair *pairs, uint64_t nrows, int16_t *idx);
+/* device arena and pair table the byte-plane tiles of this plan are read from by every later launch (both NULL: back to the int16 form) */
+int  acmhip_plan_bind_mform(acmhip_plan *plan, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs);
 
 /* introspection for benchmarks/tests */
 typedef struct acmhip_plan_stats {

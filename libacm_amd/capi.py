@@ -86,7 +86,7 @@ ACMHIP_SYMBOLS = [
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
-    "acmhip_mform_tile_rows", "acmhip_mform_group", "acmhip_mform_bytes", "acmhip_mform_rows", "acmhip_mform_unrows", "acmhip_plan_bind_mform",
+    "acmhip_mform_tile_rows", "acmhip_mform_group", "acmhip_mform_bytes", "acmhip_mform_pairs", "acmhip_mform_rows", "acmhip_mform_unrows", "acmhip_plan_bind_mform",
 ]
 # the 19 entry points of include/libacm.h (reference src/libacm.h:120-170)
 LIBACM_SYMBOLS = [
@@ -156,9 +156,11 @@ def lib():
     L.acmhip_mform_group.argtypes = [C.c_uint32]
     L.acmhip_mform_bytes.argtypes = [C.c_uint32, C.c_uint64]
     L.acmhip_mform_bytes.restype = C.c_uint64
-    L.acmhip_mform_rows.argtypes = [C.c_uint32, vp, C.c_uint64, vp]
-    L.acmhip_mform_unrows.argtypes = [C.c_uint32, vp, C.c_uint64, vp]
-    L.acmhip_plan_bind_mform.argtypes = [vp, vp]
+    L.acmhip_mform_pairs.argtypes = [C.c_uint64]
+    L.acmhip_mform_pairs.restype = C.c_uint64
+    L.acmhip_mform_rows.argtypes = [C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+    L.acmhip_mform_unrows.argtypes = [C.c_uint32, vp, vp, C.c_uint64, vp]
+    L.acmhip_plan_bind_mform.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -268,21 +270,29 @@ class PackedArena:
 
 
 class MformArena:
-    """The byte-plane staged form (acmhip_mform_rows) of several streams in one host array (.data, uint8) and .streams
-    (PackedStream with form = FORM_BYTEPLANE beside each stream descriptor)."""
+    """The byte-plane staged form (acmhip_mform_rows) of several streams: .data (uint8 arena), .pairs (uint32 pair table: offset in
+    16-byte units << 2 | width class) and .streams (PackedStream with form = FORM_BYTEPLANE beside each stream descriptor)."""
 
-    def __init__(self, data, streams):
-        self.data, self.streams = data, streams
+    def __init__(self, data, pairs, streams):
+        self.data, self.pairs, self.streams = data, pairs, streams
 
     def upload(self, dev):
-        p = dev.malloc(max(self.data.nbytes, 16))
-        for o in range(0, self.data.size, 1 << 28):
-            dev.upload(p + o, self.data[o:o + (1 << 28)])
-        return p
+        ptrs = []
+        for a in (self.data, self.pairs):
+            p = dev.malloc(max(a.nbytes, 16))
+            flat = a.view(np.uint8).reshape(-1)
+            for o in range(0, flat.size, 1 << 28):
+                dev.upload(p + o, flat[o:o + (1 << 28)])
+            ptrs.append(p)
+        return tuple(ptrs)
 
     @property
     def nbytes(self):
-        return self.data.nbytes
+        return self.data.nbytes + self.pairs.nbytes
+
+    def class_counts(self):
+        """row pairs per width class (index 1: 4 bits, 2: 8 bits, 3: 16 bits per index)"""
+        return np.bincount(self.pairs & 3, minlength=4)
 
 
 def mform_streams(idx, descs, threads=1):
@@ -291,30 +301,51 @@ def mform_streams(idx, descs, threads=1):
     from concurrent.futures import ThreadPoolExecutor
     L = lib()
     n = len(descs)
-    ntiles, off, rows = [0] * n, [0] * n, [0] * n
-    at = 0
+    ntiles, rows, cap, p_at = [0] * n, [0] * n, [0] * n, [0] * n
+    np_tot = 0
     for i, d in enumerate(descs):
         tr = L.acmhip_mform_tile_rows(d.level)
         if tr > 0 and d.row_begin == 0:
             ntiles[i] = min(d.nrows, d.n_emit >> d.level) // tr
             rows[i] = ntiles[i] * tr
-        off[i] = at
+        p_at[i] = np_tot
         if ntiles[i]:
-            at += (L.acmhip_mform_bytes(d.level, rows[i]) + 255) // 256 * 256
-    data = np.zeros(max(at, 16), dtype=np.uint8)
+            cap[i] = (L.acmhip_mform_bytes(d.level, rows[i]) + 255) // 256 * 256
+            np_tot += L.acmhip_mform_pairs(rows[i])
+    pairs = np.zeros(np_tot + 32, dtype=np.uint32)             # (the kernel's scalar loads fetch whole groups of entries)
+    parts = [None] * n
 
     def one(i):
         if ntiles[i]:
             d = descs[i]
-            _check(L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], data[off[i]:].ctypes.data), "acmhip_mform_rows")
+            buf = np.empty(cap[i], dtype=np.uint8)
+            used = C.c_uint64()
+            _check(L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], buf.ctypes.data, 0, pairs[p_at[i]:].ctypes.data,
+                                       C.byref(used)), "acmhip_mform_rows")
+            parts[i] = buf[:(used.value + 15) // 16 * 16]
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
         list(ex.map(one, range(n)))
-    return MformArena(data, [PackedStream(off[i] // 2, ntiles[i], FORM_BYTEPLANE) for i in range(n)])
+    at = 0
+    for i in range(n):
+        if parts[i] is not None:
+            k = int(L.acmhip_mform_pairs(rows[i]))
+            pairs[p_at[i]:p_at[i] + k] += np.uint32((at // 16) << 2)        # offsets were written relative to the stream's own block
+            at += parts[i].size
+    if (at >> 4) >= 1 << 30:
+        raise AcmHipError("byte-plane arena beyond 16 GB")
+    data = np.empty(max(at, 16) + 64, dtype=np.uint8)
+    at = 0
+    for i in range(n):
+        if parts[i] is not None:
+            data[at:at + parts[i].size] = parts[i]
+            at += parts[i].size
+    data[at:] = 0
+    return MformArena(data, pairs, [PackedStream(p_at[i], ntiles[i], FORM_BYTEPLANE) for i in range(n)])
 
 
-def mform_unrows(level, block, nrows):
+def mform_unrows(level, blob, pairs, nrows):
     out = np.zeros(nrows << level, dtype=np.int16)
-    _check(lib().acmhip_mform_unrows(level, block.ctypes.data, nrows, out.ctypes.data), "acmhip_mform_unrows")
+    _check(lib().acmhip_mform_unrows(level, blob.ctypes.data, pairs.ctypes.data, nrows, out.ctypes.data), "acmhip_mform_unrows")
     return out
 
 
@@ -442,9 +473,9 @@ class Plan:
         """device tables of the packed staged form for every later launch (both None: back to the int16 arena)"""
         _check(lib().acmhip_plan_bind_packed(self.h, d_chunks, d_blob), "acmhip_plan_bind_packed")
 
-    def bind_mform(self, d_mform):
-        """device arena of the byte-plane staged form for every later launch (None: back to the int16 arena)"""
-        _check(lib().acmhip_plan_bind_mform(self.h, d_mform), "acmhip_plan_bind_mform")
+    def bind_mform(self, d_mform, d_pairs):
+        """device arena and pair table of the byte-plane staged form for every later launch (both None: back to the int16 arena)"""
+        _check(lib().acmhip_plan_bind_mform(self.h, d_mform, d_pairs), "acmhip_plan_bind_mform")
 
     def launch(self, d_idx, d_hdr, d_pcm, fmt=FMT_S16LE):
         _check(lib().acmhip_plan_launch(self.h, d_idx, d_hdr, d_pcm, fmt), "acmhip_plan_launch")
@@ -535,10 +566,10 @@ def synth(dev, staged_list, fmt=FMT_S16LE, flags=PLAN_AUTO, windows=None, return
             pk = mform_streams(ar.idx, ar.descs)
             for i in patched:
                 pk.streams[i].ntiles = 0
-            pk_ptrs = (pk.upload(dev),)
+            pk_ptrs = pk.upload(dev)
         plan = Plan(dev, ar.descs, ar.patches, flags, packed=pk.streams if pk else None)
         if pk and mform:
-            plan.bind_mform(pk_ptrs[0])
+            plan.bind_mform(*pk_ptrs)
         elif pk:
             plan.bind_packed(*pk_ptrs)
         plan.launch(d_idx, d_hdr, d_pcm, fmt)

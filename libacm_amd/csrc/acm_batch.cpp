@@ -165,7 +165,8 @@ struct Slot {
 	uint32_t pk_ntiles = 0;
 	/* ACM_BATCH_STAGE_BYTEPLANE: where the stream's byte-plane block sits in the blob arena (bytes) and how many rows it may hold;
 	 * pk_ntiles = the whole tiles the pool staged that way */
-	uint64_t mf_off = 0, mf_rows_cap = 0;
+	uint64_t mf_off = 0, mf_rows_cap = 0, mf_used = 0;
+	uint64_t mf_pair_off = 0;       /* its first entry in the pair table */
 };
 
 /* Blocks a file can possibly hold: the header promises total_values, but arenas are sized by this - a block costs at
@@ -495,7 +496,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * rows plus the two rows of zeros in front */
 	bool stage_mform = (opts.flags & ACM_BATCH_STAGE_BYTEPLANE) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
 			   !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
-	uint64_t mf_total = 0;
+	uint64_t mf_total = 0, mf_pairs_total = 0;
 	if (stage_mform) {
 		stage_packed = false;           /* one second form per batch */
 		for (size_t c = 0; c < chunks.size(); c++) {
@@ -505,8 +506,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				if (!s.ok || acmhip_mform_tile_rows(s.info.level) <= 0)
 					continue;
 				s.mf_off = mf_total;
-				s.mf_rows_cap = s.need_blocks * s.info.rows;
+				s.mf_rows_cap = (s.need_blocks * s.info.rows) & ~1ull;
+				s.mf_pair_off = mf_pairs_total;
 				mf_total += (acmhip_mform_bytes(s.info.level, s.mf_rows_cap) + 255) & ~255ull;
+				mf_pairs_total += acmhip_mform_pairs(s.mf_rows_cap);
 			}
 			chunks[c].mf_end = mf_total;
 		}
@@ -660,9 +663,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	} else {
 		stage_packed = false;
 	}
-	if (stage_mform && mf_total) {
+	if (stage_mform && mf_total && (mf_total >> 4) < (1ull << 30)) {         /* (the pair table counts 16-byte units in 30 bits) */
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKBLOB, mf_total, (void **)&h_pkblob));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKBLOB, mf_total, (void **)&d_pkblob));
+		/* (+ 32 entries: the kernel's scalar loads fetch whole groups) */
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKCHUNK, (mf_pairs_total + 32) * sizeof(acmhip_mform_pair), (void **)&h_pkchunk));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKCHUNK, (mf_pairs_total + 32) * sizeof(acmhip_mform_pair), (void **)&d_pkchunk));
 	} else {
 		stage_mform = false;
 	}
@@ -756,7 +762,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		const uint64_t ntiles = full_rows / (uint64_t)tr;
 		if (ntiles == 0 || ntiles * (uint64_t)tr > s.mf_rows_cap)
 			return;
-		if (acmhip_mform_rows(s.info.level, h_idx + s.idx_off, ntiles * (uint64_t)tr, h_pkblob + s.mf_off) != ACMHIP_OK)
+		if (acmhip_mform_rows(s.info.level, h_idx + s.idx_off, ntiles * (uint64_t)tr, h_pkblob + s.mf_off, s.mf_off,
+				      reinterpret_cast<acmhip_mform_pair *>(h_pkchunk) + s.mf_pair_off, &s.mf_used) != ACMHIP_OK)
 			return;
 		s.pk_ntiles = (uint32_t)ntiles;
 	};
@@ -985,7 +992,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			if (!s.ok || items[i].words == 0)
 				continue;
 			if (stage_mform)
-				packed.push_back(acmhip_packed_stream{ s.mf_off / 2, s.pk_ntiles, ACMHIP_FORM_BYTEPLANE });
+				packed.push_back(acmhip_packed_stream{ s.mf_pair_off, s.pk_ntiles, ACMHIP_FORM_BYTEPLANE });
 			else
 				packed.push_back(acmhip_packed_stream{ s.pk_chunk_off, s.pk_ntiles, ACMHIP_FORM_PACKED });
 			acmhip_stream_desc d{};
@@ -1015,7 +1022,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		if (r == ACMHIP_OK)
-			r = stage_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob) : acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
+			r = stage_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk))
+					: acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
 		return r;
 	};
 	/* chunks made of device-parsed streams only: their plans are cut NOW, from what the headers promise (a stream the
@@ -1238,9 +1246,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						const Slot &s = slots[i];
 						if (!s.ok || !s.pk_ntiles)
 							continue;
-						const uint64_t bytes = acmhip_mform_bytes(s.info.level, (uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level));
-						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, bytes, hipMemcpyHostToDevice, st_main));
-						tm.h2d_bytes += bytes;
+						const uint64_t npairs = acmhip_mform_pairs((uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level));
+						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, s.mf_used, hipMemcpyHostToDevice, st_main));
+						HTRY(hipMemcpyAsync(reinterpret_cast<acmhip_mform_pair *>(d_pkchunk) + s.mf_pair_off,
+								    reinterpret_cast<acmhip_mform_pair *>(h_pkchunk) + s.mf_pair_off, npairs * sizeof(acmhip_mform_pair),
+								    hipMemcpyHostToDevice, st_main));
+						tm.h2d_bytes += s.mf_used + npairs * sizeof(acmhip_mform_pair);
 					}
 					tm.h2d_bytes += (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
 				} else {

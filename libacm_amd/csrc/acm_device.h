@@ -133,11 +133,11 @@ int acmk_tile2p_waves(uint32_t level);
 int acmk_tile2p_pad_shift(uint32_t level);                      /* the tile's LDS rows carry one pad dword per 2^shift elements */
 int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob,
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
-/* the byte-plane staged form: the same tile records as acm_tile2 (idx_off counts staged samples = two bytes each in either form) */
+/* the byte-plane staged form: the same tile records as acm_tile2 except that idx_off is the pair-table entry of the row pair in front of the tile */
 int acmk_tile2m_rows(uint32_t level);                           /* = acmk_tile2_rows, 0 if the level has no such build */
 int acmk_tile2m_stages(uint32_t level);                         /* stages of its first pass (3 or 4): the form keeps 2^stages columns of a residue class side by side */
-int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_blkhdr *d_hdr,
-		       int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
+int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs,
+		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 int acmk_launch_unpack(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,
 		       const int16_t *d_idx, const acmhip_blkhdr *d_hdr, int32_t *d_x, uint32_t shift, void *stream);
 int acmk_launch_prefix(const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_elems,

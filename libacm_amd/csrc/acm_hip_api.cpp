@@ -108,6 +108,7 @@ struct acmhip_plan {
 	const acmhip_packed_chunk *pk_chunks = nullptr; /* acmhip_plan_bind_packed: device tables of the packed staged form */
 	const uint8_t *pk_blob = nullptr;
 	const uint8_t *mform = nullptr;                 /* acmhip_plan_bind_mform */
+	const acmhip_mform_pair *mform_pairs = nullptr;
 	int variant = 0;                        /* fused-kernel variant the tile tables were cut for */
 	/* several tile-kernel groups (a corpus of mixed levels): their launches are independent, so they go round robin
 	 * over the device stream and two side streams - the ramp-up and the tail of one launch overlap the next one's
@@ -524,10 +525,10 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
 								     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
 								     r == 0 ? ACM_TILE_FRESH : 0u });
-			/* the byte-plane block holds the same rows at the same spacing, two rows of zeros in front */
+			/* a byte-plane tile is named by the pair-table entry of the row pair in front of it (entry 0 of a stream: the pair of zeros) */
 			for (uint64_t rm = r; mf && rm < r + T2; rm += T2M) {
 				const uint64_t rhm = rm >= 2 ? rm - 2 : 0;
-				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + ((rm + 2) << s.level), s.pcm_off + (rm << s.level),
+				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + rm / 2, s.pcm_off + (rm << s.level),
 								     (uint32_t)(s.hdr_off + rhm / s.rows), (uint32_t)(rhm % s.rows), magic,
 								     rm == 0 ? ACM_TILE_FRESH : 0u });
 			}
@@ -943,7 +944,7 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		else
 			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		if (pl->mform)
-			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, d_hdr, d_pcm, pl->d_sink, fmt, gs));
+			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, pl->mform_pairs, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		else
 			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m_plain, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
@@ -1005,11 +1006,16 @@ extern "C" int acmhip_plan_bind_packed(acmhip_plan *pl, const acmhip_packed_chun
 	return ACMHIP_OK;
 }
 
-extern "C" int acmhip_plan_bind_mform(acmhip_plan *pl, const uint8_t *d_mform)
+extern "C" int acmhip_plan_bind_mform(acmhip_plan *pl, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs)
 {
 	if (!pl)
 		return ACMHIP_ERR_ARG;
+	if ((d_mform == nullptr) != (d_pairs == nullptr)) {
+		set_err("acmhip_plan_bind_mform: the arena and its pair table, or neither");
+		return ACMHIP_ERR_ARG;
+	}
 	pl->mform = d_mform;
+	pl->mform_pairs = d_pairs;
 	return ACMHIP_OK;
 }
 

@@ -1218,6 +1218,13 @@ const FusedEntry g_fused[NVARIANTS][ACM_K1_MAX_LEVEL - ACM_K1_MIN_LEVEL + 1] = {
  * waves per SIMD), so the tile loop is written for instruction count: 32 KB tiles at four workgroups per CU, all
  * per-tile scalars in one 32-byte record, no clamping, no selects, one address register for all staged-index loads.
  */
+/* a wave-uniform address as an SGPR pair (readfirstlane says so to the compiler): the base operand of the hand-issued loads */
+__device__ __forceinline__ const uint8_t *sgpr_u64(const uint64_t a)
+{
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+	return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
+}
+
 template <class C, int G, int W, int ABL = 0>
 struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segment, the first one included, re-runs the two rows in front of it */
 	using FP = FirstPass<C, G, W, ABL, true>;
@@ -1263,10 +1270,17 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 		load(raw.r, base, voff, voff_warm);
 	}
 	struct Tables { };
+	struct Desc { };
+	static __device__ __forceinline__ Desc fetch_desc(const uint32_t *, const AcmTile2 &, const int) { return Desc{}; }
+	/* base = staged index of (tile row -2, column 0) */
+	static __device__ __forceinline__ void issue(Raw &raw, const int16_t *idx, const AcmTile2 &r, const Desc &, const int, const uint32_t voff, const uint32_t voff_warm)
+	{
+		load(raw, sgpr_u64(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS)), voff, voff_warm);
+	}
 	static constexpr bool SIGNED_ROWVAL = true;              /* odd tile rows carry -val when stage 0 is an N stage; rows in front of a stream weigh 0 */
 	static __device__ __forceinline__ bool fresh_lane(const int tid) { return tid < FP::TPS; }      /* lanes whose two rows in front are missing in a stream's first tile */
 	static __device__ __forceinline__ void fill_tables(Tables &, const int) { }
-	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &)
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &, const Desc &)
 	{
 		FP::template compute<true>(raw.r, tile, rowval, fresh_stream ? 0 : 2, tid);
 	}
@@ -1317,21 +1331,25 @@ struct FirstPassM {
 	static constexpr int NW = NT / 64;
 	static constexpr int NUNIT = (TR / 2) * NGRP;
 	static constexpr int NU = NUNIT / NW;                   /* units per wave and tile */
-	static constexpr int VPU = 2 * LB / 16;                 /* 16-byte loads per unit and lane: low bytes, high bytes (G = 3: both in one) */
+	static constexpr int VPU = 2 * LB / 16;                 /* 16-byte loads per unit and lane at 16 bits per index: low bytes, high bytes (G = 3: both in one) */
 	static constexpr int NRAW = NU * VPU * 4;
 	static_assert(SIGMA % 16 == 0 && NU * NW == NUNIT && NU >= 1, "whole units per wave");
 	/* a wave's units are consecutive in (row pair, group) order: several pairs per wave, or several waves per pair */
 	static constexpr bool MANYG = NGRP > NU;
 	static_assert(MANYG ? NGRP % NU == 0 : NU % NGRP == 0, "units of a wave are whole row pairs, or a whole fraction of one");
 	static constexpr int WPP = MANYG ? NGRP / NU : 1;       /* waves per row pair */
-	static constexpr int ROWB = COLS * 2;                   /* staged bytes per row */
-	static constexpr int RESB = 2 * QN;                     /* staged bytes per row and residue */
+	static constexpr int UPP = MANYG ? NU : NGRP;           /* units of one row pair in a wave */
+	static constexpr int NPW = NU / UPP;                    /* row pairs per wave */
+	static constexpr int ROWB_W = COLS * 2;                 /* staged bytes per row at 16 bits per index (class 3); class c: >> (3 - c) */
+	static constexpr int RESB_W = 2 * QN;                   /* ... per row and residue */
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
 	static constexpr bool SIGNED_ROWVAL = false;            /* rowval = val << SHIFT for every row; rows in front of a stream repeat row 0's */
 	using T = MfmaTables<G>;
 	typedef std::conditional_t<G == 3, uint64_t, v4i_t> Operand;
 
 	struct Raw { v4u_t r[NU * VPU]; };
+	/* pair-table entries (include/acm_hip.h: offset in 16-byte units << 2 | width class) of the wave's row pairs and of the pair in front of them */
+	struct Desc { uint32_t e[NPW + 1]; };
 	/* per-lane operands that never change, parked in LDS between tiles (registers are what the LDS passes are short of) */
 	struct Tables {
 		Operand a[NM][64];          /* lane's coefficients for output tile mt: output 16 mt + l%16, inputs of row l/16 */
@@ -1341,35 +1359,82 @@ struct FirstPassM {
 		v4i_t bias[2][NM][5];       /* [rows in front missing][mt][rs, 4 = lanes that do not own residue 0]: the "+1" response, scaled */
 	};
 
+	/* f(width class as a compile-time constant): one wave-uniform three-way branch, straight-line code behind it */
+	template <class F>
+	static __device__ __forceinline__ void by_class(const uint32_t cls, F &&f)
+	{
+		if (cls == ACMHIP_BP_WORD)
+			f(std::integral_constant<uint32_t, ACMHIP_BP_WORD>{});
+		else if (cls == ACMHIP_BP_BYTE)
+			f(std::integral_constant<uint32_t, ACMHIP_BP_BYTE>{});
+		else
+			f(std::integral_constant<uint32_t, ACMHIP_BP_NIBBLE>{});
+	}
+
 	static constexpr int pair_of(int k) { return MANYG ? 0 : k / NGRP; }                    /* relative to the wave's first row pair */
 	static constexpr int grp_of(int k) { return MANYG ? k : k % NGRP; }                     /* relative to the wave's first group */
 	static __device__ __forceinline__ int pair0(const int tid) { return MANYG ? (tid >> 6) / WPP : (tid >> 6) * (NU / (MANYG ? 1 : NGRP)); }
 	static __device__ __forceinline__ int grp0(const int tid) { return MANYG ? ((tid >> 6) % WPP) * NU : 0; }
-
-	/* byte offset of this lane's first staged bytes relative to tile row -2 */
 	static __device__ __forceinline__ uint32_t lane_offset(const int tid)
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
-		return (uint32_t)((2 * pair0(tid) + rs) * ROWB + (grp0(tid) * 16 + n) * RESB);
+		return (uint32_t)(rs * ROWB_W + (grp0(tid) * 16 + n) * RESB_W);
 	}
-	/* the two rows in front of a stream exist in this form (two rows of zeros, written by the stager): no lane reads anywhere else */
-	static __device__ __forceinline__ bool fresh_lane(const int) { return false; }
-	template <int K>
-	static __device__ __forceinline__ void load_one(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t)
+	static __device__ __forceinline__ bool fresh_lane(const int) { return false; }         /* the pair in front of a stream exists in this form: zeros */
+
+	/* through the scalar cache: the tile's entry (the pair in front of it) + the wave's first pair are wave-uniform */
+	static __device__ __forceinline__ Desc fetch_desc(const uint32_t *__restrict__ pairs, const AcmTile2 &r, const int tid)
 	{
-		constexpr int unit = K / VPU, part = K % VPU;
-		constexpr int off = pair_of(unit) * 2 * ROWB + grp_of(unit) * 16 * RESB + part * 16;
-		static_assert(off < 4096, "12-bit immediate");
-		asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(raw.r[K]) : "v"(voff), "s"(base), "n"(off) : "memory");
+		Desc d;
+		const uint32_t at = __builtin_amdgcn_readfirstlane((uint32_t)r.idx_off + (uint32_t)pair0(tid));    /* (a table of < 2^32 entries) */
+#pragma unroll
+		for (int j = 0; j <= NPW; j++)
+			d.e[j] = pairs[at + j];
+		return d;
 	}
-	template <int... Ks>
-	static __device__ __forceinline__ void load_all(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm, std::integer_sequence<int, Ks...>)
+
+	/* the loads of one tile: per unit, lanes 0-31 ask for the rows of the pair in front, lanes 32-63 for the pair's own, each at the
+	 * width its pair is stored at (16 bytes are asked for whatever the class: what lies behind a narrow residue's bytes is its neighbour's) */
+	template <int PP, int... Js>
+	static __device__ __forceinline__ void issue_pair(Raw &raw, const uint8_t *arena, const Desc &d, const int tid, const uint32_t lane16, std::integer_sequence<int, Js...>)
 	{
-		(load_one<Ks>(raw, base, voff, voff_warm), ...);
+		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
+		const uint32_t ef = d.e[PP], ec = d.e[PP + 1];
+		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(ef >> 2) << 4));
+		/* the offsets differ, the loads do not: one sequence of them, whatever the widths (a load inside a branch would also hide from
+		 * tests/test_isa_invariants.py which registers are in flight) */
+		uint32_t lane_part, ustride;
+		if ((ef & 3u) == (ec & 3u)) {
+			/* both pairs at one width (the usual case): the pair's own rows follow the rows in front at a fixed distance, every lane's
+			 * offset is the 16-bit one shifted */
+			const uint32_t sh = 3u - (ec & 3u);
+			lane_part = lane16 >> sh;
+			ustride = (uint32_t)(16 * RESB_W) >> sh;
+		} else {
+			const uint32_t delta = ((ec >> 2) - (ef >> 2)) << 4;
+			const bool front = rs < 2;
+			const uint32_t sh = front ? 3u - (ef & 3u) : 3u - (ec & 3u);
+			lane_part = ((uint32_t)((rs & 1) * ROWB_W + (grp0(tid) * 16 + n) * RESB_W) >> sh) + (front ? 0u : delta);
+			ustride = (uint32_t)(16 * RESB_W) >> sh;
+		}
+		auto one = [&](auto jj) {
+			constexpr int k = PP * UPP + decltype(jj)::value;
+			const uint32_t voff = lane_part + (uint32_t)grp_of(k) * ustride;
+			asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.r[k * VPU]) : "v"(voff), "s"(base) : "memory");
+			if constexpr (VPU == 2)
+				asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(raw.r[k * VPU + 1]) : "v"(voff), "s"(base) : "memory");
+		};
+		(one(std::integral_constant<int, Js>{}), ...);
 	}
-	static __device__ __forceinline__ void load(Raw &raw, const uint8_t *base, const uint32_t voff, const uint32_t voff_warm)
+	template <int... PPs>
+	static __device__ __forceinline__ void issue_pairs(Raw &raw, const uint8_t *arena, const Desc &d, const int tid, const uint32_t lane16, std::integer_sequence<int, PPs...>)
 	{
-		load_all(raw, base, voff, voff_warm, std::make_integer_sequence<int, NU * VPU>{});
+		(issue_pair<PPs>(raw, arena, d, tid, lane16, std::make_integer_sequence<int, UPP>{}), ...);
+	}
+	/* lane16 = lane_offset(tid): the lane's byte offset inside a unit's four rows when all of them are at 16 bits */
+	static __device__ __forceinline__ void issue(Raw &raw, const int16_t *idx, const AcmTile2 &, const Desc &d, const int tid, const uint32_t lane16, const uint32_t)
+	{
+		issue_pairs(raw, reinterpret_cast<const uint8_t *>(idx), d, tid, lane16, std::make_integer_sequence<int, NPW>{});
 	}
 
 	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid)
@@ -1434,6 +1499,19 @@ struct FirstPassM {
 			    : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "s"(val));
 		y = v4i_t{ y0, y1, y2, y3 };
 	}
+	/* the matrix core's result moved through the vector ALU once: an asm statement (scale4) must not read the matrix core's registers
+	 * directly - the compiler places the wait states those need in front of instructions it knows, not in front of asm.  The zero it adds
+	 * is one the compiler cannot see through. */
+	static __device__ __forceinline__ v4i_t settle(const v4i_t d)
+	{
+		uint32_t z;
+		asm("v_mov_b32 %0, 0" : "=v"(z));
+		v4i_t c;
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			c[i] = (int32_t)((uint32_t)d[i] + z);
+		return c;
+	}
 	/* low-byte and high-byte products of one unit -> index-weighted sums */
 	static __device__ __forceinline__ v4i_t join(const v4i_t d, const v4i_t e)
 	{
@@ -1450,69 +1528,101 @@ struct FirstPassM {
 		else
 			return keep ? a : v4i_t{ 0, 0, 0, 0 };
 	}
+	/* the matrix operand of unit k for rows stored at width class CLS: the low plane (CLS 3: low bytes minus 128; 2: the indices; 1: the
+	 * nibbles, i.e. indices plus 8) and, for CLS 3, the high plane */
+	static __device__ __forceinline__ Operand plane_lo(const Raw &raw, const int k, const uint32_t cls)
+	{
+		constexpr uint32_t M = 0x0f0f0f0fu;
+		if constexpr (G == 3) {
+			const v4u_t r = raw.r[k];
+			if (cls == ACMHIP_BP_NIBBLE)
+				return ((uint64_t)((r.x >> 4) & M) << 32) | (r.x & M);
+			return ((uint64_t)r.y << 32) | r.x;
+		} else {
+			const v4u_t r = raw.r[2 * k];
+			if (cls == ACMHIP_BP_NIBBLE)
+				return v4i_t{ (int)(r.x & M), (int)((r.x >> 4) & M), (int)(r.y & M), (int)((r.y >> 4) & M) };
+			return (v4i_t)r;
+		}
+	}
+	static __device__ __forceinline__ Operand plane_hi(const Raw &raw, const int k)
+	{
+		if constexpr (G == 3)
+			return ((uint64_t)raw.r[k].w << 32) | raw.r[k].z;
+		else
+			return (v4i_t)raw.r[2 * k + 1];
+	}
+	/* what the accumulator must start from for rows of class cls, given what it starts from at 16 bits (128 x the coefficient sums: the low
+	 * bytes are stored minus 128): nothing at 8 bits, -8 x the sums at 4 bits (stored plus 8) */
+	static __device__ __forceinline__ v4i_t k_of(const uint32_t cls, const v4i_t k16)
+	{
+		if (cls == ACMHIP_BP_WORD)
+			return k16;
+		if (cls == ACMHIP_BP_BYTE)
+			return v4i_t{ 0, 0, 0, 0 };
+		return v4i_t{ -(k16[0] >> 4), -(k16[1] >> 4), -(k16[2] >> 4), -(k16[3] >> 4) };
+	}
 
-	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put two rows of zeros there) */
-	static constexpr int UPP = MANYG ? NU : NGRP;           /* units of one row pair in a wave */
-	static constexpr int NPW = NU / UPP;                    /* row pairs per wave */
+	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put a pair of zeros there) */
 	template <int PP, int... Js>
 	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int lane,
-							const bool owns0, const Tables &t, std::integer_sequence<int, Js...>)
+							const bool owns0, const Tables &t, const uint32_t clsF, const uint32_t clsC, std::integer_sequence<int, Js...>)
 	{
 		constexpr int PS = C::PS;
 		const int rs = lane >> 4;
 		const v4i_t zero = { 0, 0, 0, 0 };
 		const int32_t va = __builtin_amdgcn_readfirstlane(rv[0]), vb = __builtin_amdgcn_readfirstlane(rv[1]);      /* rows 2P-2, 2P-1 */
 		const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]), vd = __builtin_amdgcn_readfirstlane(rv[3]);      /* rows 2P, 2P+1 */
-		auto lo = [&](int k) -> Operand {
-			if constexpr (G == 3)
-				return ((uint64_t)raw.r[k].y << 32) | raw.r[k].x;
-			else
-				return (v4i_t)raw.r[2 * k];
-		};
-		auto hi = [&](int k) -> Operand {
-			if constexpr (G == 3)
-				return ((uint64_t)raw.r[k].w << 32) | raw.r[k].z;
-			else
-				return (v4i_t)raw.r[2 * k + 1];
-		};
 		/* the "+1" only reaches the lane that owns residue 0, in the unit of group 0 (the pair's first unit, if this wave has it) */
 		auto bias = [&](int mt) { return t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4]; };
 		/* output 16 mt + 4 rs + i of the unit: row (16 mt + 4 rs) / QN of the pair, column q = (16 mt + 4 rs) % QN + i of the residue */
 		auto store = [&](int k, int mt, const v4i_t y) {
-			constexpr int per_row = QN / 16;                        /* output tiles per row of the pair: 1 (G = 4), a half (G = 3: one tile = both rows) */
+			constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;      /* output tiles per row of the pair: 1 (G = 4); G = 3: one tile = both rows */
 			uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
-			if (per_row >= 1)
-				o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % (per_row > 0 ? per_row : 1)) * 16 * SIGMA + (((mt % (per_row > 0 ? per_row : 1)) * 16 * SIGMA) >> PS));
+			if (QN >= 16)
+				o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
 #pragma unroll
 			for (int i = 0; i < 4; i++)
 				o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
 		};
-		if (va == vb && vb == vc && vc == vd) {
-			/* one val over all four rows (the usual case): the multiply moves behind the matrix */
-			auto unit = [&](auto jj) {
-				constexpr int k = PP * UPP + decltype(jj)::value;
-				constexpr bool with_bias = grp_of(k) == 0;
+		/* one matrix pass over the operand's low plane and, at 16 bits, its high plane */
+		auto product = [&](const Operand a, const int k, const uint32_t cls, const v4i_t k0) -> v4i_t {
+			const v4i_t d = mfma(a, plane_lo(raw, k, cls), k0);
+			if (cls == ACMHIP_BP_WORD)
+				return join(d, mfma(a, plane_hi(raw, k), zero));
+			return settle(d);
+		};
+		if (va == vb && vb == vc && vc == vd && clsF == clsC) {
+			/* one val over all four rows, one width (the usual case): the multiply moves behind the matrix; the width is decided once
+			 * per pair, its units are straight-line code */
+			auto units = [&](auto cc) {
+				constexpr uint32_t CLS = decltype(cc)::value;
+				auto unit = [&](auto jj) {
+					constexpr int k = PP * UPP + decltype(jj)::value;
+					constexpr bool with_bias = grp_of(k) == 0;
 #pragma unroll
-				for (int mt = 0; mt < NM; mt++) {
-					const Operand a = t.a[mt][lane];
-					const v4i_t c = join(mfma(a, lo(k), t.kc[mt][rs]), mfma(a, hi(k), zero));
-					v4i_t y = with_bias ? bias(mt) : zero;
-					scale4<with_bias>(y, c, vc);
-					store(k, mt, y);
-				}
+					for (int mt = 0; mt < NM; mt++) {
+						const v4i_t c = product(t.a[mt][lane], k, CLS, k_of(CLS, t.kc[mt][rs]));
+						v4i_t y = with_bias ? bias(mt) : zero;
+						scale4<with_bias>(y, c, vc);
+						store(k, mt, y);
+					}
+				};
+				(unit(std::integral_constant<int, Js>{}), ...);
 			};
-			(unit(std::integral_constant<int, Js>{}), ...);
+			by_class(clsC, units);
 		} else if (va == vb && vc == vd) {
-			/* a block boundary between the pair and the rows in front of it: the matrix once per half */
+			/* a block boundary between the pair and the rows in front of it (another val, maybe another width): the matrix once per half,
+			 * the other half's coefficients masked out of A - so each pass may read every lane's bytes at ITS half's width */
 			auto unit = [&](auto jj) {
 				constexpr int k = PP * UPP + decltype(jj)::value;
 				constexpr bool with_bias = grp_of(k) == 0;
 #pragma unroll
 				for (int mt = 0; mt < NM; mt++) {
 					const Operand a = t.a[mt][lane];
-					const Operand a_front = masked(a, rs < 2), a_pair = masked(a, rs >= 2);
-					const v4i_t c1 = join(mfma(a_front, lo(k), t.khalf[0][mt][rs]), mfma(a_front, hi(k), zero));
-					const v4i_t c2 = join(mfma(a_pair, lo(k), t.khalf[1][mt][rs]), mfma(a_pair, hi(k), zero));
+					v4i_t c1, c2;
+					by_class(clsF, [&](auto cc) { constexpr uint32_t CLS = decltype(cc)::value; c1 = product(masked(a, rs < 2), k, CLS, k_of(CLS, t.khalf[0][mt][rs])); });
+					by_class(clsC, [&](auto cc) { constexpr uint32_t CLS = decltype(cc)::value; c2 = product(masked(a, rs >= 2), k, CLS, k_of(CLS, t.khalf[1][mt][rs])); });
 					v4i_t y = with_bias ? bias(mt) : zero;
 					scale4<with_bias>(y, c1, va);
 					scale4<true>(y, c2, vc);
@@ -1531,8 +1641,11 @@ struct FirstPassM {
 					v4i_t y = with_bias ? bias(mt) : zero;
 #pragma unroll 1
 					for (int r = 0; r < 4; r++) {
-						const Operand ar = masked(a, rs == r);
-						const v4i_t c = join(mfma(ar, lo(k), t.krow[r][mt][rs]), mfma(ar, hi(k), zero));
+						v4i_t c;
+						by_class(r < 2 ? clsF : clsC, [&](auto cc) {
+							constexpr uint32_t CLS = decltype(cc)::value;
+							c = product(masked(a, rs == r), k, CLS, k_of(CLS, t.krow[r][mt][rs]));
+						});
 						scale4<true>(y, c, r == 0 ? va : (r == 1 ? vb : (r == 2 ? vc : vd)));
 					}
 					/* (mt is a run-time value here: the same address arithmetic as store(), spelled out) */
@@ -1550,11 +1663,12 @@ struct FirstPassM {
 	}
 	template <int... PPs>
 	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int lane, const bool owns0,
-							 const Tables &t, std::integer_sequence<int, PPs...>)
+							 const Tables &t, const Desc &d, std::integer_sequence<int, PPs...>)
 	{
-		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, std::make_integer_sequence<int, UPP>{}), ...);
+		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, d.e[PPs] & 3u, d.e[PPs + 1] & 3u, std::make_integer_sequence<int, UPP>{}), ...);
 	}
-	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t)
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t,
+						   const Desc &d)
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
 		const int p0 = pair0(tid), g0 = grp0(tid);
@@ -1565,7 +1679,7 @@ struct FirstPassM {
 		const int q_lane = (4 * rs) % QN, row_lane = (4 * rs) / QN;
 		uint32_t *const o0 = tile + lds_at<PS>(2 * p0 * COLS + g0 * 16) + n + row_lane * (COLS + (COLS >> PS)) + (q_lane * SIGMA + ((q_lane * SIGMA) >> PS));
 		const bool missing = fresh_stream && __builtin_amdgcn_readfirstlane(p0) == 0;     /* the wave's first row pair has nothing in front of it */
-		run_pairs(raw, o0, rowval + 2 * p0, missing, lane, owns0, t, std::make_integer_sequence<int, NPW>{});
+		run_pairs(raw, o0, rowval + 2 * p0, missing, lane, owns0, t, d, std::make_integer_sequence<int, NPW>{});
 	}
 };
 
@@ -1597,8 +1711,8 @@ __device__ __forceinline__ void k2_wait()
 /* MFORM: idx is the byte-plane staged form and the first pass runs on the matrix cores (FirstPassM); everything else is the same */
 template <class C, int WPS, int ABL, bool MFORM, int G0, int... Gs>
 __global__ void __launch_bounds__(C::NT, WPS)
-acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const acmhip_blkhdr *__restrict__ hdr,
-	  int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
+acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const uint32_t *__restrict__ pairs,
+	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
 	using FP = std::conditional_t<MFORM, FirstPassM<C, (MFORM ? G0 : 3)>, FirstPass2<C, G0, 2, ABL>>;
@@ -1656,13 +1770,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	auto warm_off = [&](const AcmTile2 &r) -> uint32_t {
 		return voff + (seg0 & ((r.flags & ACM_TILE_FRESH) ? (uint32_t)(2 * COLS * 2) : 0u));
 	};
-	auto sgpr_ptr = [&](const uint64_t a) -> const uint8_t * {
-		/* wave-uniform by construction; readfirstlane makes it an SGPR pair for the loads' base operand */
-		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-		return reinterpret_cast<const uint8_t *>(((uint64_t)hi << 32) | lo);
-	};
-	auto load_tile = [&](typename FP::Raw &raw, const AcmTile2 &r) {
-		FP::load(raw, sgpr_ptr(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS)), voff, warm_off(r));
+	auto load_tile = [&](typename FP::Raw &raw, const AcmTile2 &r, const typename FP::Desc &d) {
+		FP::issue(raw, idx, r, d, tid, voff, warm_off(r));
 	};
 
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / NT;      /* 16-byte PCM stores per thread and tile */
@@ -1670,9 +1779,10 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records through the scalar cache (the index is wave-uniform; readfirstlane says so to the compiler):
 	 * a vector load here would be tracked by the compiler's vmcnt bookkeeping, which knows nothing of the asm loads */
 	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
+	typename FP::Desc dcur = FP::fetch_desc(pairs, cur, tid);        /* byte-plane form: where the tile's row pairs are and how wide */
 	typename FP::Raw raw;
 	uint32_t hv = fetch_val(cur);
-	load_tile(raw, cur);
+	load_tile(raw, cur, dcur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1684,6 +1794,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* tile records come through the scalar cache one iteration ahead (asked for behind the PCM stores, used after the
 	 * next first pass); the last tile of a run names itself as its successor */
 	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+	typename FP::Desc dnxt = FP::fetch_desc(pairs, nxt, tid);
 	for (;;) {
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
@@ -1696,7 +1807,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		FP::run(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) != 0, tid, fp_tables);
+		FP::run(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) != 0, tid, fp_tables, dcur);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -1704,7 +1815,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(2);
 
 		/* (spreading these loads over the LDS passes instead of issuing them in one burst was measured: no gain) */
-		load_tile(raw, nxt);
+		load_tile(raw, nxt, dnxt);
 		phase_prio<PRIO, PRIO_LDS_PASSES>();            /* until the PCM stores are issued */
 		if (!(ABL & 8))
 			run_lds_passes<C, ABL, true, G0, Gs...>(tile, tid, fmt, carry_mem);
@@ -1740,8 +1851,10 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
 		discard = false;
 		cur = nxt;
+		dcur = dnxt;
 		t = tn;
 		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+		dnxt = FP::fetch_desc(pairs, nxt, tid);
 		buf ^= 1;
 	}
 #ifdef ACM_STAMPS
@@ -1752,7 +1865,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 }
 
 struct Tile2Entry {
-	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
+	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const uint32_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
 	Fn fn;
 	int threads, tile_rows, wg_per_cu;
 };
@@ -2349,7 +2462,7 @@ extern "C" int acmk_launch_tile2(uint32_t level, int cus, const AcmTile2 *d_tile
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, d_hdr, d_pcm, d_sink, fmt);
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, d_idx, (const uint32_t *)nullptr, d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }
@@ -2368,12 +2481,12 @@ extern "C" int acmk_tile2m_stages(uint32_t level)
 	return tile2m_entry(level).g0;
 }
 
-extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_blkhdr *d_hdr,
-				  int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
+extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs,
+				  const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream)
 {
 	if (ntiles == 0)
 		return 0;
-	if (!d_sink || !d_mform)
+	if (!d_sink || !d_mform || !d_pairs)
 		return -1;
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
 		return -1;
@@ -2381,8 +2494,8 @@ extern "C" int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_til
 	uint32_t grid = (uint32_t)((cus > 0 ? cus : 256) * e.wg_per_cu);
 	if (grid > ntiles)
 		grid = ntiles;
-	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, reinterpret_cast<const int16_t *>(d_mform), d_hdr, d_pcm,
-			   d_sink, fmt);
+	hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.threads), 0, (hipStream_t)stream, d_tiles, ntiles, reinterpret_cast<const int16_t *>(d_mform),
+			   reinterpret_cast<const uint32_t *>(d_pairs), d_hdr, d_pcm, d_sink, fmt);
 	ACMK_CHECK_LAUNCH();
 	return 0;
 }

@@ -231,16 +231,12 @@ extern "C" int acmhip_unpack_tile(uint32_t level, const acmhip_packed_chunk *til
 }
 
 /* ---------------------------------------------------------------------------
- * byte-plane staged form (include/acm_hip.h): the int16 form's bytes in the order acm_tile2's matrix-core build reads them
+ * byte-plane staged form (include/acm_hip.h): the staged indices in the order acm_tile2's matrix-core build reads them, every row pair at
+ * the narrowest of 4 / 8 / 16 bits per index that holds its indices (a block's indices lie in [-2^pwr, 2^pwr): decode.c:592-600)
  * --------------------------------------------------------------------------- */
 extern "C" int acmhip_mform_tile_rows(uint32_t level)
 {
 	return acmk_tile2m_rows(level);
-}
-
-extern "C" uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows)
-{
-	return (nrows + 2) * (2ull << level);
 }
 
 extern "C" int acmhip_mform_group(uint32_t level)
@@ -249,48 +245,135 @@ extern "C" int acmhip_mform_group(uint32_t level)
 	return g ? 1 << g : 0;
 }
 
-extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out)
+/* the kernel reads 16 bytes (32 where a residue's columns are 16) per lane whatever the class: room behind the last pair */
+static const uint64_t kMformSlack = 64;
+
+extern "C" uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows)
 {
-	const size_t qn = (size_t)acmhip_mform_group(level);
-	if (!qn || (!idx && nrows) || !out)
-		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / qn, rowb = cols * 2;
-	/* the two rows in front of the stream: index 0 everywhere */
-	for (size_t c = 0; c < 2 * sigma; c++) {
-		memset(out + c * 2 * qn, 0x80, qn);
-		memset(out + c * 2 * qn + qn, 0x00, qn);
-	}
-	for (uint64_t r = 0; r < nrows; r++) {
-		const int16_t *src = idx + r * cols;
-		uint8_t *dst = out + (r + 2) * rowb;
-		for (size_t c = 0; c < sigma; c++) {
+	const uint64_t cols = 1ull << level;
+	return nrows * cols * 2 + cols + kMformSlack;           /* every pair at 16 bits, the pair of zeros in front at 4 */
+}
+
+extern "C" uint64_t acmhip_mform_pairs(uint64_t nrows)
+{
+	return nrows / 2 + 1;
+}
+
+namespace {
+inline uint32_t pair_bytes(uint32_t level, uint32_t cls)
+{
+	return (4u << level) >> (3 - cls);             /* two rows of 2 / 1 / 0.5 bytes per index */
+}
+/* one row at width class cls: per residue c < sigma the qn indices of columns c + q * sigma */
+void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint8_t *dst)
+{
+	for (size_t c = 0; c < sigma; c++) {
+		if (cls == ACMHIP_BP_WORD) {
 			uint8_t *d = dst + c * 2 * qn;
 			for (size_t q = 0; q < qn; q++) {
 				const uint16_t x = (uint16_t)src[c + q * sigma];
-				d[q] = (uint8_t)(x ^ 0x80u);
+				d[q] = (uint8_t)(x ^ 0x80u);            /* low byte minus 128: a signed byte for the matrix instruction */
 				d[qn + q] = (uint8_t)(x >> 8);
+			}
+		} else if (cls == ACMHIP_BP_BYTE) {
+			uint8_t *d = dst + c * qn;
+			for (size_t q = 0; q < qn; q++)
+				d[q] = (uint8_t)(int8_t)src[c + q * sigma];
+		} else {
+			/* eight indices per dword, plus 8 each: index q = 8 j + i in nibble 2 i of dword j, index 8 j + 4 + i in nibble 2 i + 1
+			 * (x & 0x0f0f0f0f and (x >> 4) & 0x0f0f0f0f are then the bytes of columns 8 j .. 8 j + 3 and 8 j + 4 .. 8 j + 7) */
+			uint8_t *d = dst + c * (qn / 2);
+			for (size_t j = 0; j < qn / 8; j++) {
+				uint32_t w = 0;
+				for (size_t i = 0; i < 4; i++) {
+					w |= (uint32_t)((src[c + (8 * j + i) * sigma] + 8) & 15) << (8 * i);
+					w |= (uint32_t)((src[c + (8 * j + 4 + i) * sigma] + 8) & 15) << (8 * i + 4);
+				}
+				memcpy(d + 4 * j, &w, 4);
 			}
 		}
 	}
+}
+void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, int16_t *dst)
+{
+	for (size_t c = 0; c < sigma; c++) {
+		if (cls == ACMHIP_BP_WORD) {
+			const uint8_t *d = src + c * 2 * qn;
+			for (size_t q = 0; q < qn; q++)
+				dst[c + q * sigma] = (int16_t)(uint16_t)((d[q] ^ 0x80u) | ((unsigned)d[qn + q] << 8));
+		} else if (cls == ACMHIP_BP_BYTE) {
+			for (size_t q = 0; q < qn; q++)
+				dst[c + q * sigma] = (int16_t)(int8_t)src[c * qn + q];
+		} else {
+			for (size_t j = 0; j < qn / 8; j++) {
+				uint32_t w;
+				memcpy(&w, src + c * (qn / 2) + 4 * j, 4);
+				for (size_t i = 0; i < 4; i++) {
+					dst[c + (8 * j + i) * sigma] = (int16_t)((int)((w >> (8 * i)) & 15) - 8);
+					dst[c + (8 * j + 4 + i) * sigma] = (int16_t)((int)((w >> (8 * i + 4)) & 15) - 8);
+				}
+			}
+		}
+	}
+}
+} // namespace
+
+extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,
+				 uint64_t *bytes_used)
+{
+	const size_t qn = (size_t)acmhip_mform_group(level);
+	if (!qn || (!idx && nrows) || !out || !pairs || (nrows & 1) || (blob_base & 15))
+		return ACMHIP_ERR_ARG;
+	const size_t cols = (size_t)1 << level, sigma = cols / qn;
+	uint64_t at = 0;
+	/* the pair in front of the stream: index 0 everywhere, at 4 bits */
+	if ((blob_base >> 4) >= (1ull << 30))
+		return ACMHIP_ERR_ARG;                  /* more than 16 GB in front of this block: the pair table counts 16-byte units in 30 bits */
+	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 4) << 2 | ACMHIP_BP_NIBBLE);
+	memset(out, 0x88, pair_bytes(level, ACMHIP_BP_NIBBLE));
+	at += pair_bytes(level, ACMHIP_BP_NIBBLE);
+	for (uint64_t p = 0; p < nrows / 2; p++) {
+		const int16_t *src = idx + 2 * p * cols;
+		int lo = 0, hi = 0;
+		for (size_t m = 0; m < 2 * cols; m++) {
+			lo = src[m] < lo ? src[m] : lo;
+			hi = src[m] > hi ? src[m] : hi;
+		}
+		const uint32_t cls = (lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
+		if (((blob_base + at) >> 4) >= (1ull << 30))
+			return ACMHIP_ERR_ARG;
+		pairs[p + 1] = (acmhip_mform_pair)(((blob_base + at) >> 4) << 2 | cls);
+		const size_t rowb = pair_bytes(level, cls) / 2;
+		put_row(src, sigma, qn, cls, out + at);
+		put_row(src + cols, sigma, qn, cls, out + at + rowb);
+		at += 2 * rowb;
+	}
+	memset(out + at, 0, kMformSlack);
+	if (bytes_used)
+		*bytes_used = at + kMformSlack;
 	return ACMHIP_OK;
 }
 
-extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *block, uint64_t nrows, int16_t *idx)
+extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const acmhip_mform_pair *pairs, uint64_t nrows, int16_t *idx)
 {
 	const size_t qn = (size_t)acmhip_mform_group(level);
-	if (!qn || !block || (!idx && nrows))
+	if (!qn || !blob || !pairs || (!idx && nrows) || (nrows & 1))
 		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / qn, rowb = cols * 2;
-	for (size_t c = 0; c < 2 * sigma; c++)
-		for (size_t q = 0; q < qn; q++)
-			if (block[c * 2 * qn + q] != 0x80 || block[c * 2 * qn + qn + q] != 0)
-				return ACMHIP_ERR_ARG;
-	for (uint64_t r = 0; r < nrows; r++) {
-		const uint8_t *src = block + (r + 2) * rowb;
-		int16_t *dst = idx + r * cols;
-		for (size_t c = 0; c < sigma; c++)
-			for (size_t q = 0; q < qn; q++)
-				dst[c + q * sigma] = (int16_t)(uint16_t)((src[c * 2 * qn + q] ^ 0x80u) | ((unsigned)src[c * 2 * qn + qn + q] << 8));
+	const size_t cols = (size_t)1 << level, sigma = cols / qn;
+	std::vector<int16_t> front(2 * cols);
+	for (uint64_t p = 0; p <= nrows / 2; p++) {
+		const uint32_t cls = pairs[p] & 3;
+		if (cls < ACMHIP_BP_NIBBLE || cls > ACMHIP_BP_WORD)
+			return ACMHIP_ERR_ARG;
+		const uint8_t *src = blob + ((uint64_t)(pairs[p] >> 2) << 4);
+		const size_t rowb = pair_bytes(level, cls) / 2;
+		int16_t *dst = p ? idx + 2 * (p - 1) * cols : front.data();
+		get_row(src, sigma, qn, cls, dst);
+		get_row(src + rowb, sigma, qn, cls, dst + cols);
+		if (!p)
+			for (size_t m = 0; m < 2 * cols; m++)
+				if (front[m] != 0)
+					return ACMHIP_ERR_ARG;          /* the pair in front of a stream is zeros */
 	}
 	return ACMHIP_OK;
 }

@@ -35,7 +35,7 @@ def bind(path):
     L.acmhip_plan_launch.argtypes = [vp, vp, vp, vp, C.c_uint]
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
     L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(capi.StreamDesc), sz, C.POINTER(capi.PackedStream), C.POINTER(capi.Patch), sz, C.c_uint, C.POINTER(vp)]
-    L.acmhip_plan_bind_mform.argtypes = [vp, vp]
+    L.acmhip_plan_bind_mform.argtypes = [vp, vp, vp]
     return L
 
 
@@ -57,7 +57,7 @@ class Variant:
             # (a library whose byte-plane tiles are smaller than the stager's counts more of them over the same rows)
             pk = (capi.PackedStream * len(descs))(*[capi.PackedStream(m.chunk_off, m.ntiles * 8, m.form) for m in mform])
             rc = self.L.acmhip_plan_create_packed(self.dev, arr, len(descs), pk, None, 0, 0, C.byref(self.plan))
-            rc = rc or self.L.acmhip_plan_bind_mform(self.plan, d_mform)
+            rc = rc or self.L.acmhip_plan_bind_mform(self.plan, d_mform[0], d_mform[1])
         else:
             rc = self.L.acmhip_plan_create(self.dev, arr, len(descs), None, 0, 0, C.byref(self.plan))
         if rc:

@@ -60,15 +60,22 @@ def main():
     ap.add_argument("--verify", type=int, default=16)
     ap.add_argument("--matrix", action="store_true")
     ap.add_argument("--power", type=float, default=0.0, help="seconds of rocm-smi power / clock sampling per form")
+    ap.add_argument("--pwr-min", type=int, default=None, help="range of the blocks' pwr (their index width); default: the benchmark's")
+    ap.add_argument("--pwr-max", type=int, default=None)
     a = ap.parse_args()
     from libacm_amd import capi, workload
     dev = capi.Device(0)
     if a.matrix:
         parity_matrix(dev)
-    b = workload.build_uniform(a.streams, a.level, a.rows, a.blocks, keep_files=a.verify, threads=workload.usable_cpus())
+    kw = {}
+    if a.pwr_max is not None:
+        kw = dict(pwr_max=a.pwr_max, pwr_min=a.pwr_min if a.pwr_min is not None else min(4, a.pwr_max))
+    b = workload.build_uniform(a.streams, a.level, a.rows, a.blocks, keep_files=a.verify, threads=workload.usable_cpus(), **kw)
     t0 = time.perf_counter()
     mf = capi.mform_streams(b.idx, b.descs, threads=workload.usable_cpus())
-    print("byte-plane form: %.1f MB (int16 form %.1f MB), stager %.2f s" % (mf.nbytes / 1e6, b.idx.nbytes / 1e6, time.perf_counter() - t0), flush=True)
+    cc = mf.class_counts()
+    print("byte-plane form: %.1f MB = %.3f B/sample (int16 form %.1f MB), row pairs at 4 / 8 / 16 bits: %d / %d / %d, stager %.2f s" % (
+        mf.nbytes / 1e6, mf.nbytes / b.samples, b.idx.nbytes / 1e6, cc[1], cc[2], cc[3], time.perf_counter() - t0), flush=True)
     bufs = b.upload(dev)
     d_mf = mf.upload(dev)
     plan = capi.Plan(dev, b.descs, packed=mf.streams)
@@ -79,12 +86,12 @@ def main():
         host = np.empty(b.pcm_words, dtype=np.uint16)
         dev.download(host, bufs[2])
         return zlib.crc32(host.view(np.uint8)), host
-    plan.bind_mform(None)
+    plan.bind_mform(None, None)
     plan.launch(*bufs)
     dev.sync()
     crc16, host16 = pcm_crc()
     dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
-    plan.bind_mform(d_mf)
+    plan.bind_mform(*d_mf)
     plan.launch(*bufs)
     dev.sync()
     crcmf, hostmf = pcm_crc()
@@ -106,8 +113,8 @@ def main():
         plan.launch(*bufs)
     dev.sync()
     for r in range(a.rounds):
-        for name, bind in (("int16", None), ("mform", d_mf)):
-            plan.bind_mform(bind)
+        for name, bind in (("int16", (None, None)), ("mform", d_mf)):
+            plan.bind_mform(*bind)
             for _ in range(5):
                 plan.launch(*bufs)
             res[name].append(plan.time(*bufs, reps=a.steps) / a.steps)
@@ -118,8 +125,8 @@ def main():
     print("byte-plane / int16: %+.1f %%" % ((m16 / mmf - 1) * 100))
     if a.power:
         import bench
-        for name, bind in (("int16", None), ("mform", d_mf)):
-            plan.bind_mform(bind)
+        for name, bind in (("int16", (None, None)), ("mform", d_mf)):
+            plan.bind_mform(*bind)
             sm = bench.PowerSampler()
             sm.start()
             t0 = time.perf_counter()

@@ -22,19 +22,19 @@ def test_levels_with_a_byteplane_form():
         tr = L.acmhip_mform_tile_rows(level)
         if level in LEVELS:
             assert tr == {12: 4, 13: 2}.get(level, 8192 >> level)
-            assert L.acmhip_mform_bytes(level, 10) == 12 * (2 << level)
+            assert L.acmhip_mform_bytes(level, 10) == 10 * (2 << level) + (1 << level) + 64
             assert L.acmhip_mform_group(level) in (8, 16)
         else:
             assert tr == 0 and L.acmhip_mform_group(level) == 0
-            assert L.acmhip_mform_rows(level, None, 0, None) != 0
+            assert L.acmhip_mform_rows(level, None, 0, None, 0, None, None) != 0
 
 
 @pytest.mark.parametrize("level", LEVELS)
-@pytest.mark.parametrize("rows,pwr_max", [(1, 12), (16, 12), (17, 15)])
+@pytest.mark.parametrize("rows,pwr_max", [(1, 12), (16, 12), (16, 3), (17, 15)])
 def test_round_trip(level, rows, pwr_max):
     tr = capi.lib().acmhip_mform_tile_rows(level)
-    nblocks = (3 * tr + rows - 1) // rows + 1
-    s = capi.stage_file(make_stream(41000 + level * 100 + rows, level, rows, nblocks, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
+    nblocks = (3 * max(tr, 4) + rows - 1) // rows + 1
+    s = capi.stage_file(make_stream(41000 + level * 100 + rows, level, rows, nblocks, pwr_min=min(2, pwr_max), pwr_max=pwr_max,
                                     val_max=65535 if pwr_max == 15 else 255))
     cols = 1 << level
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
@@ -43,21 +43,59 @@ def test_round_trip(level, rows, pwr_max):
     nt = mf.streams[0].ntiles
     assert nt >= 3 and mf.streams[0].form == capi.FORM_BYTEPLANE and mf.streams[0].chunk_off == 0
     nrows = nt * tr
-    block = mf.data[:(nrows + 2) * cols * 2]
-    # two rows of index 0 in front: low bytes 0x80, high bytes 0
-    qn = capi.lib().acmhip_mform_group(level)            # columns of a residue class side by side: 8 or 16
-    front = block[:2 * cols * 2].reshape(-1, 2 * qn)
-    assert (front[:, :qn] == 0x80).all() and (front[:, qn:] == 0).all()
-    back = capi.mform_unrows(level, block, nrows)
+    npairs = nrows // 2 + 1
+    assert capi.lib().acmhip_mform_pairs(nrows) == npairs
+    pairs = mf.pairs[:npairs]
+    cls, off = pairs & 3, (pairs >> 2).astype(np.int64) * 16
+    # the pair in front of the stream: index 0 everywhere, at 4 bits (nibble value 8)
+    assert cls[0] == 1 and off[0] == 0 and (mf.data[:cols] == 0x88).all()
+    # every pair at the narrowest class that holds it, one behind the other
+    rowsv = s.idx[:nrows * cols].reshape(nrows // 2, 2 * cols).astype(np.int64)
+    lo, hi = rowsv.min(axis=1), rowsv.max(axis=1)
+    want_cls = np.where((lo >= -8) & (hi <= 7), 1, np.where((lo >= -128) & (hi <= 127), 2, 3))
+    assert np.array_equal(cls[1:], want_cls)
+    size = np.array([0, cols, 2 * cols, 4 * cols])[cls]
+    assert np.array_equal(off[1:], off[:-1] + size[:-1])
+    assert off[-1] + size[-1] + 64 <= mf.data.size <= capi.lib().acmhip_mform_bytes(level, nrows) + 256
+    back = capi.mform_unrows(level, mf.data, pairs, nrows)
     assert np.array_equal(back, s.idx[:nrows * cols])
-    # layout: row r, residue c, q -> byte (r + 2) * 2 cols + 2 qn c + q (low, bit 7 flipped) / + qn + q (high)
+    # layout: pair p, row r of it, residue c, q
+    qn = capi.lib().acmhip_mform_group(level)            # columns of a residue class side by side: 8 or 16
     sigma = cols // qn
     rng = np.random.default_rng(level)
-    for _ in range(64):
-        r, c, q = int(rng.integers(nrows)), int(rng.integers(sigma)), int(rng.integers(qn))
-        x = int(s.idx[r * cols + c + q * sigma]) & 0xFFFF
-        at = (r + 2) * 2 * cols + 2 * qn * c
-        assert block[at + q] == (x & 0xFF) ^ 0x80 and block[at + qn + q] == x >> 8
+    for _ in range(96):
+        p, r, c, q = int(rng.integers(nrows // 2)), int(rng.integers(2)), int(rng.integers(sigma)), int(rng.integers(qn))
+        x = int(s.idx[(2 * p + r) * cols + c + q * sigma])
+        k = int(cls[p + 1])
+        at = int(off[p + 1]) + r * int(size[p + 1]) // 2
+        if k == 3:
+            assert mf.data[at + 2 * qn * c + q] == (x & 0xFF) ^ 0x80 and mf.data[at + 2 * qn * c + qn + q] == (x >> 8) & 0xFF
+        elif k == 2:
+            assert mf.data[at + qn * c + q] == x & 0xFF
+        else:
+            j, i = divmod(q, 8)
+            nib = 2 * (i % 4) + (i // 4)
+            byte = mf.data[at + (qn // 2) * c + 4 * j + nib // 2]
+            assert (byte >> (4 * (nib % 2))) & 15 == x + 8
+
+
+def test_width_classes_follow_the_blocks():
+    """quiet blocks (pwr <= 3: indices in [-8, 7]) travel at 4 bits, pwr <= 7 at 8 bits: the stager's classes are what the block
+    headers promise or narrower"""
+    level, rows = 9, 16
+    s = capi.stage_file(make_stream(44000, level, rows, 40, pwr_min=0, pwr_max=12))
+    cols = 1 << level
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
+                        nrows=s.info.blocks * rows, row_begin=0)
+    mf = capi.mform_streams(s.idx, [d])
+    cls = (mf.pairs[1:1 + s.info.blocks * rows // 2] & 3).reshape(s.info.blocks, rows // 2)
+    pwr = s.hdr[:s.info.blocks, 1]
+    assert len(set(pwr.tolist())) > 4
+    for b in range(s.info.blocks):
+        bound = 1 if pwr[b] <= 3 else 2 if pwr[b] <= 7 else 3
+        assert cls[b].max() <= bound, (b, pwr[b], cls[b])
+    assert (cls == 1).any() and (cls == 2).any() and (cls == 3).any()
+    assert mf.nbytes < 0.9 * s.info.blocks * rows * cols * 2
 
 
 def load_tables(G):

@@ -107,8 +107,8 @@ def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
     plan = capi.Plan(dev, ar.descs, packed=mf.streams)
     assert plan.stats().mform_tiles > 0
     outs = []
-    for bind in (d_mf, None, d_mf):
-        plan.bind_mform(bind)
+    for bind in (d_mf, (None, None), d_mf):
+        plan.bind_mform(*bind)
         dev.upload(d_pcm, np.zeros(ar.pcm_words, dtype=np.uint16))
         plan.launch(d_idx, d_hdr, d_pcm)
         o = np.zeros(ar.pcm_words, dtype=np.uint16)
@@ -117,8 +117,10 @@ def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     for f, (_, _, po, _, ne) in zip(files, ar.layout):
         assert np.array_equal(outs[0][po:po + ne], oracle_pcm(f)[0])
+    with pytest.raises(capi.AcmHipError):
+        plan.bind_mform(d_mf[0], None)
     plan.destroy()
-    for p in (d_idx, d_hdr, d_pcm, d_mf):
+    for p in (d_idx, d_hdr, d_pcm) + d_mf:
         dev.free(p)
 
 
@@ -138,7 +140,7 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
     plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage)
     res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=True)
     assert tm0.packed_streams == 0 and tm.packed_streams >= 30, (tm0.packed_streams, tm.packed_streams)
-    assert tm.h2d_bytes <= 1.3 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
+    assert tm.h2d_bytes < 0.95 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)          # quiet blocks travel at 4 or 8 bits per index
     for k, f in enumerate(files):
         o = O.Oracle(f)
         if o.err < 0:
