@@ -49,6 +49,27 @@ def test_byteplane_matrix(dev, force_k2, level, rows, pwr_max):
     assert st.mform_tiles >= 7 and st.fused_streams == 1 and st.stagewise_streams == 0
 
 
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("rows,pwr_min,pwr_max", [(16, 3, 3), (16, 3, 12), (3, 3, 7), (1, 3, 12), (6, 3, 5), (64, 3, 9)])
+def test_byteplane_width_classes(dev, force_k2, level, rows, pwr_min, pwr_max):
+    """quiet blocks travel at 4 or 8 bits per index: row pairs of every width, width changes between the rows of a unit in every place
+    a block boundary can fall (with and without a change of val), a stream that is 4 bits throughout.  (pwr >= 3: below that the k / t
+    fillers' indices of up to 5 leave the amplitude table - H1 patches - and such a stream keeps the int16 form)"""
+    tr = max(tile_rows(level), 4)
+    nblocks = max(2, (9 * tr + rows - 1) // rows + 1)
+    f = make_stream(29000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=2, pwr_min=pwr_min, pwr_max=pwr_max)
+    s = capi.stage_file(f)
+    assert s.patches is None or len(s.patches) == 0
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows << level, level=level, rows=rows, nrows=s.info.blocks * rows, row_begin=0)
+    cc = capi.mform_streams(s.idx, [d]).class_counts()
+    if pwr_max <= 3:
+        assert cc[2] == 0 and cc[3] == 0 and cc[1] > 9
+    elif pwr_max == 12 and rows < 64:
+        assert int(cc[1] > 1) + int(cc[2] > 0) + int(cc[3] > 0) >= 2, cc          # at least two widths among its blocks
+    st = check(dev, [f])
+    assert st.mform_tiles >= 9
+
+
 @pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE])
 def test_byteplane_batch(dev, force_k2, fmt):
     """many streams in one plan, levels with and without the form side by side: workgroup runs start inside streams (lead-in tiles)
