@@ -1592,7 +1592,9 @@ struct FirstPassM {
 				return join(d, mfma(a, plane_hi(raw, k), zero));
 			return settle(d);
 		};
-		if (va == vb && vb == vc && vc == vd && clsF == clsC) {
+		/* (differences OR-ed together: a handful of scalar ops per decision instead of a compare-and-select per term) */
+		const uint32_t d_front = (uint32_t)(va ^ vb), d_pair = (uint32_t)(vc ^ vd), d_between = (uint32_t)(vb ^ vc) | (clsF ^ clsC);
+		if ((d_front | d_pair | d_between) == 0) {
 			/* one val over all four rows, one width (the usual case): the multiply moves behind the matrix; the width is decided once
 			 * per pair, its units are straight-line code */
 			auto units = [&](auto cc) {
@@ -1611,7 +1613,7 @@ struct FirstPassM {
 				(unit(std::integral_constant<int, Js>{}), ...);
 			};
 			by_class(clsC, units);
-		} else if (va == vb && vc == vd) {
+		} else if ((d_front | d_pair) == 0) {
 			/* a block boundary between the pair and the rows in front of it (another val, maybe another width): the matrix once per half,
 			 * the other half's coefficients masked out of A - so each pass may read every lane's bytes at ITS half's width */
 			auto unit = [&](auto jj) {
