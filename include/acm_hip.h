@@ -210,8 +210,8 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  * in [-2^pwr, 2^pwr) (decode.c:592-600: the amplitude table has 2^(pwr+1) entries), so quiet blocks need fewer bits:
  *
  *   stream -> a pair of zero rows (what the cascade sees in front of row 0), then its row pairs (rows 2P, 2P + 1), each at
- *             its own width class; acmhip_mform_pair k of the stream = where pair k - 1 starts (16-byte units from the
- *             arena's base) << 2 | class;
+ *             its own width class (a pair takes 64 bytes or a multiple: levels >= 7); acmhip_mform_pair k of the stream =
+ *             where pair k - 1 starts (64-byte units from the arena's base) << 2 | class;
  *   pair   -> its two rows, each row = cols/G residues c, each residue = the G indices of columns c, c + cols/G, ...:
  *             ACMHIP_BP_WORD    G low bytes ((idx & 0xff) ^ 0x80: signed bytes, the kernel adds the 128 back through the
  *                               accumulator), then G high bytes (idx >> 8)
@@ -231,7 +231,7 @@ uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);     /* upper bound 
 uint64_t acmhip_mform_pairs(uint64_t nrows);                     /* pair-table entries of nrows rows: nrows / 2 + 1 */
 /*
  * Host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them; nrows even) -> out[0 .. *bytes_used) and
- * pairs[0 .. nrows / 2].  blob_base: where out[0] will sit in the batch's arena (bytes, multiple of 16, < 16 GB); the
+ * pairs[0 .. nrows / 2].  blob_base: where out[0] will sit in the batch's arena (bytes, multiple of 64, < 64 GB); the
  * offsets written are absolute.
  */
 int  acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,

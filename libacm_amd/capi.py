@@ -271,7 +271,7 @@ class PackedArena:
 
 class MformArena:
     """The byte-plane staged form (acmhip_mform_rows) of several streams: .data (uint8 arena), .pairs (uint32 pair table: offset in
-    16-byte units << 2 | width class) and .streams (PackedStream with form = FORM_BYTEPLANE beside each stream descriptor)."""
+    64-byte units << 2 | width class) and .streams (PackedStream with form = FORM_BYTEPLANE beside each stream descriptor)."""
 
     def __init__(self, data, pairs, streams):
         self.data, self.pairs, self.streams = data, pairs, streams
@@ -322,17 +322,18 @@ def mform_streams(idx, descs, threads=1):
             used = C.c_uint64()
             _check(L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], buf.ctypes.data, 0, pairs[p_at[i]:].ctypes.data,
                                        C.byref(used)), "acmhip_mform_rows")
-            parts[i] = buf[:(used.value + 15) // 16 * 16]
+            parts[i] = buf[:(used.value + 63) // 64 * 64]
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
         list(ex.map(one, range(n)))
+    total = sum(p.size for p in parts if p is not None)
+    if (total >> 6) >= 1 << 30:
+        raise AcmHipError("byte-plane arena beyond 64 GB")
     at = 0
     for i in range(n):
         if parts[i] is not None:
             k = int(L.acmhip_mform_pairs(rows[i]))
-            pairs[p_at[i]:p_at[i] + k] += np.uint32((at // 16) << 2)        # offsets were written relative to the stream's own block
+            pairs[p_at[i]:p_at[i] + k] += np.uint32((at // 64) << 2)        # offsets were written relative to the stream's own block
             at += parts[i].size
-    if (at >> 4) >= 1 << 30:
-        raise AcmHipError("byte-plane arena beyond 16 GB")
     data = np.empty(max(at, 16) + 64, dtype=np.uint8)
     at = 0
     for i in range(n):

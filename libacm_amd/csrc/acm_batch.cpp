@@ -663,7 +663,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	} else {
 		stage_packed = false;
 	}
-	if (stage_mform && mf_total && (mf_total >> 4) < (1ull << 30)) {         /* (the pair table counts 16-byte units in 30 bits) */
+	if (stage_mform && mf_total && (mf_total >> 6) < (1ull << 30)) {         /* (the pair table counts 64-byte units in 30 bits) */
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PKBLOB, mf_total, (void **)&h_pkblob));
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKBLOB, mf_total, (void **)&d_pkblob));
 		/* (+ 32 entries: the kernel's scalar loads fetch whole groups) */

@@ -1348,7 +1348,7 @@ struct FirstPassM {
 	typedef std::conditional_t<G == 3, uint64_t, v4i_t> Operand;
 
 	struct Raw { v4u_t r[NU * VPU]; };
-	/* pair-table entries (include/acm_hip.h: offset in 16-byte units << 2 | width class) of the wave's row pairs and of the pair in front of them */
+	/* pair-table entries (include/acm_hip.h: offset in 64-byte units << 2 | width class) of the wave's row pairs and of the pair in front of them */
 	struct Desc { uint32_t e[NPW + 1]; };
 	/* per-lane operands that never change, parked in LDS between tiles (registers are what the LDS passes are short of) */
 	struct Tables {
@@ -1400,7 +1400,7 @@ struct FirstPassM {
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
 		const uint32_t ef = d.e[PP], ec = d.e[PP + 1];
-		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(ef >> 2) << 4));
+		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(ef >> 2) << 6));
 		/* the offsets differ, the loads do not: one sequence of them, whatever the widths (a load inside a branch would also hide from
 		 * tests/test_isa_invariants.py which registers are in flight) */
 		uint32_t lane_part, ustride;
@@ -1411,7 +1411,7 @@ struct FirstPassM {
 			lane_part = lane16 >> sh;
 			ustride = (uint32_t)(16 * RESB_W) >> sh;
 		} else {
-			const uint32_t delta = ((ec >> 2) - (ef >> 2)) << 4;
+			const uint32_t delta = ((ec >> 2) - (ef >> 2)) << 6;
 			const bool front = rs < 2;
 			const uint32_t sh = front ? 3u - (ef & 3u) : 3u - (ec & 3u);
 			lane_part = ((uint32_t)((rs & 1) * ROWB_W + (grp0(tid) * 16 + n) * RESB_W) >> sh) + (front ? 0u : delta);

@@ -322,14 +322,14 @@ extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nr
 				 uint64_t *bytes_used)
 {
 	const size_t qn = (size_t)acmhip_mform_group(level);
-	if (!qn || (!idx && nrows) || !out || !pairs || (nrows & 1) || (blob_base & 15))
+	if (!qn || (!idx && nrows) || !out || !pairs || (nrows & 1) || (blob_base & 63))
 		return ACMHIP_ERR_ARG;
 	const size_t cols = (size_t)1 << level, sigma = cols / qn;
 	uint64_t at = 0;
 	/* the pair in front of the stream: index 0 everywhere, at 4 bits */
-	if ((blob_base >> 4) >= (1ull << 30))
-		return ACMHIP_ERR_ARG;                  /* more than 16 GB in front of this block: the pair table counts 16-byte units in 30 bits */
-	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 4) << 2 | ACMHIP_BP_NIBBLE);
+	if ((blob_base >> 6) >= (1ull << 30))
+		return ACMHIP_ERR_ARG;                  /* more than 64 GB in front of this block: the pair table counts 64-byte units in 30 bits */
+	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | ACMHIP_BP_NIBBLE);
 	memset(out, 0x88, pair_bytes(level, ACMHIP_BP_NIBBLE));
 	at += pair_bytes(level, ACMHIP_BP_NIBBLE);
 	for (uint64_t p = 0; p < nrows / 2; p++) {
@@ -340,9 +340,9 @@ extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nr
 			hi = src[m] > hi ? src[m] : hi;
 		}
 		const uint32_t cls = (lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
-		if (((blob_base + at) >> 4) >= (1ull << 30))
+		if (((blob_base + at) >> 6) >= (1ull << 30))
 			return ACMHIP_ERR_ARG;
-		pairs[p + 1] = (acmhip_mform_pair)(((blob_base + at) >> 4) << 2 | cls);
+		pairs[p + 1] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | cls);
 		const size_t rowb = pair_bytes(level, cls) / 2;
 		put_row(src, sigma, qn, cls, out + at);
 		put_row(src + cols, sigma, qn, cls, out + at + rowb);
@@ -365,7 +365,7 @@ extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const ac
 		const uint32_t cls = pairs[p] & 3;
 		if (cls < ACMHIP_BP_NIBBLE || cls > ACMHIP_BP_WORD)
 			return ACMHIP_ERR_ARG;
-		const uint8_t *src = blob + ((uint64_t)(pairs[p] >> 2) << 4);
+		const uint8_t *src = blob + ((uint64_t)(pairs[p] >> 2) << 6);
 		const size_t rowb = pair_bytes(level, cls) / 2;
 		int16_t *dst = p ? idx + 2 * (p - 1) * cols : front.data();
 		get_row(src, sigma, qn, cls, dst);

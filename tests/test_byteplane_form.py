@@ -5,6 +5,7 @@ The form is the int16 form's bytes in another order, so the round trip must be e
 oracle's own juggle cascade (reference decode.c:527-590): three stages over a residue class of the columns, computed as
 A x inputs with the staged bytes exactly as the kernel's matrix instruction sees them, must equal what the oracle leaves in its
 block buffer after stage 2 (sub_count 2, 4, 8)."""
+import ctypes as C
 import re
 
 import numpy as np
@@ -46,7 +47,7 @@ def test_round_trip(level, rows, pwr_max):
     npairs = nrows // 2 + 1
     assert capi.lib().acmhip_mform_pairs(nrows) == npairs
     pairs = mf.pairs[:npairs]
-    cls, off = pairs & 3, (pairs >> 2).astype(np.int64) * 16
+    cls, off = pairs & 3, (pairs >> 2).astype(np.int64) * 64
     # the pair in front of the stream: index 0 everywhere, at 4 bits (nibble value 8)
     assert cls[0] == 1 and off[0] == 0 and (mf.data[:cols] == 0x88).all()
     # every pair at the narrowest class that holds it, one behind the other
@@ -180,3 +181,30 @@ def test_matrix_tables_reproduce_the_first_stages(level, G):
     sign = np.where(np.arange(2 * qn) & 1, -1, 1)
     assert np.array_equal(t["A"][1], A * sign[:, None])
     assert np.array_equal(t["KROW"][1], KROW * sign[None, :]) and np.array_equal(t["BIAS"][1], BIAS * sign[None, :])
+
+
+def test_stager_rejects_what_the_kernel_could_not_read():
+    """odd row counts (a unit is a row pair), a block that would not start on 16 bytes, offsets beyond the pair table's 30 bits, levels
+    without the form; the inverse refuses a table with an unknown width class or a non-zero pair in front"""
+    L = capi.lib()
+    level, cols = 9, 512
+    idx = np.zeros(4 * cols, dtype=np.int16)
+    out = np.zeros(L.acmhip_mform_bytes(level, 4), dtype=np.uint8)
+    pairs = np.zeros(8, dtype=np.uint32)
+    used = C.c_uint64()
+    args = lambda lv, n, base: (lv, idx.ctypes.data, n, out.ctypes.data, base, pairs.ctypes.data, C.byref(used))
+    assert L.acmhip_mform_rows(*args(level, 4, 0)) == 0 and used.value == cols + 2 * cols + 64         # three pairs at 4 bits + slack
+    assert (pairs[:3] & 3 == 1).all() and pairs[3] == 0
+    assert L.acmhip_mform_rows(*args(level, 3, 0)) != 0
+    assert L.acmhip_mform_rows(*args(level, 4, 16)) != 0
+    assert L.acmhip_mform_rows(*args(level, 4, 1 << 36)) != 0
+    assert L.acmhip_mform_rows(*args(level, 4, 1 << 34)) == 0 and pairs[0] >> 2 == 1 << 28
+    assert L.acmhip_mform_rows(*args(5, 4, 0)) != 0
+    assert L.acmhip_mform_rows(*args(level, 4, 0)) == 0
+    back = np.zeros(4 * cols, dtype=np.int16)
+    assert L.acmhip_mform_unrows(level, out.ctypes.data, pairs.ctypes.data, 4, back.ctypes.data) == 0
+    bad = pairs.copy()
+    bad[2] &= ~np.uint32(3)
+    assert L.acmhip_mform_unrows(level, out.ctypes.data, bad.ctypes.data, 4, back.ctypes.data) != 0
+    out[5] = 0x98                                   # an index of 1 in the pair in front of the stream
+    assert L.acmhip_mform_unrows(level, out.ctypes.data, pairs.ctypes.data, 4, back.ctypes.data) != 0

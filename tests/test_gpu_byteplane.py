@@ -145,6 +145,20 @@ def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
         dev.free(p)
 
 
+def test_plan_rejects_a_byteplane_form_that_is_too_short(dev, force_k2):
+    """a stream that comes with fewer byte-plane tiles than the plan would decode from them, or with an unknown form, is an argument
+    error at plan creation - not a launch that reads past its pair table"""
+    f = make_stream(26500, 9, 16, 6)
+    s = capi.stage_file(f)
+    ar = capi.Arena([s])
+    mf = capi.mform_streams(ar.idx, ar.descs)
+    assert mf.streams[0].ntiles == 6
+    for ntiles, form in ((5, capi.FORM_BYTEPLANE), (6, 7)):
+        with pytest.raises(capi.AcmHipError):
+            capi.Plan(dev, ar.descs, packed=[capi.PackedStream(0, ntiles, form)])
+    capi.Plan(dev, ar.descs, packed=[capi.PackedStream(0, 6, capi.FORM_BYTEPLANE)]).destroy()
+
+
 @pytest.mark.parametrize("prestage", [False, True])
 def test_batch_decode_stages_byteplanes(dev, prestage):
     """acm_batch_decode with ACM_BATCH_STAGE_BYTEPLANE: the host pool re-orders the whole tiles of every clean stream of a level
