@@ -1563,14 +1563,53 @@ struct FirstPassM {
 		return v4i_t{ -(k16[0] >> 4), -(k16[1] >> 4), -(k16[2] >> 4), -(k16[3] >> 4) };
 	}
 
-	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put a pair of zeros there) */
-	template <int PP, int... Js>
-	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int lane,
-							const bool owns0, const Tables &t, const uint32_t clsF, const uint32_t clsC, std::integer_sequence<int, Js...>)
+	/* the units of row pair PP when its four input rows share one val and one width CLS: the multiply moves behind the matrix */
+	template <int PP, uint32_t CLS, int... Js>
+	static __device__ __forceinline__ void fast_pair(const Raw &raw, uint32_t *const o0, const bool nothing_in_front, const int lane, const bool owns0,
+							 const Tables &t, const int32_t val, std::integer_sequence<int, Js...>)
 	{
 		constexpr int PS = C::PS;
 		const int rs = lane >> 4;
 		const v4i_t zero = { 0, 0, 0, 0 };
+		auto unit = [&](auto jj) {
+			constexpr int k = PP * UPP + decltype(jj)::value;
+			constexpr bool with_bias = grp_of(k) == 0;
+#pragma unroll
+			for (int mt = 0; mt < NM; mt++) {
+				const Operand a = t.a[mt][lane];
+				const v4i_t d = mfma(a, plane_lo(raw, k, CLS), k_of(CLS, t.kc[mt][rs]));
+				const v4i_t c = CLS == ACMHIP_BP_WORD ? join(d, mfma(a, plane_hi(raw, k), zero)) : settle(d);
+				v4i_t y = with_bias ? t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4] : zero;
+				scale4<with_bias>(y, c, val);
+				constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;
+				uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
+				if (QN >= 16)
+					o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
+			}
+		};
+		(unit(std::integral_constant<int, Js>{}), ...);
+	}
+
+	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put a pair of zeros there) */
+	template <int PP, int... Js>
+	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int lane,
+							const bool owns0, const Tables &t, const uint32_t clsF, const uint32_t clsC, const bool one_val_one_width,
+							const bool halves_uniform, std::integer_sequence<int, Js...>)
+	{
+		constexpr int PS = C::PS;
+		const int rs = lane >> 4;
+		const v4i_t zero = { 0, 0, 0, 0 };
+		if (one_val_one_width) {
+			/* one val over all four rows, one width (the usual case): the width is decided once per pair, its units are straight-line code */
+			const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]);
+			by_class(clsC, [&](auto cc) {
+				fast_pair<PP, decltype(cc)::value>(raw, o0, nothing_in_front, lane, owns0, t, vc, std::integer_sequence<int, Js...>{});
+			});
+			return;
+		}
 		const int32_t va = __builtin_amdgcn_readfirstlane(rv[0]), vb = __builtin_amdgcn_readfirstlane(rv[1]);      /* rows 2P-2, 2P-1 */
 		const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]), vd = __builtin_amdgcn_readfirstlane(rv[3]);      /* rows 2P, 2P+1 */
 		/* the "+1" only reaches the lane that owns residue 0, in the unit of group 0 (the pair's first unit, if this wave has it) */
@@ -1592,28 +1631,7 @@ struct FirstPassM {
 				return join(d, mfma(a, plane_hi(raw, k), zero));
 			return settle(d);
 		};
-		/* (differences OR-ed together: a handful of scalar ops per decision instead of a compare-and-select per term) */
-		const uint32_t d_front = (uint32_t)(va ^ vb), d_pair = (uint32_t)(vc ^ vd), d_between = (uint32_t)(vb ^ vc) | (clsF ^ clsC);
-		if ((d_front | d_pair | d_between) == 0) {
-			/* one val over all four rows, one width (the usual case): the multiply moves behind the matrix; the width is decided once
-			 * per pair, its units are straight-line code */
-			auto units = [&](auto cc) {
-				constexpr uint32_t CLS = decltype(cc)::value;
-				auto unit = [&](auto jj) {
-					constexpr int k = PP * UPP + decltype(jj)::value;
-					constexpr bool with_bias = grp_of(k) == 0;
-#pragma unroll
-					for (int mt = 0; mt < NM; mt++) {
-						const v4i_t c = product(t.a[mt][lane], k, CLS, k_of(CLS, t.kc[mt][rs]));
-						v4i_t y = with_bias ? bias(mt) : zero;
-						scale4<with_bias>(y, c, vc);
-						store(k, mt, y);
-					}
-				};
-				(unit(std::integral_constant<int, Js>{}), ...);
-			};
-			by_class(clsC, units);
-		} else if ((d_front | d_pair) == 0) {
+		if (halves_uniform) {
 			/* a block boundary between the pair and the rows in front of it (another val, maybe another width): the matrix once per half,
 			 * the other half's coefficients masked out of A - so each pass may read every lane's bytes at ITS half's width */
 			auto unit = [&](auto jj) {
@@ -1667,7 +1685,20 @@ struct FirstPassM {
 	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int lane, const bool owns0,
 							 const Tables &t, const Desc &d, std::integer_sequence<int, PPs...>)
 	{
-		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, d.e[PPs] & 3u, d.e[PPs + 1] & 3u, std::make_integer_sequence<int, UPP>{}), ...);
+		/* which path each row pair takes, decided for all of them at once with one lane per pair: lane j looks at the four row values of
+		 * pair j and at whether its width differs from the width in front of it; two ballots later a pair's decision is one scalar bit test
+		 * (instead of four readfirstlanes and a dozen scalar compare-and-select instructions per pair) */
+		uint32_t width_change = 0;
+#pragma unroll
+		for (int j = 0; j < NPW; j++)
+			width_change |= (((d.e[j] ^ d.e[j + 1]) & 3u) != 0 ? 1u : 0u) << j;
+		const int j = lane < NPW ? lane : 0;
+		const int32_t a = rv0[2 * j], b = rv0[2 * j + 1], c = rv0[2 * j + 2], e = rv0[2 * j + 3];
+		const uint32_t within = (uint32_t)((a ^ b) | (c ^ e)), between = (uint32_t)(b ^ c) | ((width_change >> j) & 1u);
+		const uint32_t fast_mask = (uint32_t)__builtin_amdgcn_ballot_w64((within | between) == 0);
+		const uint32_t halves_mask = (uint32_t)__builtin_amdgcn_ballot_w64(within == 0);
+		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, d.e[PPs] & 3u, d.e[PPs + 1] & 3u, (fast_mask >> PPs) & 1u,
+			       (halves_mask >> PPs) & 1u, std::make_integer_sequence<int, UPP>{}), ...);
 	}
 	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t,
 						   const Desc &d)
