@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--stagewise", action="store_true", help="force the generic stage-wise kernels")
     ap.add_argument("--form", choices=["auto", "int16", "byteplane", "packed"], default="auto",
                     help="staged form the timed launches read (all three are written by the host stager, include/acm_hip.h): int16 = one "
-                         "index per sample; byteplane = the same two bytes per sample in matrix-core operand order (levels 7-12: first pass "
+                         "index per sample; byteplane = every row pair at 4 / 8 / 16 bits per index in matrix-core operand order (levels 7-14: first pass "
                          "on v_mfma_i32_16x16x32_i8); packed = width class per column pair + packed residuals (levels 6-9).  auto = "
                          "byteplane where the level has it, else int16.  The other forms are timed as side measurements")
     ap.add_argument("--packed", action="store_true", help="= --form packed")
@@ -87,7 +87,7 @@ def parse_args():
         a.form = "packed"
     if a.form == "auto":
         # the corpus (levels 7-9) has the byte-plane form throughout
-        a.form = "byteplane" if not a.stagewise and (a.workload == "corpus" or 7 <= a.level <= 12) else "int16"
+        a.form = "byteplane" if not a.stagewise and (a.workload == "corpus" or 7 <= a.level <= 14) else "int16"
     a.packed = a.form == "packed"
     return a
 
@@ -567,7 +567,7 @@ def main():
         pk_ptrs = pk.upload(dev)
     elif args.form == "byteplane":
         if args.stagewise or (args.workload == "uniform" and capi.lib().acmhip_mform_tile_rows(args.level) <= 0):
-            raise SystemExit("bench.py: --form byteplane needs a level with a byte-plane form (7-12)")
+            raise SystemExit("bench.py: --form byteplane needs a level with a byte-plane form (7-14)")
         t0 = time.perf_counter()
         mf = capi.mform_streams(batch.idx, batch.descs, threads=stage_threads)
         t_mform = time.perf_counter() - t0

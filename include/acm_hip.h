@@ -334,9 +334,9 @@ typedef struct acm_batch_opts {
                                        upload carries the packed form + the int16 rows the other kernels still read (ragged tails) instead
                                        of the whole int16 arena - about half the bytes over PCIe and through HBM, for ~30 % more host
                                        work per stream and a synthesis launch that is 10-18 % slower (acm_tile2p).  Off by default. */
-#define ACM_BATCH_STAGE_BYTEPLANE 4u /* host parsing only: the pool also re-orders the whole tiles of every clean stream of levels 7-12 into the
+#define ACM_BATCH_STAGE_BYTEPLANE 4u /* host parsing only: the pool also re-orders the whole tiles of every clean stream of levels 7-14 into the
                                        byte-plane form (acmhip_mform_rows; same bytes) and the upload carries that + the int16 rows the other
-                                       kernels still read: the synthesis launch runs its first pass on the matrix cores (+3-7 %).  Wins over
+                                       kernels still read: fewer bytes to upload, and the synthesis launch runs its first pass on the matrix cores (+3 ... +24 % by level).  Wins over
                                        ACM_BATCH_STAGE_PACKED when both are set. */
 #define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
                                        the PCM straight into it, stream by stream, instead of through the library's own pinned

@@ -87,7 +87,7 @@ struct AcmParseResult {
 /* levels whose acm_tile2 build has a three-stage first pass and therefore a build that runs it on the matrix cores, fed with the
  * byte-plane staged form (acmhip_mform_rows) */
 #define ACM_K2M_MIN_LEVEL 7
-#define ACM_K2M_MAX_LEVEL 13
+#define ACM_K2M_MAX_LEVEL 14
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 

@@ -1982,13 +1982,14 @@ const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { ACM_K2M_L11 } },
 	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { ACM_K2M_L12 } },
 	/* level 13: the vector-ALU build needs 128 KB tiles (its first pass re-runs two rows per segment); here the rows in front cost a second
-	 * read through L2 and nothing else, so a tile may be one row pair.  (Level 14: a row pair is 128 KB, sixteen waves of 128 registers -
-	 * the build spills six of them; it stays with the vector-ALU build.) */
+	 * read through L2 and nothing else, so a tile may be one row pair.  Level 14: a row pair IS 128 KB, sixteen waves of 128 registers;
+	 * (4,3,3,2,2) and (4,3,2,3,2) spill seven of them, (4,2,3,3,2) none */
 	{ { Tile2Entry{ nullptr, 0, 0, 0 }, 0 }, { ACM_K2M_L13 } },
+	{ { Tile2Entry{ nullptr, 0, 0, 0 }, 0 }, { entry_k2mw<TileCfg<14, 1024, 32768>, 1, 4, 2, 3, 3, 2>(), 4 } },
 };
 /* measured (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box): level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12
  * four stages +5.5 / +6.6 / +5 % (one LDS pass, or one of its stages, less) */
-constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4 };
+constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4, 4 };
 inline const Tile2MEntry &tile2m_entry(uint32_t level)
 {
 	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;

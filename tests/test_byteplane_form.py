@@ -14,7 +14,7 @@ import pytest
 from helpers import make_stream
 from libacm_amd import capi
 
-LEVELS = [7, 8, 9, 10, 11, 12, 13]
+LEVELS = [7, 8, 9, 10, 11, 12, 13, 14]
 
 
 def test_levels_with_a_byteplane_form():
@@ -22,7 +22,7 @@ def test_levels_with_a_byteplane_form():
     for level in range(16):
         tr = L.acmhip_mform_tile_rows(level)
         if level in LEVELS:
-            assert tr == {12: 4, 13: 2}.get(level, 8192 >> level)
+            assert tr == {12: 4, 13: 2, 14: 2}.get(level, 8192 >> level)
             assert L.acmhip_mform_bytes(level, 10) == 10 * (2 << level) + (1 << level) + 64
             assert L.acmhip_mform_group(level) in (8, 16)
         else:

@@ -10,7 +10,7 @@ from libacm_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-LEVELS = [7, 8, 9, 10, 11, 12, 13]
+LEVELS = [7, 8, 9, 10, 11, 12, 13, 14]
 
 
 @pytest.fixture
@@ -90,7 +90,7 @@ def test_byteplane_every_filler_code(dev, force_k2):
     valid = [0] + list(range(3, 17)) + [17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29]
     files = []
     for j, code in enumerate(valid):
-        lv = 7 + j % 7
+        lv = 7 + j % 8
         files.append(make_stream(24000 + j, lv, 16, 3 * tile_rows(lv) // 16 + 2, mix=2, single_code=code, pwr_min=15 if 3 <= code <= 16 else 4,
                                  pwr_max=15 if 3 <= code <= 16 else 12))
     check(dev, files)
@@ -209,7 +209,7 @@ from helpers import make_stream, oracle_pcm
 from libacm_amd import capi
 dev = capi.Device(0)
 bad = 0
-for level in range(7, 14):
+for level in range(7, 15):
     assert capi.lib().acmhip_mform_group(level) == (16 if (%d == 4 and level >= 8) or level >= 13 else 8)
     tr = max(capi.lib().acmhip_mform_tile_rows(level), 4)
     for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
