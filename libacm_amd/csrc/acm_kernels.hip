@@ -1371,6 +1371,11 @@ struct FirstPassM {
 			f(std::integral_constant<uint32_t, ACMHIP_BP_NIBBLE>{});
 	}
 
+	/* what every row pair of a wave needs from the tables, fetched once per tile */
+	struct Pre {
+		Operand a[NM];
+		v4i_t kc[NM];
+	};
 	static constexpr int pair_of(int k) { return MANYG ? 0 : k / NGRP; }                    /* relative to the wave's first row pair */
 	static constexpr int grp_of(int k) { return MANYG ? k : k % NGRP; }                     /* relative to the wave's first group */
 	static __device__ __forceinline__ int pair0(const int tid) { return MANYG ? (tid >> 6) / WPP : (tid >> 6) * (NU / (MANYG ? 1 : NGRP)); }
@@ -1566,7 +1571,7 @@ struct FirstPassM {
 	/* the units of row pair PP when its four input rows share one val and one width CLS: the multiply moves behind the matrix */
 	template <int PP, uint32_t CLS, int... Js>
 	static __device__ __forceinline__ void fast_pair(const Raw &raw, uint32_t *const o0, const bool nothing_in_front, const int lane, const bool owns0,
-							 const Tables &t, const int32_t val, std::integer_sequence<int, Js...>)
+							 const Tables &t, const Pre &pre, const int32_t val, std::integer_sequence<int, Js...>)
 	{
 		constexpr int PS = C::PS;
 		const int rs = lane >> 4;
@@ -1576,8 +1581,8 @@ struct FirstPassM {
 			constexpr bool with_bias = grp_of(k) == 0;
 #pragma unroll
 			for (int mt = 0; mt < NM; mt++) {
-				const Operand a = t.a[mt][lane];
-				const v4i_t d = mfma(a, plane_lo(raw, k, CLS), k_of(CLS, t.kc[mt][rs]));
+				const Operand a = pre.a[mt];
+				const v4i_t d = mfma(a, plane_lo(raw, k, CLS), k_of(CLS, pre.kc[mt]));
 				const v4i_t c = CLS == ACMHIP_BP_WORD ? join(d, mfma(a, plane_hi(raw, k), zero)) : settle(d);
 				v4i_t y = with_bias ? t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4] : zero;
 				scale4<with_bias>(y, c, val);
@@ -1596,8 +1601,8 @@ struct FirstPassM {
 	/* rowval[lr + 2] = val << SHIFT of tile row lr (rows -2, -1 of a stream's first tile: row 0's; the stager put a pair of zeros there) */
 	template <int PP, int... Js>
 	static __device__ __forceinline__ void run_pair(const Raw &raw, uint32_t *const o0, const int32_t *rv, const bool nothing_in_front, const int lane,
-							const bool owns0, const Tables &t, const uint32_t clsF, const uint32_t clsC, const bool one_val_one_width,
-							const bool halves_uniform, std::integer_sequence<int, Js...>)
+							const bool owns0, const Tables &t, const Pre &pre, const uint32_t clsF, const uint32_t clsC,
+							const bool one_val_one_width, const bool halves_uniform, std::integer_sequence<int, Js...>)
 	{
 		constexpr int PS = C::PS;
 		const int rs = lane >> 4;
@@ -1606,7 +1611,7 @@ struct FirstPassM {
 			/* one val over all four rows, one width (the usual case): the width is decided once per pair, its units are straight-line code */
 			const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]);
 			by_class(clsC, [&](auto cc) {
-				fast_pair<PP, decltype(cc)::value>(raw, o0, nothing_in_front, lane, owns0, t, vc, std::integer_sequence<int, Js...>{});
+				fast_pair<PP, decltype(cc)::value>(raw, o0, nothing_in_front, lane, owns0, t, pre, vc, std::integer_sequence<int, Js...>{});
 			});
 			return;
 		}
@@ -1639,7 +1644,7 @@ struct FirstPassM {
 				constexpr bool with_bias = grp_of(k) == 0;
 #pragma unroll
 				for (int mt = 0; mt < NM; mt++) {
-					const Operand a = t.a[mt][lane];
+					const Operand a = pre.a[mt];
 					v4i_t c1, c2;
 					by_class(clsF, [&](auto cc) { constexpr uint32_t CLS = decltype(cc)::value; c1 = product(masked(a, rs < 2), k, CLS, k_of(CLS, t.khalf[0][mt][rs])); });
 					by_class(clsC, [&](auto cc) { constexpr uint32_t CLS = decltype(cc)::value; c2 = product(masked(a, rs >= 2), k, CLS, k_of(CLS, t.khalf[1][mt][rs])); });
@@ -1657,7 +1662,7 @@ struct FirstPassM {
 				constexpr bool with_bias = grp_of(k) == 0;
 #pragma unroll 1
 				for (int mt = 0; mt < NM; mt++) {
-					const Operand a = t.a[mt][lane];
+					const Operand a = t.a[mt][lane];         /* (mt is a run-time value in this loop) */
 					v4i_t y = with_bias ? bias(mt) : zero;
 #pragma unroll 1
 					for (int r = 0; r < 4; r++) {
@@ -1683,7 +1688,7 @@ struct FirstPassM {
 	}
 	template <int... PPs>
 	static __device__ __forceinline__ void run_pairs(const Raw &raw, uint32_t *const o0, const int32_t *rv0, const bool missing, const int lane, const bool owns0,
-							 const Tables &t, const Desc &d, std::integer_sequence<int, PPs...>)
+							 const Tables &t, const Pre &pre, const Desc &d, std::integer_sequence<int, PPs...>)
 	{
 		/* which path each row pair takes, decided for all of them at once with one lane per pair: lane j looks at the four row values of
 		 * pair j and at whether its width differs from the width in front of it; two ballots later a pair's decision is one scalar bit test
@@ -1697,7 +1702,7 @@ struct FirstPassM {
 		const uint32_t within = (uint32_t)((a ^ b) | (c ^ e)), between = (uint32_t)(b ^ c) | ((width_change >> j) & 1u);
 		const uint32_t fast_mask = (uint32_t)__builtin_amdgcn_ballot_w64((within | between) == 0);
 		const uint32_t halves_mask = (uint32_t)__builtin_amdgcn_ballot_w64(within == 0);
-		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, d.e[PPs] & 3u, d.e[PPs + 1] & 3u, (fast_mask >> PPs) & 1u,
+		(run_pair<PPs>(raw, o0, rv0 + 2 * PPs, missing && PPs == 0, lane, owns0, t, pre, d.e[PPs] & 3u, d.e[PPs + 1] & 3u, (fast_mask >> PPs) & 1u,
 			       (halves_mask >> PPs) & 1u, std::make_integer_sequence<int, UPP>{}), ...);
 	}
 	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t,
@@ -1712,7 +1717,13 @@ struct FirstPassM {
 		const int q_lane = (4 * rs) % QN, row_lane = (4 * rs) / QN;
 		uint32_t *const o0 = tile + lds_at<PS>(2 * p0 * COLS + g0 * 16) + n + row_lane * (COLS + (COLS >> PS)) + (q_lane * SIGMA + ((q_lane * SIGMA) >> PS));
 		const bool missing = fresh_stream && __builtin_amdgcn_readfirstlane(p0) == 0;     /* the wave's first row pair has nothing in front of it */
-		run_pairs(raw, o0, rowval + 2 * p0, missing, lane, owns0, t, d, std::make_integer_sequence<int, NPW>{});
+		Pre pre;
+#pragma unroll
+		for (int mt = 0; mt < NM; mt++) {
+			pre.a[mt] = t.a[mt][lane];
+			pre.kc[mt] = t.kc[mt][rs];
+		}
+		run_pairs(raw, o0, rowval + 2 * p0, missing, lane, owns0, t, pre, d, std::make_integer_sequence<int, NPW>{});
 	}
 };
 
