@@ -238,7 +238,9 @@ int  acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8
 		       uint64_t *bytes_used);
 /* the inverse, for tests and tools (blob = the arena's base) */
 int  acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const acmhip_mform_pair *pairs, uint64_t nrows, int16_t *idx);
-/* device arena and pair table the byte-plane tiles of this plan are read from by every later launch (both NULL: back to the int16 form) */
+/* device arena and pair table the byte-plane tiles of this plan are read from by every later launch (both NULL: back to the int16 form).
+ * The table must be readable 32 entries past its last one (the kernel fetches entries in groups through the scalar cache), the arena
+ * 64 bytes past the last pair (acmhip_mform_rows leaves that slack behind every block it writes). */
 int  acmhip_plan_bind_mform(acmhip_plan *plan, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs);
 
 /* introspection for benchmarks/tests */
