@@ -1568,6 +1568,21 @@ struct FirstPassM {
 		return v4i_t{ -(k16[0] >> 4), -(k16[1] >> 4), -(k16[2] >> 4), -(k16[3] >> 4) };
 	}
 
+	/* the lane's four outputs of output tile mt of unit k into the LDS tile.  Output 16 mt + 4 rs + i of a unit is row (16 mt + 4 rs) / QN of
+	 * the pair, column q = (16 mt + 4 rs) % QN + i of the lane's residue; o0 already names rs and the residue (run()).  G = 4: one output tile
+	 * per row of the pair; G = 3: the one tile is both rows */
+	static __device__ __forceinline__ void put_outputs(uint32_t *const o0, const int k, const int mt, const v4i_t y)
+	{
+		constexpr int PS = C::PS;
+		constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;
+		uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
+		if (QN >= 16)
+			o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
+	}
+
 	/* the units of row pair PP when its four input rows share one val and one width CLS: the multiply moves behind the matrix */
 	template <int PP, uint32_t CLS, int... Js>
 	static __device__ __forceinline__ void fast_pair(const Raw &raw, uint32_t *const o0, const bool nothing_in_front, const int lane, const bool owns0,
@@ -1586,13 +1601,7 @@ struct FirstPassM {
 				const v4i_t c = CLS == ACMHIP_BP_WORD ? join(d, mfma(a, plane_hi(raw, k), zero)) : settle(d);
 				v4i_t y = with_bias ? t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4] : zero;
 				scale4<with_bias>(y, c, val);
-				constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;
-				uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
-				if (QN >= 16)
-					o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
-#pragma unroll
-				for (int i = 0; i < 4; i++)
-					o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
+				put_outputs(o0, k, mt, y);
 			}
 		};
 		(unit(std::integral_constant<int, Js>{}), ...);
@@ -1619,16 +1628,7 @@ struct FirstPassM {
 		const int32_t vc = __builtin_amdgcn_readfirstlane(rv[2]), vd = __builtin_amdgcn_readfirstlane(rv[3]);      /* rows 2P, 2P+1 */
 		/* the "+1" only reaches the lane that owns residue 0, in the unit of group 0 (the pair's first unit, if this wave has it) */
 		auto bias = [&](int mt) { return t.bias[nothing_in_front ? 1 : 0][mt][owns0 ? rs : 4]; };
-		/* output 16 mt + 4 rs + i of the unit: row (16 mt + 4 rs) / QN of the pair, column q = (16 mt + 4 rs) % QN + i of the residue */
-		auto store = [&](int k, int mt, const v4i_t y) {
-			constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;      /* output tiles per row of the pair: 1 (G = 4); G = 3: one tile = both rows */
-			uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
-			if (QN >= 16)
-				o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-				o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
-		};
+		auto store = [&](int k, int mt, const v4i_t y) { put_outputs(o0, k, mt, y); };
 		/* one matrix pass over the operand's low plane and, at 16 bits, its high plane */
 		auto product = [&](const Operand a, const int k, const uint32_t cls, const v4i_t k0) -> v4i_t {
 			const v4i_t d = mfma(a, plane_lo(raw, k, cls), k0);
@@ -1673,14 +1673,7 @@ struct FirstPassM {
 						});
 						scale4<true>(y, c, r == 0 ? va : (r == 1 ? vb : (r == 2 ? vc : vd)));
 					}
-					/* (mt is a run-time value here: the same address arithmetic as store(), spelled out) */
-					constexpr int per_row = QN / 16 > 0 ? QN / 16 : 1;
-					uint32_t *o = o0 + pair_of(k) * (2 * COLS + ((2 * COLS) >> PS)) + (16 * grp_of(k) + ((16 * grp_of(k)) >> PS));
-					if (QN >= 16)
-						o += (mt / per_row) * (COLS + (COLS >> PS)) + ((mt % per_row) * 16 * SIGMA + (((mt % per_row) * 16 * SIGMA) >> PS));
-#pragma unroll
-					for (int i = 0; i < 4; i++)
-						o[i * SIGMA + ((i * SIGMA) >> PS)] = (uint32_t)y[i];
+					store(k, mt, y);
 				}
 			};
 			(unit(std::integral_constant<int, Js>{}), ...);
