@@ -804,6 +804,14 @@ def main():
                             "samples_max_over_mean": round(max(sm) / (sum(sm) / len(sm)), 4)}
     if other_forms:
         out["other_staged_forms"] = other_forms
+        if mf:
+            # north_star says "no MFMA"; VERDICT r3 (task 8) allowed the matrix-core first pass as an experiment to keep if it wins.  The
+            # headline is that build; the same streams on the int16 form run the vector-ALU build of the same kernel - its figure, measured
+            # in this run, sits right beside the headline's for whoever wants to price the path without the matrix cores
+            i16 = [o for o in other_forms if o["form"].startswith("int16")]
+            if i16:
+                out["roofline"]["frac_vector_alu_build_int16_form"] = i16[0]["frac"]
+                out["roofline"]["launch_ms_vector_alu_build_int16_form"] = i16[0]["launch_ms"]
     if sustained:
         out["sustained"] = sustained
     if power:
