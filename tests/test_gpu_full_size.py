@@ -31,26 +31,33 @@ def test_full_size_config_2(dev):
     assert len(b.descs) == 4000 and {d.level for d in b.descs} == {7, 8, 9} and b.samples > 1_800_000_000
     with ThreadPoolExecutor(max_workers=threads) as ex:
         want = list(ex.map(lambda k: oracle_crc(b.files[k], b.descs[k].n_emit), range(4000)))
-    # (a) one plan over the staged arena
+    # (a) one plan over the staged arena: on the int16 form, then with the byte-plane form of the whole tiles bound (first pass on the
+    # matrix cores; the ragged tails stay int16)
     bufs = b.upload(dev)
+    mf = capi.mform_streams(b.idx, b.descs, threads=threads)
+    mf_ptrs = mf.upload(dev)
     try:
-        plan = capi.Plan(dev, b.descs)
+        plan = capi.Plan(dev, b.descs, packed=mf.streams)
         st = plan.stats()
-        assert st.fused_streams == 4000 and st.stagewise_streams == 0 and st.samples == b.samples
-        plan.launch(*bufs)
-        dev.sync()
-        host = np.empty(b.pcm_words, dtype=np.uint16)
-        dev.download(host, bufs[2])
+        assert st.fused_streams == 4000 and st.stagewise_streams == 0 and st.samples == b.samples and st.mform_tiles > 100000
+        for bind in ((None, None), mf_ptrs):
+            plan.bind_mform(*bind)
+            dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+            plan.launch(*bufs)
+            dev.sync()
+            host = np.empty(b.pcm_words, dtype=np.uint16)
+            dev.download(host, bufs[2])
+            raw = host.view(np.uint8)
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                got = list(ex.map(lambda k: zlib.crc32(raw[2 * b.descs[k].pcm_off: 2 * (b.descs[k].pcm_off + b.descs[k].n_emit)]), range(4000)))
+            bad = [k for k in range(4000) if got[k] != want[k]]
+            assert not bad, (bind[0] is not None, bad[:10])
+            del host, raw
         plan.destroy()
     finally:
-        for p in bufs:
+        for p in bufs + mf_ptrs:
             dev.free(p)
-    raw = host.view(np.uint8)
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        got = list(ex.map(lambda k: zlib.crc32(raw[2 * b.descs[k].pcm_off: 2 * (b.descs[k].pcm_off + b.descs[k].n_emit)]), range(4000)))
-    bad = [k for k in range(4000) if got[k] != want[k]]
-    assert not bad, bad[:10]
-    del host, raw
+    del mf
     # (b) the batch front end, device-side bit parsing
     files = [f.tobytes() for f in b.files]
     res, tm = capi.batch_decode(dev, files, parse=capi.PARSE_DEVICE)
@@ -81,24 +88,31 @@ def test_full_size_config_4(dev):
     d_idx, d_hdr, d_pcm0 = b.upload(dev)
     dev.free(d_pcm0)
     d_pcm = dev.malloc(len(descs) * pad * 2)
+    # the byte-plane form of the 1024 distinct streams; the replicas name the same pair-table entries
+    mf = capi.mform_streams(b.idx, b.descs, threads=threads)
+    mf_ptrs = mf.upload(dev)
     try:
-        plan = capi.Plan(dev, descs)
+        plan = capi.Plan(dev, descs, packed=[mf.streams[k % distinct] for k in range(len(descs))])
         st = plan.stats()
-        assert st.samples == 65536 * per and st.fused_streams == 65536
-        plan.launch(d_idx, d_hdr, d_pcm)
-        dev.sync()
-        # read back replica by replica (1024 streams = 537 MB each)
-        slab = np.empty(distinct * pad, dtype=np.uint16)
-        for r in range(reps):
-            dev.download(slab, d_pcm + 2 * r * distinct * pad)
-            raw = slab.view(np.uint8)
-            with ThreadPoolExecutor(max_workers=threads) as ex:
-                got = list(ex.map(lambda k: zlib.crc32(raw[2 * k * pad: 2 * (k * pad + per)]), range(distinct)))
-            bad = [k for k in range(distinct) if got[k] != want[k]]
-            assert not bad, (r, bad[:10])
+        assert st.samples == 65536 * per and st.fused_streams == 65536 and st.mform_tiles == 65536 * 128 // 4
+        for bind in ((None, None), mf_ptrs):                  # the int16 form (vector-ALU first pass), then the byte-plane form
+            plan.bind_mform(*bind)
+            plan.launch(d_idx, d_hdr, d_pcm)
+            dev.sync()
+            # read back replica by replica (1024 streams = 537 MB each)
+            slab = np.empty(distinct * pad, dtype=np.uint16)
+            for r in range(reps):
+                dev.download(slab, d_pcm + 2 * r * distinct * pad)
+                raw = slab.view(np.uint8)
+                with ThreadPoolExecutor(max_workers=threads) as ex:
+                    got = list(ex.map(lambda k: zlib.crc32(raw[2 * k * pad: 2 * (k * pad + per)]), range(distinct)))
+                bad = [k for k in range(distinct) if got[k] != want[k]]
+                assert not bad, (bind[0] is not None, r, bad[:10])
+                if r == 0:
+                    dev.upload(d_pcm, np.zeros(1 << 20, dtype=np.uint16))       # the next form must write this again
         plan.destroy()
     finally:
-        for p in (d_idx, d_hdr, d_pcm):
+        for p in (d_idx, d_hdr, d_pcm) + mf_ptrs:
             dev.free(p)
 
 

@@ -171,9 +171,11 @@ def test_header_extremes(dev, level, rows, blocks, carry, monkeypatch):
             assert res[0][0] == wst and np.array_equal(res[0][1], want), parse
 
 
-def test_full_size_config_1(dev):
+@pytest.mark.parametrize("form", ["int16", "byteplane"])
+def test_full_size_config_1(dev, form):
     """BASELINE.json configs[1] at its full size - 1024 mono streams, level 7, 16 rows, 1000 blocks each (2.1 Gsamples) -
-    through one plan, every stream's PCM compared with the CPU oracle by CRC-32 (the oracle side runs on all host cores)"""
+    through one plan, every stream's PCM compared with the CPU oracle by CRC-32 (the oracle side runs on all host cores);
+    once on the int16 staged form (vector-ALU first pass), once on the byte-plane form (first pass on the matrix cores)"""
     import zlib
     from concurrent.futures import ThreadPoolExecutor
     import oracle_api as O
@@ -181,15 +183,23 @@ def test_full_size_config_1(dev):
     threads = max(4, min(64, workload.usable_cpus()))
     b = workload.build_uniform(1024, 7, 16, 1000, keep_files=1 << 30, threads=threads)
     bufs = b.upload(dev)
+    extra = ()
     try:
-        plan = capi.Plan(dev, b.descs)
+        if form == "byteplane":
+            mf = capi.mform_streams(b.idx, b.descs, threads=threads)
+            extra = mf.upload(dev)
+            plan = capi.Plan(dev, b.descs, packed=mf.streams)
+            plan.bind_mform(*extra)
+            assert plan.stats().mform_tiles == 1024 * 1000 * 16 // 64
+        else:
+            plan = capi.Plan(dev, b.descs)
         plan.launch(*bufs)
         dev.sync()
         host = np.empty(b.pcm_words, dtype=np.uint16)
         dev.download(host, bufs[2])
         plan.destroy()
     finally:
-        for p in bufs:
+        for p in bufs + tuple(extra):
             dev.free(p)
     raw = host.view(np.uint8)
 
