@@ -33,6 +33,7 @@ extern "C" {
 #define ACMHIP_ERR_HIP       -102   /* a HIP call failed; see acmhip_last_error() */
 #define ACMHIP_ERR_ARG       -103   /* invalid argument */
 #define ACMHIP_ERR_NOMEM     -104
+#define ACMHIP_ERR_RANGE     -105   /* the input cannot be put into the form asked for (acmhip_mform_rows); nothing is wrong with it */
 
 /* output sample layouts = the four writers of decode.c:617-655 */
 #define ACMHIP_FMT_S16LE 0u

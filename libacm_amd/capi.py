@@ -15,6 +15,7 @@ from . import _build
 FMT_S16LE, FMT_S16BE, FMT_U16LE, FMT_U16BE = 0, 1, 2, 3
 PLAN_AUTO, PLAN_STAGEWISE = 0, 1
 ERR_NO_DEVICE = -101
+ERR_RANGE = -105
 
 
 class BlkHdr(C.Structure):
@@ -320,8 +321,12 @@ def mform_streams(idx, descs, threads=1):
             d = descs[i]
             buf = np.empty(cap[i], dtype=np.uint8)
             used = C.c_uint64()
-            _check(L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], buf.ctypes.data, 0, pairs[p_at[i]:].ctypes.data,
-                                       C.byref(used)), "acmhip_mform_rows")
+            rc = L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], buf.ctypes.data, 0, pairs[p_at[i]:].ctypes.data,
+                                     C.byref(used))
+            if rc == ERR_RANGE:                 # an index the form cannot hold (>= 32640 at a level of the chunk kernel): the stream stays int16
+                ntiles[i] = 0
+                return
+            _check(rc, "acmhip_mform_rows")
             parts[i] = buf[:(used.value + 63) // 64 * 64]
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
         list(ex.map(one, range(n)))

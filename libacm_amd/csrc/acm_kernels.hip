@@ -615,6 +615,21 @@ struct TileCtx {
 /* bit of the ABL template argument that is not an ablation: the first pass reads an int32 plane (stages already applied by
  * the stage-wise kernels: levels 13-15) instead of staged indices - no unpack multiply, no "+1" */
 constexpr int MODE_PLANE = 64;
+/* another one: the tile belongs to ONE wavefront (acm_chunk) - the LDS operations of a wavefront are carried out in the order they were
+ * issued, so what orders its lanes among themselves is the order of the instructions: no workgroup barrier, only a fence the compiler
+ * may not move LDS accesses across */
+constexpr int MODE_WAVE = 128;
+template <int ABL>
+__device__ __forceinline__ void tile_barrier()
+{
+	if constexpr ((ABL & MODE_WAVE) != 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	} else if constexpr (!(ABL & 32)) {
+		__syncthreads();
+	}
+}
 
 template <class C, int G, int W, int ABL = 0, bool FORCE_WARM = false>
 struct FirstPass {
@@ -798,8 +813,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 	 * segment's owner, who is about to overwrite them in place - read them
 	 * first, then everybody may start walking.  Segment 0 reads the zeroed guard
 	 * zone in front of the tile (history before the tile = zeros). */
-	if (!(ABL & 32))
-		__syncthreads();
+	tile_barrier<ABL>();
 	uint32_t w[BODY];
 	constexpr int NTAIL = CARRY ? (BS + C::NT - 1) / C::NT : 1;     /* carried elements per thread (1 for every default geometry) */
 	uint32_t tail[NTAIL];
@@ -820,8 +834,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 		for (int u = 0; u < BODY; u++)
 			w[u] = pw[P::off(u)];
 	}
-	if (!(ABL & 32))
-		__syncthreads();
+	tile_barrier<ABL>();
 	if constexpr (CARRY) {
 #pragma unroll
 		for (int k = 0; k < NTAIL; k++) {
@@ -1901,6 +1914,364 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// K3: the chunk kernel - six stages on the matrix cores, one wavefront per chunk, no workgroup barrier
+// ---------------------------------------------------------------------------
+/*
+ * What bounded acm_tile2 with its first three stages on the matrix cores (profiles/r4_level9_summary.txt) was no longer instruction issue
+ * and not yet memory: a third of the wave time parked at workgroup barriers and waits, the LDS pipe busy 57 % of the launch.  Both come from
+ * the LDS passes.  This kernel removes one of them and every barrier:
+ *
+ * Six stages at once.  Over one residue class of the columns (columns c + q * cols / 64, q < 64) the first six stages of juggle_block
+ * (decode.c:528-577) are a block-Toeplitz operator over ROWS: out[r] = T0 x[r] + T1 x[r - 1] + T2 x[r - 2], three 64 x 64 integer matrices
+ * with |coefficient| <= 64 (tools/gen_mfma_tables.py; the stages' signs repeat with the row and their reach, 126 positions, stays inside two
+ * rows).  val is constant over a block, so as in acm_tile2's matrix build the multiply moves behind the matrix and the operands are the
+ * staged INDICES as signed bytes: v_mfma_i32_16x16x64_i8 with A = indices (16 instances = residue classes x row walkers; lane l: instance
+ * l % 16, columns q = 16 (l / 16) ...), B = coefficients (lane l: output q = 16 mt + l % 16) and D = four consecutive instances of one
+ * output per lane - four ADJACENT COLUMNS, which go to the LDS tile without a bank conflict.  A 16-bit index is idx = 256 hi + lo with
+ * BOTH bytes signed (the byte-plane form of this kernel's levels, acm_pack.cpp): two matrix passes, joined behind the multiply.
+ *
+ * One wavefront per chunk.  What is left is ONE LDS pass (level 9: stages 6-8, stride <= 4), and with 32 consecutive elements per lane
+ * its walks never leave the 2048 elements a wavefront has just produced: a chunk of 2048 samples (4 rows at level 9) is produced, finished
+ * and stored by ONE wavefront.  The LDS operations of a wavefront are carried out in issue order, so nothing in the loop needs a barrier;
+ * the sixteen wavefronts of a workgroup share nothing but the coefficient tables (12 KB of LDS, which is why the workgroup is the CU) and
+ * drift apart by themselves, which is what the phase priorities want.  The first pass is stateless (it re-reads the two rows in front of
+ * its walk, like FirstPassM); the last pass takes its 16-element history from the previous chunk through a carry buffer of the
+ * wavefront's own, as every LDS pass of acm_tile2 does.
+ */
+#include "acm_toeplitz_tables.inc"
+
+template <int L_>
+struct FirstPassZ {
+	using C = TileCfg<L_, 64, 2048>;                        /* what ONE wavefront holds in LDS: 2048 elements, 32 per lane in the last pass */
+	static constexpr int L = L_, COLS = C::COLS, TR = C::TR, PS = C::PS;
+	static constexpr int G = 6, QN = 1 << G, SIGMA = COLS / QN;            /* QN columns of a residue class per row, SIGMA classes */
+	static_assert(SIGMA == 8 || SIGMA == 16, "sixteen instances per matrix instruction: the classes of one row, or of two");
+	static constexpr int RR = 16 / SIGMA;                   /* row walkers among the instances */
+	static constexpr int NS = TR / RR;                      /* rows a walker walks = matrix "sets" per chunk */
+	static constexpr int NX = NS + 2;                       /* rows a lane loads: its walk and the two rows in front of it */
+	static constexpr int NE = RR + 1;                       /* pair-table entries a chunk reads: the pair in front and its own */
+	static constexpr int NM = QN / 16;                      /* output tiles per row */
+	static_assert(NS == 2 && NX == 4 && TR == 2 * RR, "a walker walks one row pair");
+	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
+
+	struct Raw { v4u_t lo[NX], hi[NX]; };
+	struct Desc { uint32_t e[NE]; };
+	struct Tables {
+		v4i_t coef[3][NM][64];          /* [j][mt][lane]: T_j[16 mt + lane % 16][16 (lane / 16) .. + 15] */
+		int32_t bias[3][2][QN];         /* [rows in front that exist][lane owns residue 0: 0, else 1][q], scaled */
+	};
+
+	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid, const int nthreads)
+	{
+		constexpr int32_t ONE = 1 << OutScale<L>::SHIFT;
+		for (int k = tid; k < 3 * NM * 64; k += nthreads) {
+			const int j = k / (NM * 64), mt = (k / 64) % NM, lane = k % 64;
+			t.coef[j][mt][lane] = *reinterpret_cast<const v4i_t *>(&ACM_TZ6[VARIANT][j][16 * mt + (lane & 15)][16 * (lane >> 4)]);
+		}
+		for (int k = tid; k < 3 * 2 * QN; k += nthreads) {
+			const int var = k / (2 * QN), par = (k / QN) & 1, q = k % QN;
+			t.bias[var][par][q] = par ? 0 : ACM_TZ6_BIAS[VARIANT][var][q] * ONE;
+		}
+	}
+
+	static __device__ __forceinline__ Desc fetch_desc(const uint32_t *__restrict__ pairs, const AcmTile2 &r)
+	{
+		Desc d;
+		const uint32_t at = __builtin_amdgcn_readfirstlane((uint32_t)r.idx_off);        /* the entry of the pair in front of the chunk */
+#pragma unroll
+		for (int j = 0; j < NE; j++)
+			d.e[j] = pairs[at + j];
+		return d;
+	}
+
+	/* the loads of one chunk: lane l = (instance i = l % 16: class c = i % SIGMA, walker i / SIGMA; columns 16 (l / 16) .. + 15 of the class)
+	 * asks for 16 low bytes and, 64 bytes on, 16 high bytes of each of its four rows (a pair at 8 bits has no high bytes: what comes
+	 * back instead is never used, see run()) */
+	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane)
+	{
+		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4, c = i % SIGMA, rr = i / SIGMA;
+		const uint32_t e0 = d.e[0];
+		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
+		uint32_t ea = d.e[0], eb = d.e[1];
+		if constexpr (RR == 2) {
+			ea = rr ? d.e[1] : d.e[0];
+			eb = rr ? d.e[2] : d.e[1];
+		}
+		const uint32_t sha = (ea & 3u) - ACMHIP_BP_BYTE, shb = (eb & 3u) - ACMHIP_BP_BYTE;      /* 0: a byte per index, 1: two */
+		const uint32_t pa = (((ea >> 2) - (e0 >> 2)) << 6) + ((c * (uint32_t)QN) << sha) + 16u * ks;
+		const uint32_t pb = (((eb >> 2) - (e0 >> 2)) << 6) + ((c * (uint32_t)QN) << shb) + 16u * ks;
+		const uint32_t v0 = pa, v1 = pa + ((uint32_t)COLS << sha), v2 = pb, v3 = pb + ((uint32_t)COLS << shb);
+#define ACM_Z_LOAD(K, V) \
+		asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[K]) : "v"(V), "s"(base) : "memory"); \
+		asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(raw.hi[K]) : "v"(V), "s"(base) : "memory")
+		ACM_Z_LOAD(0, v0);
+		ACM_Z_LOAD(1, v1);
+		ACM_Z_LOAD(2, v2);
+		ACM_Z_LOAD(3, v3);
+#undef ACM_Z_LOAD
+	}
+	static constexpr int NLOAD = 2 * NX;
+
+	static __device__ __forceinline__ v4i_t mfma(const v4u_t data, const v4i_t coef, const v4i_t acc)
+	{
+		return __builtin_amdgcn_mfma_i32_16x16x64_i8((v4i_t)data, coef, acc, 0, 0, 0);
+	}
+
+	/*
+	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.
+	 * WORDS: some pair of the chunk is stored at 16 bits (hi_ok[k]: row k of this lane's four is - else its high bytes are not
+	 *        there and what was loaded in their place is replaced by zeros).
+	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
+	 *        and scaled one by one; else they are one accumulator chain and one multiply.
+	 */
+	/* v * c with both inside 24 bits.  (The library's __mul24 is plain arithmetic to the optimiser, which then turns val * hi * 256 + val * lo
+	 * into ONE multiply of val with a sum that no longer fits 24 bits - the quarter-rate v_mul_lo_u32; the opaque copy of val keeps
+	 * the two products apart.) */
+	static __device__ __forceinline__ int32_t opaque_s(int32_t v)
+	{
+		asm("" : "+s"(v));
+		return v;
+	}
+	static __device__ __forceinline__ int32_t opaque_v(int32_t v)
+	{
+		asm("" : "+v"(v));
+		return v;
+	}
+
+	/*
+	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.
+	 * WORDS: some pair of the chunk is stored at 16 bits (mask_a / mask_b: all ones where this lane's first / second loaded row pair is -
+	 *        else the pair has no high bytes, and what was loaded in their place counts as zeros).
+	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
+	 *        and scaled one by one; else they are one accumulator chain and one multiply.
+	 */
+	template <bool WORDS, bool SPLIT>
+	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
+						     const bool stream_start, const uint32_t mask_a, const uint32_t mask_b)
+	{
+		const v4i_t zero = { 0, 0, 0, 0 };
+		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker, output q = 16 mt + lane % 16 */
+		const uint32_t h = (uint32_t)lane >> 4, qd = (uint32_t)lane & 15u;
+		const uint32_t c0 = (4u * h) % SIGMA, rrd = (4u * h) / SIGMA;
+		const uint32_t m_lane = rrd * (uint32_t)(NS * COLS) + c0 + (uint32_t)SIGMA * qd;
+		uint32_t *o_lane = tile + (m_lane + (m_lane >> PS));
+		/* the "+1" of decode.c:561-564, six stages on: the lane that owns residue 0 adds it to its first output; rows in front of a
+		 * stream do not exist and add nothing */
+		uint32_t bias_at[NS];           /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
+#pragma unroll
+		for (int s = 0; s < NS; s++) {
+			const uint32_t row = rrd * NS + s;
+			bias_at[s] = ((stream_start && row < 2 ? row : 2u) * 2u + (c0 == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
+		}
+		const v4i_t *cf = &t.coef[0][0][lane];
+		/* val of the row this lane's outputs of set s, term j come from: chunk row rrd * NS + s - j */
+		auto val_of = [&](const int s, const int j) -> int32_t {
+			if constexpr (RR == 1)
+				return rowval[s - j + 2];
+			else
+				return rrd ? rowval[NS + s - j + 2] : rowval[s - j + 2];
+		};
+		v4u_t hi[NX];
+		if constexpr (WORDS) {
+#pragma unroll
+			for (int k = 0; k < NX; k++)
+				hi[k] = raw.hi[k] & (k < 2 ? mask_a : mask_b);
+		}
+#pragma unroll 1
+		for (int mt = 0; mt < NM; mt++) {
+			const v4i_t cf0 = cf[0], cf1 = cf[NM * 64], cf2 = cf[2 * NM * 64];
+#pragma unroll
+			for (int s = 0; s < NS; s++) {
+				/* rows of set s: x[r] = raw[s + 2], x[r - 1] = raw[s + 1], x[r - 2] = raw[s] */
+				v4i_t y;
+				const int32_t b = (&t.bias[0][0][0])[bias_at[s] + 16u * (uint32_t)mt];
+				if constexpr (!SPLIT) {
+					const int32_t val = rowval[2];
+					v4i_t lo = mfma(raw.lo[s + 2], cf0, zero);
+					lo = mfma(raw.lo[s + 1], cf1, lo);
+					lo = mfma(raw.lo[s], cf2, lo);
+					if constexpr (WORDS) {
+						const int32_t valh = opaque_s(val);
+						v4i_t hh = mfma(hi[s + 2], cf0, zero);
+						hh = mfma(hi[s + 1], cf1, hh);
+						hh = mfma(hi[s], cf2, hh);
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] = (int32_t)(((uint32_t)opaque_v(__mul24(hh[v], valh)) << 8) + (uint32_t)(__mul24(lo[v], val) + (v == 0 ? b : 0)));
+					} else {
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] = __mul24(lo[v], val) + (v == 0 ? b : 0);
+					}
+				} else {
+					const int32_t v0 = val_of(s, 0), v1 = val_of(s, 1), v2 = val_of(s, 2);
+					const v4i_t l0 = mfma(raw.lo[s + 2], cf0, zero), l1 = mfma(raw.lo[s + 1], cf1, zero), l2 = mfma(raw.lo[s], cf2, zero);
+					if constexpr (WORDS) {
+						const int32_t w0 = opaque_v(v0), w1 = opaque_v(v1), w2 = opaque_v(v2);
+						const v4i_t h0 = mfma(hi[s + 2], cf0, zero), h1 = mfma(hi[s + 1], cf1, zero), h2 = mfma(hi[s], cf2, zero);
+#pragma unroll
+						for (int v = 0; v < 4; v++) {
+							const int32_t yl = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
+							const int32_t yh = opaque_v(__mul24(h0[v], w0) + __mul24(h1[v], w1) + __mul24(h2[v], w2));      /* (or the shift moves into the vals) */
+							y[v] = (int32_t)(((uint32_t)yh << 8) + (uint32_t)yl);
+						}
+					} else {
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
+					}
+				}
+				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0, "the constant parts of the address are multiples of 32: the pad rule splits");
+				uint32_t *const o = o_lane + (s * COLS + ((s * COLS) >> PS));
+#pragma unroll
+				for (int v = 0; v < 4; v++)
+					o[v] = (uint32_t)y[v];
+			}
+			cf += 64;
+			o_lane += SIGMA * 16 + ((SIGMA * 16) >> PS);
+		}
+	}
+
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
+						   const Desc &d, const bool stream_start)
+	{
+		uint32_t any_word = 0;
+#pragma unroll
+		for (int j = 0; j < NE; j++)
+			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
+		bool one_val = true;
+#pragma unroll
+		for (int k = 1; k < TR + 2; k++)
+			one_val = one_val && rowval[k] == rowval[0];
+		if (any_word) {
+			const uint32_t rr = ((uint32_t)lane & 15u) / SIGMA;
+			uint32_t ea = d.e[0], eb = d.e[1];
+			if constexpr (RR == 2) {
+				ea = rr ? d.e[1] : d.e[0];
+				eb = rr ? d.e[2] : d.e[1];
+			}
+			const uint32_t mask_a = (ea & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u, mask_b = (eb & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+			if (one_val)
+				run_t<true, false>(raw, tile, t, lane, rowval, stream_start, mask_a, mask_b);
+			else
+				run_t<true, true>(raw, tile, t, lane, rowval, stream_start, mask_a, mask_b);
+		} else {
+			if (one_val)
+				run_t<false, false>(raw, tile, t, lane, rowval, stream_start, 0u, 0u);
+			else
+				run_t<false, true>(raw, tile, t, lane, rowval, stream_start, 0u, 0u);
+		}
+	}
+};
+
+/* Gs: the LDS passes behind the six matrix-core stages (they add up to level - 6) */
+template <int L_, int ABL, int... Gs>
+__global__ void __launch_bounds__(1024, 1)
+acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16_t *__restrict__ idx, const uint32_t *__restrict__ pairs,
+	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
+{
+	using FP = FirstPassZ<L_>;
+	using C = typename FP::C;
+	constexpr int L = L_, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST, NW = 16;
+	constexpr int WTILE = 8 + NELEM + (NELEM >> C::PS);
+	constexpr int NCARRY_WORDS = carry_total<C, FP::G, Gs...>();
+	constexpr int PASS_ABL = (ABL & ~MODE_WAVE) | MODE_WAVE;
+
+	__shared__ uint32_t tile_mem[NW][WTILE];
+	__shared__ uint32_t carry_all[NW][NCARRY_WORDS];
+	__shared__ typename FP::Tables tables;
+
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	FP::fill_tables(tables, threadIdx.x, NW * 64);
+	__syncthreads();                                /* the only one: the coefficient tables are shared */
+
+	uint32_t *const tile = tile_mem[wave] + 8;
+	uint32_t *const carry_mem = carry_all[wave];
+
+	/* a wavefront is a workgroup of its own from here on: a contiguous run of the chunk table */
+	const uint32_t nvw = gridDim.x * NW, vw = blockIdx.x * NW + wave;
+	const uint32_t per = (ntiles + nvw - 1) / nvw;
+	uint32_t t = vw * per;
+	const uint32_t t_end = t + per < ntiles ? t + per : ntiles;
+	if (t >= t_end)
+		return;
+	bool discard = false;
+	if (!(tiles[__builtin_amdgcn_readfirstlane(t)].flags & ACM_TILE_FRESH)) {
+		discard = true;                         /* a run that starts inside a stream replays the chunk in front of it without storing PCM */
+		t--;
+	}
+
+	/* row values: lane lr < TR + 2 fetches the val of chunk row lr - 2 (decode.c:589); every lane issues the load */
+	const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
+	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
+		const bool fr = (r.flags & ACM_TILE_FRESH) != 0;
+		const uint32_t q = r.rowpos + (fr ? (lr_fetch < 2 ? 0u : lr_fetch - 2) : lr_fetch);
+		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;
+		const uint32_t *p = &hdr[r.hdr_blk + b].val;
+		uint32_t v;
+		asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+		return v;
+	};
+
+	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / 64;
+	static_assert(NVEC % 64 == 0, "whole rounds");
+	const uint8_t *const arena = reinterpret_cast<const uint8_t *>(idx);
+	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
+	typename FP::Desc dcur = FP::fetch_desc(pairs, cur);
+	typename FP::Raw raw;
+	uint32_t hv = fetch_val(cur);
+	FP::issue(raw, arena, dcur, lane);
+	k2_wait<0>();
+	bool fresh = true;
+	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+	typename FP::Desc dnxt = FP::fetch_desc(pairs, nxt);
+	for (;;) {
+		const uint32_t tn = t + 1;
+		const bool more = tn < t_end;
+		if (fresh)
+			for (int k = lane; k < NCARRY_WORDS; k += 64)
+				carry_mem[k] = 0u;
+		int32_t rowval[TR + 2];
+#pragma unroll
+		for (int k = 0; k < TR + 2; k++)
+			rowval[k] = (int32_t)(__builtin_amdgcn_readlane(hv, k) << OutScale<L>::SHIFT);
+		phase_prio<true, PRIO_FIRST_PASS>();
+		FP::run(raw, tile, tables, lane, rowval, dcur, (cur.flags & ACM_TILE_FRESH) != 0);
+		phase_prio<true, PRIO_IDLE>();
+
+		hv = fetch_val(nxt);                            /* the last chunk of a run fetches its own again: no branch around the loads */
+		FP::issue(raw, arena, dnxt, lane);
+		phase_prio<true, PRIO_LDS_PASSES>();
+		run_lds_passes<C, PASS_ABL, true, FP::G, Gs...>(tile, lane, fmt, carry_mem);
+		tile_barrier<MODE_WAVE>();
+		{
+			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+			v4u *out = discard ? reinterpret_cast<v4u *>(sink) : reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
+#pragma unroll
+			for (int k = 0; k < NSTORE; k++) {
+				const int vec = lane + k * 64;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				const v4u o = { q[0], q[1], q[2], q[3] };
+				__builtin_nontemporal_store(o, &out[vec]);
+			}
+		}
+		phase_prio<true, PRIO_IDLE>();
+		k2_wait<NSTORE>();                              /* the next chunk's indices are here; only this chunk's PCM stores may still be on their way */
+		tile_barrier<MODE_WAVE>();                      /* (the next first pass overwrites what the stores have just read) */
+		if (!more)
+			break;
+		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
+		discard = false;
+		cur = nxt;
+		dcur = dnxt;
+		t = tn;
+		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+		dnxt = FP::fetch_desc(pairs, nxt);
+	}
+}
+
 struct Tile2Entry {
 	typedef void (*Fn)(const AcmTile2 *, uint32_t, const int16_t *, const uint32_t *, const acmhip_blkhdr *, int16_t *, int16_t *, unsigned);
 	Fn fn;
@@ -1994,8 +2365,28 @@ const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 /* measured (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box): level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12
  * four stages +5.5 / +6.6 / +5 % (one LDS pass, or one of its stages, less) */
 constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4, 4 };
+/* levels whose byte-plane tiles go to the chunk kernel (acm_chunk: six stages on the matrix cores, a wavefront per chunk of 2048 samples)
+ * unless ACM_K3=0 asks for acm_tile2's matrix build; the staged form follows the choice (64 columns of a residue class side by side) */
+template <int L, int... Gs>
+constexpr Tile2MEntry entry_k3()
+{
+	return Tile2MEntry{ Tile2Entry{ acm_chunk<L, 0, Gs...>, 1024, FirstPassZ<L>::TR, 1 }, 6 };
+}
+const Tile2MEntry g_chunk[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	entry_k3<9, 3>(),
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+};
 inline const Tile2MEntry &tile2m_entry(uint32_t level)
 {
+	static const bool k3 = !(getenv("ACM_K3") && atoi(getenv("ACM_K3")) == 0);
+	if (k3 && g_chunk[level - ACM_K2M_MIN_LEVEL].g0)
+		return g_chunk[level - ACM_K2M_MIN_LEVEL];
 	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;
 	const Tile2MEntry *row = g_tile2m[level - ACM_K2M_MIN_LEVEL];
 	const int want = forced ? forced : g_tile2m_default[level - ACM_K2M_MIN_LEVEL];

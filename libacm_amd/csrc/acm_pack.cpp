@@ -254,7 +254,7 @@ static const uint64_t kMformSlack = 64;
 extern "C" uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows)
 {
 	const uint64_t cols = 1ull << level;
-	return nrows * cols * 2 + cols + kMformSlack;           /* every pair at 16 bits, the pair of zeros in front at 4 */
+	return nrows * cols * 2 + 2 * cols + kMformSlack;       /* every pair at 16 bits, the pair of zeros in front at 4 bits or at 8 */
 }
 
 extern "C" uint64_t acmhip_mform_pairs(uint64_t nrows)
@@ -286,14 +286,15 @@ inline void transpose8x8(__m128i (&v)[8])
 	v[4] = _mm_unpacklo_epi64(b2, b6); v[5] = _mm_unpackhi_epi64(b2, b6);
 	v[6] = _mm_unpacklo_epi64(b3, b7); v[7] = _mm_unpackhi_epi64(b3, b7);
 }
-/* classes 2 and 3 of put_row for qn = 8 or 16 (sigma is a multiple of 16) */
-bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint8_t *dst)
+/* classes 2 and 3 of put_row for qn = 8, 16 or 64 (sigma is a multiple of 8).  split: the 16-bit class stores idx = 256 hi + lo with BOTH bytes
+ * signed (the chunk kernel's form, qn = 64); else the low byte minus 128 and the arithmetic high byte */
+bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, uint8_t *dst)
 {
-	if ((qn != 8 && qn != 16) || (sigma & 7) || (cls != ACMHIP_BP_WORD && cls != ACMHIP_BP_BYTE))
+	if ((qn != 8 && qn != 16 && qn != 64) || (sigma & 7) || (cls != ACMHIP_BP_WORD && cls != ACMHIP_BP_BYTE))
 		return false;
 	const __m128i flip = _mm_set1_epi16(0x0080), low = _mm_set1_epi16(0x00ff);
 	for (size_t c0 = 0; c0 < sigma; c0 += 8) {
-		__m128i t[2][8];
+		__m128i t[8][8];
 		for (size_t h = 0; h < qn / 8; h++) {
 			for (size_t q = 0; q < 8; q++)
 				t[h][q] = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + c0 + (8 * h + q) * sigma));
@@ -301,21 +302,29 @@ bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint
 		}
 		for (size_t c = 0; c < 8; c++) {
 			uint8_t *d = dst + (c0 + c) * (cls == ACMHIP_BP_WORD ? 2 * qn : qn);
-			const __m128i xa = t[0][c], xb = qn == 16 ? t[1][c] : _mm_setzero_si128();
-			if (cls == ACMHIP_BP_BYTE) {
-				const __m128i b = _mm_packs_epi16(xa, xb);                      /* every index in [-128, 127]: no saturation */
-				if (qn == 16)
-					_mm_storeu_si128(reinterpret_cast<__m128i *>(d), b);
-				else
-					_mm_storel_epi64(reinterpret_cast<__m128i *>(d), b);
-			} else {
-				const __m128i lo = _mm_packus_epi16(_mm_and_si128(_mm_xor_si128(xa, flip), low), _mm_and_si128(_mm_xor_si128(xb, flip), low));
-				const __m128i hi = _mm_packs_epi16(_mm_srai_epi16(xa, 8), _mm_srai_epi16(xb, 8));
-				if (qn == 16) {
-					_mm_storeu_si128(reinterpret_cast<__m128i *>(d), lo);
-					_mm_storeu_si128(reinterpret_cast<__m128i *>(d + 16), hi);
+			for (size_t h = 0; h < qn / 8; h += 2) {
+				const __m128i xa = t[h][c], xb = h + 1 < qn / 8 ? t[h + 1][c] : _mm_setzero_si128();
+				__m128i lo, hi;
+				if (cls == ACMHIP_BP_BYTE) {
+					lo = _mm_packs_epi16(xa, xb);                   /* every index in [-128, 127]: no saturation */
+					hi = lo;
+				} else if (split) {
+					const __m128i la = _mm_srai_epi16(_mm_slli_epi16(xa, 8), 8), lb = _mm_srai_epi16(_mm_slli_epi16(xb, 8), 8);       /* the low byte, signed */
+					lo = _mm_packs_epi16(la, lb);
+					hi = _mm_packs_epi16(_mm_srai_epi16(_mm_sub_epi16(xa, la), 8), _mm_srai_epi16(_mm_sub_epi16(xb, lb), 8));     /* (idx < 32640: no overflow, no saturation) */
 				} else {
-					_mm_storeu_si128(reinterpret_cast<__m128i *>(d), _mm_unpacklo_epi64(lo, hi));
+					lo = _mm_packus_epi16(_mm_and_si128(_mm_xor_si128(xa, flip), low), _mm_and_si128(_mm_xor_si128(xb, flip), low));
+					hi = _mm_packs_epi16(_mm_srai_epi16(xa, 8), _mm_srai_epi16(xb, 8));
+				}
+				if (qn == 8) {
+					if (cls == ACMHIP_BP_BYTE)
+						_mm_storel_epi64(reinterpret_cast<__m128i *>(d), lo);
+					else
+						_mm_storeu_si128(reinterpret_cast<__m128i *>(d), _mm_unpacklo_epi64(lo, hi));
+				} else {
+					_mm_storeu_si128(reinterpret_cast<__m128i *>(d + 8 * h), lo);
+					if (cls == ACMHIP_BP_WORD)
+						_mm_storeu_si128(reinterpret_cast<__m128i *>(d + qn + 8 * h), hi);
 				}
 			}
 		}
@@ -325,19 +334,25 @@ bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint
 #endif
 
 /* one row at width class cls: per residue c < sigma the qn indices of columns c + q * sigma */
-void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint8_t *dst)
+void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, uint8_t *dst)
 {
 #if defined(__SSE2__)
-	if (put_row_sse(src, sigma, qn, cls, dst))
+	if (put_row_sse(src, sigma, qn, cls, split, dst))
 		return;
 #endif
 	for (size_t c = 0; c < sigma; c++) {
 		if (cls == ACMHIP_BP_WORD) {
 			uint8_t *d = dst + c * 2 * qn;
 			for (size_t q = 0; q < qn; q++) {
-				const uint16_t x = (uint16_t)src[c + q * sigma];
-				d[q] = (uint8_t)(x ^ 0x80u);            /* low byte minus 128: a signed byte for the matrix instruction */
-				d[qn + q] = (uint8_t)(x >> 8);
+				const int x = src[c + q * sigma];
+				if (split) {
+					const int lo = (int8_t)(uint8_t)x;      /* idx = 256 hi + lo, both signed bytes */
+					d[q] = (uint8_t)lo;
+					d[qn + q] = (uint8_t)((x - lo) >> 8);
+				} else {
+					d[q] = (uint8_t)((uint16_t)x ^ 0x80u);  /* low byte minus 128: a signed byte for the matrix instruction */
+					d[qn + q] = (uint8_t)((uint16_t)x >> 8);
+				}
 			}
 		} else if (cls == ACMHIP_BP_BYTE) {
 			uint8_t *d = dst + c * qn;
@@ -358,13 +373,14 @@ void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, uint8_t 
 		}
 	}
 }
-void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, int16_t *dst)
+void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, int16_t *dst)
 {
 	for (size_t c = 0; c < sigma; c++) {
 		if (cls == ACMHIP_BP_WORD) {
 			const uint8_t *d = src + c * 2 * qn;
 			for (size_t q = 0; q < qn; q++)
-				dst[c + q * sigma] = (int16_t)(uint16_t)((d[q] ^ 0x80u) | ((unsigned)d[qn + q] << 8));
+				dst[c + q * sigma] = split ? (int16_t)(256 * (int)(int8_t)d[qn + q] + (int)(int8_t)d[q])
+							   : (int16_t)(uint16_t)((d[q] ^ 0x80u) | ((unsigned)d[qn + q] << 8));
 		} else if (cls == ACMHIP_BP_BYTE) {
 			for (size_t q = 0; q < qn; q++)
 				dst[c + q * sigma] = (int16_t)(int8_t)src[c * qn + q];
@@ -380,6 +396,8 @@ void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, int16_t 
 		}
 	}
 }
+/* the chunk kernel's form (64 columns of a residue class side by side): classes 8 and 16 bits only, the 16-bit one as two SIGNED bytes */
+inline bool split_form(size_t qn) { return qn == 64; }
 } // namespace
 
 extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,
@@ -390,12 +408,14 @@ extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nr
 		return ACMHIP_ERR_ARG;
 	const size_t cols = (size_t)1 << level, sigma = cols / qn;
 	uint64_t at = 0;
-	/* the pair in front of the stream: index 0 everywhere, at 4 bits */
+	const bool split = split_form(qn);
+	/* the pair in front of the stream: index 0 everywhere, at 4 bits (8 in the chunk kernel's form, which has no narrower class) */
 	if ((blob_base >> 6) >= (1ull << 30))
 		return ACMHIP_ERR_ARG;                  /* more than 64 GB in front of this block: the pair table counts 64-byte units in 30 bits */
-	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | ACMHIP_BP_NIBBLE);
-	memset(out, 0x88, pair_bytes(level, ACMHIP_BP_NIBBLE));
-	at += pair_bytes(level, ACMHIP_BP_NIBBLE);
+	const uint32_t cls_front = split ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE;
+	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | cls_front);
+	memset(out, split ? 0 : 0x88, pair_bytes(level, cls_front));
+	at += pair_bytes(level, cls_front);
 	for (uint64_t p = 0; p < nrows / 2; p++) {
 		const int16_t *src = idx + 2 * p * cols;
 		int lo = 0, hi = 0;
@@ -403,13 +423,15 @@ extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nr
 			lo = src[m] < lo ? src[m] : lo;
 			hi = src[m] > hi ? src[m] : hi;
 		}
-		const uint32_t cls = (lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
+		if (split && hi >= 32640)
+			return ACMHIP_ERR_RANGE;          /* 256 hi + lo with two signed bytes ends at 32639: such a stream stays in the int16 form */
+		const uint32_t cls = (!split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
 		if (((blob_base + at) >> 6) >= (1ull << 30))
 			return ACMHIP_ERR_ARG;
 		pairs[p + 1] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | cls);
 		const size_t rowb = pair_bytes(level, cls) / 2;
-		put_row(src, sigma, qn, cls, out + at);
-		put_row(src + cols, sigma, qn, cls, out + at + rowb);
+		put_row(src, sigma, qn, cls, split, out + at);
+		put_row(src + cols, sigma, qn, cls, split, out + at + rowb);
 		at += 2 * rowb;
 	}
 	memset(out + at, 0, kMformSlack);
@@ -427,13 +449,13 @@ extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const ac
 	std::vector<int16_t> front(2 * cols);
 	for (uint64_t p = 0; p <= nrows / 2; p++) {
 		const uint32_t cls = pairs[p] & 3;
-		if (cls < ACMHIP_BP_NIBBLE || cls > ACMHIP_BP_WORD)
+		if (cls < (split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
 			return ACMHIP_ERR_ARG;
 		const uint8_t *src = blob + ((uint64_t)(pairs[p] >> 2) << 6);
 		const size_t rowb = pair_bytes(level, cls) / 2;
 		int16_t *dst = p ? idx + 2 * (p - 1) * cols : front.data();
-		get_row(src, sigma, qn, cls, dst);
-		get_row(src + rowb, sigma, qn, cls, dst + cols);
+		get_row(src, sigma, qn, cls, split_form(qn), dst);
+		get_row(src + rowb, sigma, qn, cls, split_form(qn), dst + cols);
 		if (!p)
 			for (size_t m = 0; m < 2 * cols; m++)
 				if (front[m] != 0)
