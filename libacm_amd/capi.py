@@ -308,6 +308,8 @@ def mform_streams(idx, descs, threads=1):
         tr = L.acmhip_mform_tile_rows(d.level)
         if tr > 0 and d.row_begin == 0:
             ntiles[i] = min(d.nrows, d.n_emit >> d.level) // tr
+            if (ntiles[i] * tr) & 1:            # the form is written pair by pair (chunks of one row: an even number of them)
+                ntiles[i] -= 1
             rows[i] = ntiles[i] * tr
         p_at[i] = np_tot
         if ntiles[i]:

@@ -759,7 +759,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			return;
 		const int tr = acmhip_mform_tile_rows(s.info.level);
 		const uint64_t full_rows = std::min<uint64_t>((uint64_t)s.info.blocks * s.info.rows, items[i].words >> s.info.level);
-		const uint64_t ntiles = full_rows / (uint64_t)tr;
+		uint64_t ntiles = full_rows / (uint64_t)tr;
+		if ((ntiles * (uint64_t)tr) & 1)
+			ntiles--;                       /* the form is written pair by pair (tiles of one row: an even number of them) */
 		if (ntiles == 0 || ntiles * (uint64_t)tr > s.mf_rows_cap)
 			return;
 		if (acmhip_mform_rows(s.info.level, h_idx + s.idx_off, ntiles * (uint64_t)tr, h_pkblob + s.mf_off, s.mf_off,

@@ -35,6 +35,9 @@ struct AcmTile {
  * of recomputing two halo rows; a workgroup walks a contiguous run of the tile table */
 #define ACM_TILE_FRESH   1u    /* nothing in front of this tile: the carries start from zero (stream row 0, or a lead-in) */
 #define ACM_TILE_DISCARD 2u    /* lead-in: run the passes to build the carries, store no PCM */
+/* records of the chunk kernel whose chunks are ONE row (acm_chunk, level 11) */
+#define ACM_TILE_ROW1    4u    /* the chunk is row 1 of its stream: one row in front of it */
+#define ACM_TILE_ODD     8u    /* the chunk starts on the second row of a pair (idx_off still names the entry of the pair in front of that pair) */
 
 /* one tile of the lean kernel (acm_tile2): tile_rows consecutive rows of a stream decoded from its row 0, all of them
  * present and emitted.  Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH. */

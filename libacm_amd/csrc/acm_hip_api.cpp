@@ -528,9 +528,10 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			/* a byte-plane tile is named by the pair-table entry of the row pair in front of it (entry 0 of a stream: the pair of zeros) */
 			for (uint64_t rm = r; mf && rm < r + T2; rm += T2M) {
 				const uint64_t rhm = rm >= 2 ? rm - 2 : 0;
+				/* (chunks of one row - T2M == 1, the chunk kernel at level 11 - also say whether they start a pair and whether they are row 1) */
 				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + rm / 2, s.pcm_off + (rm << s.level),
 								     (uint32_t)(s.hdr_off + rhm / s.rows), (uint32_t)(rhm % s.rows), magic,
-								     rm == 0 ? ACM_TILE_FRESH : 0u });
+								     (rm == 0 ? ACM_TILE_FRESH : 0u) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
 			}
 		}
 		return ACMHIP_OK;

@@ -359,7 +359,8 @@ struct TileCfg {
 	static constexpr int NJ_LAST = NELEM_ / NT_;      // samples per thread in the last pass
 	static constexpr int PS = NJ_LAST >= 64 ? 6 : 5;  // LDS pad: one dword per 2^PS elements (= one last-pass walk)
 	static_assert(NJ_LAST == 64 || NJ_LAST == 32 || NJ_LAST == 128, "walk length of the last pass");
-	static_assert(TR >= 2 && (TR % 2) == 0, "whole row pairs (the halo flavour of acm_fused_tile needs four: two of them are halo)");
+	static_assert(TR >= 1, "whole rows");
+	static constexpr bool ROW_PAIRS = TR >= 2 && (TR % 2) == 0;     /* what the first passes fed from HBM work on (the halo flavour of acm_fused_tile needs four rows: two of them are halo) */
 };
 
 /* t - 2*z: one VALU op when 25 result bits suffice (level <= 9: the write-out
@@ -455,6 +456,15 @@ struct StageKind {
  */
 template <int PS = 6>
 __device__ __forceinline__ int lds_at(int m) { return m + (m >> PS); }
+/*
+ * Where the last pass parks its packed samples: dwords between the 16-byte pieces of one thread's parking area (the start of its own,
+ * consumed, walk).  The write-out reads piece p of owner o into lane 4 o + p (32-sample walks): side by side (4 dwords apart) the
+ * pieces of the four lanes that share an owner meet the next owners' on the same banks - owner o sits 33 o dwords on, bank o + 4 p -
+ * a two-way conflict on every read of the write-out (SQ_LDS_BANK_CONFLICT, profiles/r5_level9_summary.txt).  Eight apart they do not
+ * (bank o + 8 p: 32 lanes, 32 banks), and there is room: the samples of a body need half the dwords its inputs had.
+ */
+template <int NJ_LAST>
+constexpr int park_piece() { return NJ_LAST == 32 ? 8 : 4; }
 
 /*
  * Write-out without per-sample shifts where possible.  The whole cascade is linear mod 2^32 and only bits
@@ -645,6 +655,7 @@ struct FirstPass {
 	static constexpr bool PLANE = (ABL & MODE_PLANE) != 0;
 	static constexpr int NREG = NRAW * (PLANE ? W : 1);        // a plane holds int32: the second column of a lane sits NRAW further on
 	static_assert(W == 1 || W == 2, "1 or 2 adjacent columns per lane");
+	static_assert(C::ROW_PAIRS, "a body is two tile rows");
 	static_assert(SIGMA % W == 0 && TPS <= NT && NT % TPS == 0, "segment geometry");
 	static_assert(RPS >= 2 && RPS % 2 == 0 && NSEG * RPS == C::TR, "segments are whole row pairs");
 	/* LDS offset of the residue's q-th column / second row relative to (first row, first column) of the body */
@@ -875,10 +886,11 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 			for (int u = 0; u < BODY; u++)
 				p[P::off(u)] = v[u];
 		} else {
-			uint32_t *o = base + it * (BODY / 2);
 #pragma unroll
-			for (int u = 0; u < BODY; u += 2)
-				o[u / 2] = pack_pcm<L, FLIP, BIGEND>(v[u], v[u + 1], pf);
+			for (int u = 0; u < BODY; u += 2) {
+				const int d = it * (BODY / 2) + u / 2;          /* dword of the thread's samples */
+				base[(d / 4) * park_piece<C::NJ_LAST>() + d % 4] = pack_pcm<L, FLIP, BIGEND>(v[u], v[u + 1], pf);
+			}
 		}
 	}
 }
@@ -1109,7 +1121,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 					if (k < NVEC / NT || vec < NVEC) {      /* only the last round can be partial */
 						const int owner = (HALO * COLS / 8 + vec) / PER_OWNER;
 						const int piece = (HALO * COLS / 8 + vec) % PER_OWNER;
-						const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + piece * 4;
+						const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + piece * park_piece<NJ_LAST>();
 						uint4 o;
 						o.x = q[0];
 						o.y = q[1];
@@ -1131,7 +1143,7 @@ acm_fused_tile(const AcmDevStream *__restrict__ streams, const AcmTile *__restri
 					if (g >= cur.n_emit)
 						break;
 					const int owner = ml / NJ_LAST;
-					const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + (ml % NJ_LAST) / 2;
+					const uint32_t *q = tile + lds_at<C::PS>(owner * NJ_LAST) + (ml % NJ_LAST) / 8 * park_piece<NJ_LAST>();
 					const uint32_t w[4] = { q[0], q[1], q[2], q[3] };
 					if (g + 8 <= cur.n_emit) {
 						*reinterpret_cast<uint4 *>(cur.dst + g) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -1338,6 +1350,7 @@ struct FirstPassM {
 	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS, TR = C::TR;
 	static constexpr int G = G_, QN = 1 << G, SIGMA = COLS / QN;    /* QN columns of a residue class per row */
 	static_assert(G == 3 || G == 4, "one matrix instruction spans the four input rows: 4 x 2^G = its K");
+	static_assert(C::ROW_PAIRS, "a unit is a row pair");
 	static constexpr int NM = 2 * QN / 16;                  /* matrix instructions per unit and byte plane: 16 outputs each (G = 4: one per row of the pair) */
 	static constexpr int LB = QN;                           /* operand bytes per lane: lane l feeds input row l / 16, all its QN columns */
 	static constexpr int NGRP = SIGMA / 16;                 /* groups of 16 residues per row pair */
@@ -1881,7 +1894,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 #pragma unroll
 			for (int k = 0; k < NVEC / NT; k++) {
 				const int vec = tid + k * NT;
-				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * park_piece<NJ_LAST>();
 				const v4u o = { q[0], q[1], q[2], q[3] };
 				if ((ABL & 16) && o.x != 0x12345u)              /* timing-only build: no stores */
 					continue;
@@ -1946,16 +1959,35 @@ struct FirstPassZ {
 	using C = TileCfg<L_, 64, 2048>;                        /* what ONE wavefront holds in LDS: 2048 elements, 32 per lane in the last pass */
 	static constexpr int L = L_, COLS = C::COLS, TR = C::TR, PS = C::PS;
 	static constexpr int G = 6, QN = 1 << G, SIGMA = COLS / QN;            /* QN columns of a residue class per row, SIGMA classes */
-	static_assert(SIGMA == 8 || SIGMA == 16, "sixteen instances per matrix instruction: the classes of one row, or of two");
-	static constexpr int RR = 16 / SIGMA;                   /* row walkers among the instances */
-	static constexpr int NS = TR / RR;                      /* rows a walker walks = matrix "sets" per chunk */
-	static constexpr int NX = NS + 2;                       /* rows a lane loads: its walk and the two rows in front of it */
-	static constexpr int NE = RR + 1;                       /* pair-table entries a chunk reads: the pair in front and its own */
+	static_assert(SIGMA >= 8 && TR >= 1, "sixteen instances per matrix instruction: sixteen classes of one row, or the eight of two rows");
+	static constexpr int RR = SIGMA >= 16 ? 1 : 16 / SIGMA; /* row walkers among the sixteen instances */
+	static constexpr int NG = SIGMA >= 16 ? SIGMA / 16 : 1; /* groups of sixteen classes per row */
+	static constexpr int NSW = TR / RR;                     /* rows a walker walks */
+	static constexpr int NX = NSW + 2;                      /* rows a lane loads per group: its walk and the two rows in front of it */
+	static constexpr int NSET = NSW * NG;                   /* matrix "sets" (sixteen instances x 64 outputs) per chunk: 2048 / 1024 */
+	static constexpr int NE = ((1 + (RR - 1) * NSW + NX - 1) >> 1) + 1;     /* pair-table entries a chunk may read, from the pair in front of it on */
 	static constexpr int NM = QN / 16;                      /* output tiles per row */
-	static_assert(NS == 2 && NX == 4 && TR == 2 * RR, "a walker walks one row pair");
+	static_assert(NSW * RR == TR && NSET == 2, "a chunk is two sets");
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
+	/*
+	 * Which class instance i of a set stands for.  A lane receives four consecutive instances of one output (instances 4 h .. 4 h + 3,
+	 * h = lane / 16, output q = 16 mt + lane % 16) and stores them as four adjacent columns; a store instruction serves lanes 0-31
+	 * (h = 0, 1) and 32-63 in turn, and column c of output q sits at c + SIGMA q + (that >> 5): on bank c + 8 q + q / 4 (SIGMA 8),
+	 * c + 16 q + q / 2 (16), c + q (32).  So that the 32 lanes land on 32 banks, h = 1 must sit 4 / 8 / 16 columns beyond h = 0:
+	 * SIGMA 8: classes 4 (h & 1) + v of walker h >> 1; SIGMA >= 16: classes v + CB (h & 1) + 4 (h >> 1), CB = 8 or 16, and with
+	 * 32 classes the second group of sixteen is the same pattern 8 further on.
+	 */
+	static constexpr uint32_t CB = SIGMA >= 32 ? 16 : 8, GSTEP = SIGMA >= 32 ? 8 : 16;
+	static_assert(NG <= 2, "two groups of sixteen classes at most");
+	static __device__ __forceinline__ uint32_t class_of(const uint32_t i)
+	{
+		if constexpr (RR > 1)
+			return i % SIGMA;
+		else
+			return (i & 3u) + CB * ((i >> 2) & 1u) + 4u * (i >> 3);
+	}
 
-	struct Raw { v4u_t lo[NX], hi[NX]; };
+	struct Raw { v4u_t lo[NG][NX], hi[NG][NX]; };
 	struct Desc { uint32_t e[NE]; };
 	struct Tables {
 		v4i_t coef[3][NM][64];          /* [j][mt][lane]: T_j[16 mt + lane % 16][16 (lane / 16) .. + 15] */
@@ -1978,53 +2010,55 @@ struct FirstPassZ {
 	static __device__ __forceinline__ Desc fetch_desc(const uint32_t *__restrict__ pairs, const AcmTile2 &r)
 	{
 		Desc d;
-		const uint32_t at = __builtin_amdgcn_readfirstlane((uint32_t)r.idx_off);        /* the entry of the pair in front of the chunk */
+		const uint32_t at = __builtin_amdgcn_readfirstlane((uint32_t)r.idx_off);        /* the entry of the pair in front of the chunk's first pair */
 #pragma unroll
 		for (int j = 0; j < NE; j++)
 			d.e[j] = pairs[at + j];
 		return d;
 	}
 
-	/* the loads of one chunk: lane l = (instance i = l % 16: class c = i % SIGMA, walker i / SIGMA; columns 16 (l / 16) .. + 15 of the class)
-	 * asks for 16 low bytes and, 64 bytes on, 16 high bytes of each of its four rows (a pair at 8 bits has no high bytes: what comes
-	 * back instead is never used, see run()) */
-	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane)
+	/* the pair-table entry of row `u` counted from the first row of the pair in front (u = 0, 1: d.e[0]; 2, 3: d.e[1]; ...) */
+	static __device__ __forceinline__ uint32_t entry_of(const Desc &d, const uint32_t u)
 	{
-		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4, c = i % SIGMA, rr = i / SIGMA;
+		/* (opaque copies: a chain of selects over the members of a struct is otherwise turned into an indexed load from a copy of the
+		 * struct in scratch memory) */
+		uint32_t e = (uint32_t)opaque_s((int32_t)d.e[0]);
+#pragma unroll
+		for (int j = 1; j < NE; j++)
+			e = (u >> 1) >= (uint32_t)j ? (uint32_t)opaque_s((int32_t)d.e[j]) : e;
+		return e;
+	}
+
+	/* the loads of one chunk: lane l = (instance i = l % 16: class and walker; columns 16 (l / 16) .. + 15 of the class) asks for 16 low bytes
+	 * and, 64 bytes on, 16 high bytes of each of its rows (a pair at 8 bits has no high bytes: what comes back instead is never
+	 * used, see run_t()).  odd: the chunk starts on the second row of a pair (chunks of one row only) */
+	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd)
+	{
+		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4;
+		const uint32_t c = class_of(i), rr = RR == 1 ? 0u : i / SIGMA;
 		const uint32_t e0 = d.e[0];
 		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
-		uint32_t ea = d.e[0], eb = d.e[1];
-		if constexpr (RR == 2) {
-			ea = rr ? d.e[1] : d.e[0];
-			eb = rr ? d.e[2] : d.e[1];
+#pragma unroll
+		for (int k = 0; k < NX; k++) {
+			const uint32_t u = (TR & 1 ? odd : 0u) + rr * NSW + k;          /* row 0 = the first row of the pair in front */
+			const uint32_t e = entry_of(d, u);
+			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
+			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((u & 1u) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				const uint32_t v = row_at + (((GSTEP * g + c) * (uint32_t)QN) << sh);
+				asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[g][k]) : "v"(v), "s"(base) : "memory");
+				asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(raw.hi[g][k]) : "v"(v), "s"(base) : "memory");
+			}
 		}
-		const uint32_t sha = (ea & 3u) - ACMHIP_BP_BYTE, shb = (eb & 3u) - ACMHIP_BP_BYTE;      /* 0: a byte per index, 1: two */
-		const uint32_t pa = (((ea >> 2) - (e0 >> 2)) << 6) + ((c * (uint32_t)QN) << sha) + 16u * ks;
-		const uint32_t pb = (((eb >> 2) - (e0 >> 2)) << 6) + ((c * (uint32_t)QN) << shb) + 16u * ks;
-		const uint32_t v0 = pa, v1 = pa + ((uint32_t)COLS << sha), v2 = pb, v3 = pb + ((uint32_t)COLS << shb);
-#define ACM_Z_LOAD(K, V) \
-		asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[K]) : "v"(V), "s"(base) : "memory"); \
-		asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(raw.hi[K]) : "v"(V), "s"(base) : "memory")
-		ACM_Z_LOAD(0, v0);
-		ACM_Z_LOAD(1, v1);
-		ACM_Z_LOAD(2, v2);
-		ACM_Z_LOAD(3, v3);
-#undef ACM_Z_LOAD
 	}
-	static constexpr int NLOAD = 2 * NX;
+	static constexpr int NLOAD = 2 * NX * NG;
 
 	static __device__ __forceinline__ v4i_t mfma(const v4u_t data, const v4i_t coef, const v4i_t acc)
 	{
 		return __builtin_amdgcn_mfma_i32_16x16x64_i8((v4i_t)data, coef, acc, 0, 0, 0);
 	}
 
-	/*
-	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.
-	 * WORDS: some pair of the chunk is stored at 16 bits (hi_ok[k]: row k of this lane's four is - else its high bytes are not
-	 *        there and what was loaded in their place is replaced by zeros).
-	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
-	 *        and scaled one by one; else they are one accumulator chain and one multiply.
-	 */
 	/* v * c with both inside 24 bits.  (The library's __mul24 is plain arithmetic to the optimiser, which then turns val * hi * 256 + val * lo
 	 * into ONE multiply of val with a sum that no longer fits 24 bits - the quarter-rate v_mul_lo_u32; the opaque copy of val keeps
 	 * the two products apart.) */
@@ -2040,62 +2074,69 @@ struct FirstPassZ {
 	}
 
 	/*
-	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.
-	 * WORDS: some pair of the chunk is stored at 16 bits (mask_a / mask_b: all ones where this lane's first / second loaded row pair is -
-	 *        else the pair has no high bytes, and what was loaded in their place counts as zeros).
+	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.  in_front: rows of the stream in front of the chunk (0, 1, or 2
+	 * for "two or more").
+	 * WORDS: some pair of the chunk is stored at 16 bits (mask[k]: all ones where this lane's row k is - else it has no high bytes,
+	 *        and what was loaded in their place counts as zeros).
 	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
 	 *        and scaled one by one; else they are one accumulator chain and one multiply.
 	 */
 	template <bool WORDS, bool SPLIT>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
-						     const bool stream_start, const uint32_t mask_a, const uint32_t mask_b)
+						     const uint32_t in_front, const uint32_t (&mask)[NX])
 	{
 		const v4i_t zero = { 0, 0, 0, 0 };
 		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker, output q = 16 mt + lane % 16 */
 		const uint32_t h = (uint32_t)lane >> 4, qd = (uint32_t)lane & 15u;
-		const uint32_t c0 = (4u * h) % SIGMA, rrd = (4u * h) / SIGMA;
-		const uint32_t m_lane = rrd * (uint32_t)(NS * COLS) + c0 + (uint32_t)SIGMA * qd;
+		const uint32_t c0 = class_of(4u * h), rrd = RR == 1 ? 0u : (4u * h) / SIGMA;
+		const uint32_t m_lane = rrd * (uint32_t)(NSW * COLS) + c0 + (uint32_t)SIGMA * qd;
 		uint32_t *o_lane = tile + (m_lane + (m_lane >> PS));
 		/* the "+1" of decode.c:561-564, six stages on: the lane that owns residue 0 adds it to its first output; rows in front of a
 		 * stream do not exist and add nothing */
-		uint32_t bias_at[NS];           /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
+		uint32_t bias_at[NSW];          /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
 #pragma unroll
-		for (int s = 0; s < NS; s++) {
-			const uint32_t row = rrd * NS + s;
-			bias_at[s] = ((stream_start && row < 2 ? row : 2u) * 2u + (c0 == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
+		for (int s = 0; s < NSW; s++) {
+			const uint32_t row = in_front + rrd * NSW + s;
+			bias_at[s] = ((row < 2 ? row : 2u) * 2u + (c0 == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
 		}
 		const v4i_t *cf = &t.coef[0][0][lane];
-		/* val of the row this lane's outputs of set s, term j come from: chunk row rrd * NS + s - j */
+		/* val of the row this lane's outputs of walk row s, term j come from: chunk row rrd * NSW + s - j */
 		auto val_of = [&](const int s, const int j) -> int32_t {
 			if constexpr (RR == 1)
 				return rowval[s - j + 2];
 			else
-				return rrd ? rowval[NS + s - j + 2] : rowval[s - j + 2];
+				return rrd ? rowval[NSW + s - j + 2] : rowval[s - j + 2];
 		};
-		v4u_t hi[NX];
+		v4u_t hi[NG][NX];
 		if constexpr (WORDS) {
 #pragma unroll
-			for (int k = 0; k < NX; k++)
-				hi[k] = raw.hi[k] & (k < 2 ? mask_a : mask_b);
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int k = 0; k < NX; k++)
+					hi[g][k] = raw.hi[g][k] & mask[k];
 		}
-#pragma unroll 1
+#ifndef ACM_K3_MT_UNROLL
+#define ACM_K3_MT_UNROLL 1              /* (unrolled further the loop wants more registers than a wave of four per SIMD has) */
+#endif
+#pragma unroll ACM_K3_MT_UNROLL
 		for (int mt = 0; mt < NM; mt++) {
 			const v4i_t cf0 = cf[0], cf1 = cf[NM * 64], cf2 = cf[2 * NM * 64];
 #pragma unroll
-			for (int s = 0; s < NS; s++) {
-				/* rows of set s: x[r] = raw[s + 2], x[r - 1] = raw[s + 1], x[r - 2] = raw[s] */
+			for (int e = 0; e < NSET; e++) {
+				const int g = e / NSW, s = e % NSW;
+				/* rows of this set: x[r] = raw[g][s + 2], x[r - 1] = raw[g][s + 1], x[r - 2] = raw[g][s] */
 				v4i_t y;
-				const int32_t b = (&t.bias[0][0][0])[bias_at[s] + 16u * (uint32_t)mt];
+				const int32_t b = g == 0 ? (&t.bias[0][0][0])[bias_at[s] + 16u * (uint32_t)mt] : 0;     /* (residue 0 is in group 0) */
 				if constexpr (!SPLIT) {
 					const int32_t val = rowval[2];
-					v4i_t lo = mfma(raw.lo[s + 2], cf0, zero);
-					lo = mfma(raw.lo[s + 1], cf1, lo);
-					lo = mfma(raw.lo[s], cf2, lo);
+					v4i_t lo = mfma(raw.lo[g][s + 2], cf0, zero);
+					lo = mfma(raw.lo[g][s + 1], cf1, lo);
+					lo = mfma(raw.lo[g][s], cf2, lo);
 					if constexpr (WORDS) {
 						const int32_t valh = opaque_s(val);
-						v4i_t hh = mfma(hi[s + 2], cf0, zero);
-						hh = mfma(hi[s + 1], cf1, hh);
-						hh = mfma(hi[s], cf2, hh);
+						v4i_t hh = mfma(hi[g][s + 2], cf0, zero);
+						hh = mfma(hi[g][s + 1], cf1, hh);
+						hh = mfma(hi[g][s], cf2, hh);
 #pragma unroll
 						for (int v = 0; v < 4; v++)
 							y[v] = (int32_t)(((uint32_t)opaque_v(__mul24(hh[v], valh)) << 8) + (uint32_t)(__mul24(lo[v], val) + (v == 0 ? b : 0)));
@@ -2106,10 +2147,10 @@ struct FirstPassZ {
 					}
 				} else {
 					const int32_t v0 = val_of(s, 0), v1 = val_of(s, 1), v2 = val_of(s, 2);
-					const v4i_t l0 = mfma(raw.lo[s + 2], cf0, zero), l1 = mfma(raw.lo[s + 1], cf1, zero), l2 = mfma(raw.lo[s], cf2, zero);
+					const v4i_t l0 = mfma(raw.lo[g][s + 2], cf0, zero), l1 = mfma(raw.lo[g][s + 1], cf1, zero), l2 = mfma(raw.lo[g][s], cf2, zero);
 					if constexpr (WORDS) {
 						const int32_t w0 = opaque_v(v0), w1 = opaque_v(v1), w2 = opaque_v(v2);
-						const v4i_t h0 = mfma(hi[s + 2], cf0, zero), h1 = mfma(hi[s + 1], cf1, zero), h2 = mfma(hi[s], cf2, zero);
+						const v4i_t h0 = mfma(hi[g][s + 2], cf0, zero), h1 = mfma(hi[g][s + 1], cf1, zero), h2 = mfma(hi[g][s], cf2, zero);
 #pragma unroll
 						for (int v = 0; v < 4; v++) {
 							const int32_t yl = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
@@ -2122,8 +2163,10 @@ struct FirstPassZ {
 							y[v] = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
 					}
 				}
-				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0, "the constant parts of the address are multiples of 32: the pad rule splits");
-				uint32_t *const o = o_lane + (s * COLS + ((s * COLS) >> PS));
+				/* the constant parts of the address: multiples of 32, or (16 g) small enough to stay inside the lane's group of 32 - the pad rule splits */
+				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0 && (NG == 1 || (GSTEP * (NG - 1) + CB + 7 < (1 << PS) && SIGMA % (1 << PS) == 0)),
+					      "address split");
+				uint32_t *const o = o_lane + (s * COLS + ((s * COLS) >> PS)) + GSTEP * g;
 #pragma unroll
 				for (int v = 0; v < 4; v++)
 					o[v] = (uint32_t)y[v];
@@ -2134,7 +2177,7 @@ struct FirstPassZ {
 	}
 
 	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
-						   const Desc &d, const bool stream_start)
+						   const Desc &d, const uint32_t in_front, const uint32_t odd)
 	{
 		uint32_t any_word = 0;
 #pragma unroll
@@ -2144,23 +2187,24 @@ struct FirstPassZ {
 #pragma unroll
 		for (int k = 1; k < TR + 2; k++)
 			one_val = one_val && rowval[k] == rowval[0];
+		uint32_t mask[NX];
+#pragma unroll
+		for (int k = 0; k < NX; k++)
+			mask[k] = 0u;
 		if (any_word) {
-			const uint32_t rr = ((uint32_t)lane & 15u) / SIGMA;
-			uint32_t ea = d.e[0], eb = d.e[1];
-			if constexpr (RR == 2) {
-				ea = rr ? d.e[1] : d.e[0];
-				eb = rr ? d.e[2] : d.e[1];
-			}
-			const uint32_t mask_a = (ea & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u, mask_b = (eb & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+			const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
+#pragma unroll
+			for (int k = 0; k < NX; k++)
+				mask[k] = (entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
 			if (one_val)
-				run_t<true, false>(raw, tile, t, lane, rowval, stream_start, mask_a, mask_b);
+				run_t<true, false>(raw, tile, t, lane, rowval, in_front, mask);
 			else
-				run_t<true, true>(raw, tile, t, lane, rowval, stream_start, mask_a, mask_b);
+				run_t<true, true>(raw, tile, t, lane, rowval, in_front, mask);
 		} else {
 			if (one_val)
-				run_t<false, false>(raw, tile, t, lane, rowval, stream_start, 0u, 0u);
+				run_t<false, false>(raw, tile, t, lane, rowval, in_front, mask);
 			else
-				run_t<false, true>(raw, tile, t, lane, rowval, stream_start, 0u, 0u);
+				run_t<false, true>(raw, tile, t, lane, rowval, in_front, mask);
 		}
 	}
 };
@@ -2203,11 +2247,14 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		t--;
 	}
 
-	/* row values: lane lr < TR + 2 fetches the val of chunk row lr - 2 (decode.c:589); every lane issues the load */
+	/* rows of the stream in front of a chunk: 0, 1 (chunks of one row only), or 2 for "two or more" */
+	auto rows_in_front = [](const AcmTile2 &r) -> uint32_t { return (r.flags & ACM_TILE_FRESH) ? 0u : (r.flags & ACM_TILE_ROW1) ? 1u : 2u; };
+	/* row values: lane lr < TR + 2 fetches the val of chunk row lr - 2 (decode.c:589; the record counts from that row, or from row 0 of the
+	 * stream where it does not exist); every lane issues the load */
 	const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
 	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
-		const bool fr = (r.flags & ACM_TILE_FRESH) != 0;
-		const uint32_t q = r.rowpos + (fr ? (lr_fetch < 2 ? 0u : lr_fetch - 2) : lr_fetch);
+		const uint32_t missing = 2u - rows_in_front(r);
+		const uint32_t q = r.rowpos + (lr_fetch < missing ? 0u : lr_fetch - missing);
 		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;
 		const uint32_t *p = &hdr[r.hdr_blk + b].val;
 		uint32_t v;
@@ -2222,7 +2269,7 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	typename FP::Desc dcur = FP::fetch_desc(pairs, cur);
 	typename FP::Raw raw;
 	uint32_t hv = fetch_val(cur);
-	FP::issue(raw, arena, dcur, lane);
+	FP::issue(raw, arena, dcur, lane, (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
 	k2_wait<0>();
 	bool fresh = true;
 	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
@@ -2238,11 +2285,11 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		for (int k = 0; k < TR + 2; k++)
 			rowval[k] = (int32_t)(__builtin_amdgcn_readlane(hv, k) << OutScale<L>::SHIFT);
 		phase_prio<true, PRIO_FIRST_PASS>();
-		FP::run(raw, tile, tables, lane, rowval, dcur, (cur.flags & ACM_TILE_FRESH) != 0);
+		FP::run(raw, tile, tables, lane, rowval, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
 		phase_prio<true, PRIO_IDLE>();
 
 		hv = fetch_val(nxt);                            /* the last chunk of a run fetches its own again: no branch around the loads */
-		FP::issue(raw, arena, dnxt, lane);
+		FP::issue(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
 		phase_prio<true, PRIO_LDS_PASSES>();
 		run_lds_passes<C, PASS_ABL, true, FP::G, Gs...>(tile, lane, fmt, carry_mem);
 		tile_barrier<MODE_WAVE>();
@@ -2252,7 +2299,7 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 #pragma unroll
 			for (int k = 0; k < NSTORE; k++) {
 				const int vec = lane + k * 64;
-				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * park_piece<NJ_LAST>();
 				const v4u o = { q[0], q[1], q[2], q[3] };
 				__builtin_nontemporal_store(o, &out[vec]);
 			}
@@ -2376,8 +2423,8 @@ const Tile2MEntry g_chunk[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
 	entry_k3<9, 3>(),
-	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
-	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	entry_k3<10, 2, 2>(),
+	entry_k3<11, 3, 2>(),
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
@@ -2666,7 +2713,7 @@ acm_tile2p(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const uint
 #pragma unroll
 			for (int k = 0; k < NVEC / NT; k++) {
 				const int vec = tid + k * NT;
-				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * 4;
+				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * park_piece<NJ_LAST>();
 				const v4u o = { q[0], q[1], q[2], q[3] };
 				__builtin_nontemporal_store(o, &out[vec]);
 			}

@@ -32,7 +32,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection
     acc = defaultdict(lambda: [0.0, 0])
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            if not any(k in r.get("Kernel_Name", "") for k in ("fused", "acm_sw", "acm_tile")):
+            if not any(k in r.get("Kernel_Name", "") for k in ("fused", "acm_sw", "acm_tile", "acm_chunk")):
                 continue
             key = (r["Kernel_Name"][:40], r["Counter_Name"])
             acc[key][0] += float(r["Counter_Value"])

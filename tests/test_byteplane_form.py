@@ -22,9 +22,11 @@ def test_levels_with_a_byteplane_form():
     for level in range(16):
         tr = L.acmhip_mform_tile_rows(level)
         if level in LEVELS:
-            assert tr == {12: 4, 13: 2, 14: 2}.get(level, 8192 >> level)
-            assert L.acmhip_mform_bytes(level, 10) == 10 * (2 << level) + (1 << level) + 64
-            assert L.acmhip_mform_group(level) in (8, 16)
+            qn = L.acmhip_mform_group(level)
+            assert qn in (8, 16, 64)
+            # a level of the chunk kernel (64 columns of a residue class side by side) is cut into chunks of 2048 samples
+            assert tr == (2048 >> level if qn == 64 else {12: 4, 13: 2, 14: 2}.get(level, 8192 >> level))
+            assert L.acmhip_mform_bytes(level, 10) == 10 * (2 << level) + (2 << level) + 64
         else:
             assert tr == 0 and L.acmhip_mform_group(level) == 0
             assert L.acmhip_mform_rows(level, None, 0, None, 0, None, None) != 0
@@ -35,8 +37,12 @@ def test_levels_with_a_byteplane_form():
 def test_round_trip(level, rows, pwr_max):
     tr = capi.lib().acmhip_mform_tile_rows(level)
     nblocks = (3 * max(tr, 4) + rows - 1) // rows + 1
+    qn = capi.lib().acmhip_mform_group(level)            # columns of a residue class side by side: 8, 16 or 64
+    split = qn == 64                                     # the chunk kernel's form: 8 and 16 bits only, idx = 256 hi + lo with both bytes signed
     s = capi.stage_file(make_stream(41000 + level * 100 + rows, level, rows, nblocks, pwr_min=min(2, pwr_max), pwr_max=pwr_max,
                                     val_max=65535 if pwr_max == 15 else 255))
+    if split and int(s.idx.max()) >= 32640:
+        s.idx[s.idx >= 32640] = 32639                    # (beyond that the form has no place for an index: test_split_form_range)
     cols = 1 << level
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
                         nrows=s.info.blocks * rows, row_begin=0)
@@ -48,12 +54,15 @@ def test_round_trip(level, rows, pwr_max):
     assert capi.lib().acmhip_mform_pairs(nrows) == npairs
     pairs = mf.pairs[:npairs]
     cls, off = pairs & 3, (pairs >> 2).astype(np.int64) * 64
-    # the pair in front of the stream: index 0 everywhere, at 4 bits (nibble value 8)
-    assert cls[0] == 1 and off[0] == 0 and (mf.data[:cols] == 0x88).all()
+    # the pair in front of the stream: index 0 everywhere, at 4 bits (nibble value 8) - at 8 bits in the chunk kernel's form
+    if split:
+        assert cls[0] == 2 and off[0] == 0 and (mf.data[:2 * cols] == 0).all()
+    else:
+        assert cls[0] == 1 and off[0] == 0 and (mf.data[:cols] == 0x88).all()
     # every pair at the narrowest class that holds it, one behind the other
     rowsv = s.idx[:nrows * cols].reshape(nrows // 2, 2 * cols).astype(np.int64)
     lo, hi = rowsv.min(axis=1), rowsv.max(axis=1)
-    want_cls = np.where((lo >= -8) & (hi <= 7), 1, np.where((lo >= -128) & (hi <= 127), 2, 3))
+    want_cls = np.where((lo >= -8) & (hi <= 7) & (not split), 1, np.where((lo >= -128) & (hi <= 127), 2, 3))
     assert np.array_equal(cls[1:], want_cls)
     size = np.array([0, cols, 2 * cols, 4 * cols])[cls]
     assert np.array_equal(off[1:], off[:-1] + size[:-1])
@@ -61,7 +70,6 @@ def test_round_trip(level, rows, pwr_max):
     back = capi.mform_unrows(level, mf.data, pairs, nrows)
     assert np.array_equal(back, s.idx[:nrows * cols])
     # layout: pair p, row r of it, residue c, q
-    qn = capi.lib().acmhip_mform_group(level)            # columns of a residue class side by side: 8 or 16
     sigma = cols // qn
     rng = np.random.default_rng(level)
     for _ in range(96):
@@ -69,7 +77,11 @@ def test_round_trip(level, rows, pwr_max):
         x = int(s.idx[(2 * p + r) * cols + c + q * sigma])
         k = int(cls[p + 1])
         at = int(off[p + 1]) + r * int(size[p + 1]) // 2
-        if k == 3:
+        if k == 3 and split:
+            lo_s = ((x & 0xFF) ^ 0x80) - 0x80
+            assert mf.data[at + 2 * qn * c + q] == lo_s & 0xFF and mf.data[at + 2 * qn * c + qn + q] == ((x - lo_s) >> 8) & 0xFF
+            assert -128 <= (x - lo_s) >> 8 <= 127
+        elif k == 3:
             assert mf.data[at + 2 * qn * c + q] == (x & 0xFF) ^ 0x80 and mf.data[at + 2 * qn * c + qn + q] == (x >> 8) & 0xFF
         elif k == 2:
             assert mf.data[at + qn * c + q] == x & 0xFF
@@ -80,10 +92,33 @@ def test_round_trip(level, rows, pwr_max):
             assert (byte >> (4 * (nib % 2))) & 15 == x + 8
 
 
+def test_split_form_range():
+    """the chunk kernel's form writes a 16-bit index as two SIGNED bytes, 256 hi + lo: that ends at 32639, and a stream with a larger index
+    is refused (ACMHIP_ERR_RANGE: it stays in the int16 form) instead of being written wrong"""
+    L = capi.lib()
+    levels = [lv for lv in LEVELS if L.acmhip_mform_group(lv) == 64]
+    assert levels
+    for level in levels:
+        cols, tr = 1 << level, L.acmhip_mform_tile_rows(level)
+        nrows = 2 * max(tr, 2)
+        for top, ok in ((32639, True), (32640, False), (32767, False)):
+            idx = np.zeros(nrows * cols, dtype=np.int16)
+            idx[5], idx[cols + 9], idx[3 * cols - 1] = top, -32768, -129
+            buf = np.zeros(L.acmhip_mform_bytes(level, nrows) + 256, dtype=np.uint8)
+            pairs = np.zeros(nrows // 2 + 33, dtype=np.uint32)
+            used = C.c_uint64()
+            rc = L.acmhip_mform_rows(level, idx.ctypes.data, nrows, buf.ctypes.data, 0, pairs.ctypes.data, C.byref(used))
+            assert rc == (0 if ok else capi.ERR_RANGE), (level, top, rc)
+            if ok:
+                assert np.array_equal(capi.mform_unrows(level, buf, pairs, nrows), idx)
+        d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=nrows * cols, level=level, rows=1, nrows=nrows, row_begin=0)
+        assert capi.mform_streams(idx, [d]).streams[0].ntiles == 0           # (idx still holds 32767)
+
+
 def test_width_classes_follow_the_blocks():
     """quiet blocks (pwr <= 3: indices in [-8, 7]) travel at 4 bits, pwr <= 7 at 8 bits: the stager's classes are what the block
     headers promise or narrower"""
-    level, rows = 9, 16
+    level, rows = 8, 16
     s = capi.stage_file(make_stream(44000, level, rows, 40, pwr_min=0, pwr_max=12))
     cols = 1 << level
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
@@ -183,11 +218,55 @@ def test_matrix_tables_reproduce_the_first_stages(level, G):
     assert np.array_equal(t["KROW"][1], KROW * sign[None, :]) and np.array_equal(t["BIAS"][1], BIAS * sign[None, :])
 
 
+def load_toeplitz(G=6):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    txt = open(os.path.join(here, "..", "libacm_amd", "csrc", "acm_toeplitz_tables.inc")).read()
+    U = 1 << G
+    out = {}
+    for name, key, shape in (("T", "ACM_TZ%d[" % G, (2, 3, U, U)), ("BIAS", "ACM_TZ%d_BIAS[" % G, (2, 3, U))):
+        body = txt[txt.index(key):]
+        body = body[body.index("=") + 1:body.index(";")]
+        out[name] = np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int64).reshape(shape)
+    return out
+
+
+@pytest.mark.parametrize("level", [9, 10])
+def test_toeplitz_tables_reproduce_the_first_six_stages(level):
+    """acm_chunk's first pass: over one residue class (columns c + q cols/64) the first six stages of the cascade are
+    out[r] = T0 x[r] + T1 x[r-1] + T2 x[r-2] on the rows' 64 indices each; with the index split into two SIGNED bytes (the staged form of the
+    kernel's levels), the products scaled by val and the "+1" response added for the rows that exist, that is what the oracle's stage formula
+    leaves after stage 5 - for every class and row of a staged stream, the first rows of the stream included.  The second storage convention
+    is the first with the odd outputs negated."""
+    t = load_toeplitz()
+    T, BIAS = t["T"][0], t["BIAS"][0]
+    assert np.abs(t["T"]).max() <= 64
+    cols, sigma, rows = 1 << level, (1 << level) // 64, 7
+    s = capi.stage_file(make_stream(43500 + level, level, rows, 1, pwr_max=15, val_max=65535))
+    val = int(s.hdr[0, 0])
+    idx = np.minimum(s.idx[:rows * cols].astype(np.int64), 32639).reshape(rows, cols)
+    want = juggle_stages(idx * val, cols, 6)
+    lo = ((idx & 0xFF) ^ 0x80) - 0x80
+    hi = (idx - lo) >> 8
+    assert hi.min() >= -128 and hi.max() <= 127 and np.array_equal(256 * hi + lo, idx)
+    z = np.zeros(64, dtype=np.int64)
+    for r in range(rows):
+        for c in range(sigma):
+            x = [(lo[r - j, c::sigma], hi[r - j, c::sigma]) if r - j >= 0 else (z, z) for j in range(3)]
+            dl = sum(T[j] @ x[j][0] for j in range(3))
+            dh = sum(T[j] @ x[j][1] for j in range(3))
+            assert max(np.abs(dl).max(), np.abs(dh).max()) < 1 << 23                  # the kernel multiplies with the 24-bit multiplier
+            y = (dl + (dh << 8)) * val + (BIAS[min(r, 2)] if c == 0 else 0)
+            assert np.array_equal(y, want[r, c::sigma]), (r, c)
+    sign = np.where(np.arange(64) & 1, -1, 1)
+    assert np.array_equal(t["T"][1], T * sign[None, :, None]) and np.array_equal(t["BIAS"][1], BIAS * sign[None, :])
+
+
 def test_stager_rejects_what_the_kernel_could_not_read():
     """odd row counts (a unit is a row pair), a block that would not start on 16 bytes, offsets beyond the pair table's 30 bits, levels
     without the form; the inverse refuses a table with an unknown width class or a non-zero pair in front"""
     L = capi.lib()
-    level, cols = 9, 512
+    level, cols = 8, 256
     idx = np.zeros(4 * cols, dtype=np.int16)
     out = np.zeros(L.acmhip_mform_bytes(level, 4), dtype=np.uint8)
     pairs = np.zeros(8, dtype=np.uint32)

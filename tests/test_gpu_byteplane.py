@@ -22,6 +22,12 @@ def tile_rows(level):
     return capi.lib().acmhip_mform_tile_rows(level)
 
 
+def plan_rows(level):
+    """rows the planner hands out at a time: whole tiles of the lean kernel's vector-ALU build, cut into the byte-plane build's own (a level
+    of the chunk kernel: 2048-sample chunks; level 13: row pairs)"""
+    return max(tile_rows(level), capi.lib().acmk_tile2_rows(level), 4)
+
+
 def check(dev, files, fmt=capi.FMT_S16LE, force_chans=0):
     staged = [capi.stage_file(f, force_chans) for f in files]
     got, st = capi.synth(dev, staged, fmt=fmt, return_stats=True, mform=True)
@@ -41,12 +47,16 @@ def test_byteplane_matrix(dev, force_k2, level, rows, pwr_max):
     """whole tiles from the byte-plane form, the ragged tail from the int16 arena; block heights that put a val change between the
     rows of a unit in every possible place (even: between row pairs, odd: inside them, 1: everywhere) and 16-bit indices with
     16-bit row values (pwr_max 15)"""
-    tr = max(tile_rows(level), 4)                 # (level 13: the plan takes whole tiles of the vector-ALU build's height, two byte-plane tiles each)
+    tr = plan_rows(level)
     nblocks = max(2, (7 * tr + rows - 1) // rows + 1)
     f = make_stream(22000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=5, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
                     val_max=65535 if pwr_max == 15 else 255)
     st = check(dev, [f])
-    assert st.mform_tiles >= 7 and st.fused_streams == 1 and st.stagewise_streams == 0
+    if capi.lib().acmhip_mform_group(level) == 64 and int(capi.stage_file(f).idx.max()) >= 32640:
+        assert st.mform_tiles == 0            # the chunk kernel's form ends at 32639 (two signed bytes): such a stream stays int16
+    else:
+        assert st.mform_tiles >= 7
+    assert st.fused_streams == 1 and st.stagewise_streams == 0
 
 
 @pytest.mark.parametrize("level", LEVELS)
@@ -55,17 +65,18 @@ def test_byteplane_width_classes(dev, force_k2, level, rows, pwr_min, pwr_max):
     """quiet blocks travel at 4 or 8 bits per index: row pairs of every width, width changes between the rows of a unit in every place
     a block boundary can fall (with and without a change of val), a stream that is 4 bits throughout.  (pwr >= 3: below that the k / t
     fillers' indices of up to 5 leave the amplitude table - H1 patches - and such a stream keeps the int16 form)"""
-    tr = max(tile_rows(level), 4)
+    tr = plan_rows(level)
     nblocks = max(2, (9 * tr + rows - 1) // rows + 1)
     f = make_stream(29000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=2, pwr_min=pwr_min, pwr_max=pwr_max)
     s = capi.stage_file(f)
     assert s.patches is None or len(s.patches) == 0
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows << level, level=level, rows=rows, nrows=s.info.blocks * rows, row_begin=0)
     cc = capi.mform_streams(s.idx, [d]).class_counts()
+    narrow = 2 if capi.lib().acmhip_mform_group(level) == 64 else 1           # (the chunk kernel's form has no 4-bit class)
     if pwr_max <= 3:
-        assert cc[2] == 0 and cc[3] == 0 and cc[1] > 9
+        assert cc[3] == 0 and cc[narrow] > 9 and cc[1] + cc[2] == cc[narrow]
     elif pwr_max == 12 and rows < 64:
-        assert int(cc[1] > 1) + int(cc[2] > 0) + int(cc[3] > 0) >= 2, cc          # at least two widths among its blocks
+        assert int(cc[1] > 1) + int(cc[2] > 1) + int(cc[3] > 0) >= 2, cc          # at least two widths among its blocks
     st = check(dev, [f])
     assert st.mform_tiles >= 9
 
@@ -91,7 +102,7 @@ def test_byteplane_every_filler_code(dev, force_k2):
     files = []
     for j, code in enumerate(valid):
         lv = 7 + j % 8
-        files.append(make_stream(24000 + j, lv, 16, 3 * tile_rows(lv) // 16 + 2, mix=2, single_code=code, pwr_min=15 if 3 <= code <= 16 else 4,
+        files.append(make_stream(24000 + j, lv, 16, 3 * plan_rows(lv) // 16 + 2, mix=2, single_code=code, pwr_min=15 if 3 <= code <= 16 else 4,
                                  pwr_max=15 if 3 <= code <= 16 else 12))
     check(dev, files)
 
@@ -99,7 +110,7 @@ def test_byteplane_every_filler_code(dev, force_k2):
 def test_byteplane_extreme_indices(dev, force_k2):
     """the widest linear filler with the largest row values: indices over the whole int16 range (the high byte plane at -128 and 127,
     the low one at both ends), val = 65535"""
-    files = [make_stream(24500 + lv, lv, 16, 4 * tile_rows(lv) // 16 + 1, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535) for lv in LEVELS]
+    files = [make_stream(24500 + lv, lv, 16, 4 * plan_rows(lv) // 16 + 1, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535) for lv in LEVELS]
     staged = [capi.stage_file(f) for f in files]
     assert max(int(s.idx.max()) for s in staged) > 32000 and min(int(s.idx.min()) for s in staged) < -32000
     check(dev, files)
@@ -112,7 +123,7 @@ def test_byteplane_streams_with_h1_patches_keep_the_int16_form(dev, force_k2):
     staged = [capi.stage_file(f) for f in files]
     assert staged[1].patches is not None and len(staged[1].patches) > 0
     st = check(dev, files)
-    assert st.mform_tiles == (12 * 16 // 16) + (40 * 16 // 4)
+    assert st.mform_tiles == (12 * 16 // tile_rows(9)) + (40 * 16 // tile_rows(11))
 
 
 def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
@@ -152,11 +163,12 @@ def test_plan_rejects_a_byteplane_form_that_is_too_short(dev, force_k2):
     s = capi.stage_file(f)
     ar = capi.Arena([s])
     mf = capi.mform_streams(ar.idx, ar.descs)
-    assert mf.streams[0].ntiles == 6
-    for ntiles, form in ((5, capi.FORM_BYTEPLANE), (6, 7)):
+    nt = 6 * 16 // tile_rows(9)
+    assert mf.streams[0].ntiles == nt
+    for ntiles, form in ((nt - 1, capi.FORM_BYTEPLANE), (nt, 7)):
         with pytest.raises(capi.AcmHipError):
             capi.Plan(dev, ar.descs, packed=[capi.PackedStream(0, ntiles, form)])
-    capi.Plan(dev, ar.descs, packed=[capi.PackedStream(0, 6, capi.FORM_BYTEPLANE)]).destroy()
+    capi.Plan(dev, ar.descs, packed=[capi.PackedStream(0, nt, capi.FORM_BYTEPLANE)]).destroy()
 
 
 @pytest.mark.parametrize("prestage", [False, True])
@@ -211,7 +223,7 @@ dev = capi.Device(0)
 bad = 0
 for level in range(7, 15):
     assert capi.lib().acmhip_mform_group(level) == (16 if (%d == 4 and level >= 8) or level >= 13 else 8)
-    tr = max(capi.lib().acmhip_mform_tile_rows(level), 4)
+    tr = max(capi.lib().acmhip_mform_tile_rows(level), capi.lib().acmk_tile2_rows(level), 4)
     for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
         f = make_stream(28000 + level * 100 + rows, level, rows, (5 * tr + rows - 1) // rows + 1, cut=3, pwr_min=min(4, pm), pwr_max=pm,
                         val_max=65535 if pm == 15 else 255)
@@ -221,6 +233,6 @@ for level in range(7, 15):
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (os.path.dirname(os.path.abspath(__file__)), g0)
-    env = dict(os.environ, ACM_K2M_G0=str(g0), ACM_K2="1")
+    env = dict(os.environ, ACM_K2M_G0=str(g0), ACM_K2="1", ACM_K3="0")          # (ACM_K3=0: no level goes to the chunk kernel and its form)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]

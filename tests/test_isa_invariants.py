@@ -1,5 +1,6 @@
-"""Generated-code invariants of the lean tile kernels (libacm_amd/csrc/acm_kernels.hip: acm_tile2 and its packed-form build
-acm_tile2p, whose mangled names both match `acm_tile2`).
+"""Generated-code invariants of the lean tile kernels (libacm_amd/csrc/acm_kernels.hip: acm_tile2, its packed-form build
+acm_tile2p - their mangled names both match `acm_tile2` - and the chunk kernel acm_chunk, which issues and counts its vector memory
+operations the same way).
 
 acm_tile2 issues its global loads from inline asm and waits for them by hand (one `s_waitcnt vmcnt(N)` at the end
 of the iteration that issued them), so the compiler does not know that the destination registers of those loads are
@@ -48,7 +49,7 @@ def kernel_asm(tmp_path_factory):
 
 
 def tile2_bodies(asm):
-    for m in re.finditer(r"^(_ZN\S*acm_tile2\S*):", asm, re.M):
+    for m in re.finditer(r"^(_ZN\S*(?:acm_tile2|acm_chunk)\S*):", asm, re.M):
         end = asm.index(".Lfunc_end", m.end())
         yield m.group(1), asm[m.end():end].split("\n")
 
@@ -128,7 +129,7 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                     state_in[t] |= pending
                     work.append(t)
         assert n_loads >= 2 * 9, (name, n_loads)           # prologue + in-loop sets of staged-index loads (the matrix-core builds: 8 + the row values)
-    assert n_kernels >= 26                                 # nine levels of acm_tile2, thirteen matrix-core builds of it (levels 7-14, two depths where both exist), four of acm_tile2p
+    assert n_kernels >= 27                                 # the chunk kernel, nine levels of acm_tile2, thirteen matrix-core builds of it (levels 7-14, two depths where both exist), four of acm_tile2p
 
 
 def test_every_wait_is_written_by_hand(kernel_asm):
@@ -138,7 +139,7 @@ def test_every_wait_is_written_by_hand(kernel_asm):
         assert not any(l.strip().startswith("scratch_") for l in lines), name[:60]     # a spill is a compiler-tracked vector access
         stores = [l for l in lines if l.strip().startswith("global_store")]
         assert len(stores) in (4, 8), (name[:60], len(stores))
-        if "Lb1E" in name and "acm_tile2I" in name:
+        if ("Lb1E" in name and "acm_tile2I" in name) or "acm_chunk" in name:
             # the matrix-core builds first fill their coefficient tables from constant memory: compiler-tracked loads and their waits,
             # all in front of the first hand-issued load (nothing of the kernel's own is in flight there)
             first_hand = next(k for k, l in enumerate(lines) if l.strip().startswith(";;#ASMSTART") and lines[k + 1].strip().startswith("global_load"))
@@ -190,6 +191,22 @@ def test_phase_priorities_are_in_the_tile_loop(kernel_asm):
             assert set(prios) == {"0", "2", "3"}, (name[:60], prios)
         n += 1
     assert n >= 13
+
+
+def test_chunk_kernel_keeps_its_tables_in_lds(kernel_asm):
+    """acm_chunk: no flat access (a table pointer picked at run time loses its address space, and a flat load waits for every vector memory
+    operation in flight), no scratch, one workgroup barrier (behind the table fill) and none in the loop, the matrix instruction it is
+    written around"""
+    n = 0
+    for name, lines in tile2_bodies(kernel_asm):
+        if "acm_chunk" not in name:
+            continue
+        n += 1
+        text = "\n".join(l.split(";")[0] for l in lines)
+        assert "flat_" not in text and "scratch_" not in text and "buffer_load" not in text, name[:60]
+        assert text.count("s_barrier") == 1, name[:60]
+        assert text.count("v_mfma_i32_16x16x64_i8") >= 36 and "v_mul_lo_u32" not in text, name[:60]
+    assert n >= 1
 
 
 def test_packed_build_reads_its_descriptors_through_the_scalar_cache(kernel_asm):
