@@ -629,6 +629,9 @@ constexpr int MODE_PLANE = 64;
  * issued, so what orders its lanes among themselves is the order of the instructions: no workgroup barrier, only a fence the compiler
  * may not move LDS accesses across */
 constexpr int MODE_WAVE = 128;
+/* and: do not read the next body of an LDS pass while this one is computed (level 11 of acm_chunk keeps three rows of staged bytes in
+ * registers through its LDS passes and has none to spare) */
+constexpr int MODE_LEAN = 256;
 template <int ABL>
 __device__ __forceinline__ void tile_barrier()
 {
@@ -873,7 +876,7 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 #pragma unroll
 		for (int u = 0; u < BODY; u++)
 			v[u] = nxt[u];
-		if (it + 1 < NBODY) {
+		if (it + 1 < NBODY && !(ABL & MODE_LEAN)) {
 			const uint32_t *pn = body_ptr(it + 1);
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
@@ -881,6 +884,14 @@ __device__ __forceinline__ void lds_pass(uint32_t *tile, const int tid, const un
 		}
 		if (!(ABL & 2))
 			pass_body<L, K0, G>(v, h, K0 == 0 ? bias : 0u, K0 == 0 ? bias : 0u);
+		if (it + 1 < NBODY && (ABL & MODE_LEAN) != 0) {
+			/* short of registers: the next body is asked for behind this one's butterflies, not beside them */
+			__builtin_amdgcn_sched_barrier(0);
+			const uint32_t *pn = body_ptr(it + 1);
+#pragma unroll
+			for (int u = 0; u < BODY; u++)
+				nxt[u] = pn[P::off(u)];
+		}
 		if constexpr (!LAST) {
 #pragma unroll
 			for (int u = 0; u < BODY; u++)
@@ -2032,14 +2043,19 @@ struct FirstPassZ {
 	/* the loads of one chunk: lane l = (instance i = l % 16: class and walker; columns 16 (l / 16) .. + 15 of the class) asks for 16 low bytes
 	 * and, 64 bytes on, 16 high bytes of each of its rows (a pair at 8 bits has no high bytes: what comes back instead is never
 	 * used, see run_t()).  odd: the chunk starts on the second row of a pair (chunks of one row only) */
+	/* KEEP (one walker only: the rows in front of a lane's walk are rows the SAME lane loaded for the chunk in front): only the walk's own
+	 * rows are asked for, the two rows in front stay in their registers (shift_history) - a third (level 11) or half of the requests */
+	static constexpr bool HISTORY_IN_REGISTERS = RR == 1;
+	template <bool KEEP>
 	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd)
 	{
-		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4;
+		static_assert(!KEEP || HISTORY_IN_REGISTERS, "the rows in front belong to another lane");
+		const uint32_t i = (uint32_t)opaque_v(lane) & 15u, ks = (uint32_t)opaque_v(lane) >> 4;
 		const uint32_t c = class_of(i), rr = RR == 1 ? 0u : i / SIGMA;
 		const uint32_t e0 = d.e[0];
 		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
 #pragma unroll
-		for (int k = 0; k < NX; k++) {
+		for (int k = KEEP ? 2 : 0; k < NX; k++) {
 			const uint32_t u = (TR & 1 ? odd : 0u) + rr * NSW + k;          /* row 0 = the first row of the pair in front */
 			const uint32_t e = entry_of(d, u);
 			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
@@ -2052,7 +2068,27 @@ struct FirstPassZ {
 			}
 		}
 	}
-	static constexpr int NLOAD = 2 * NX * NG;
+	/* what the chunk behind this one finds in front of its walk: the last two rows of this one's (the registers of rows 2 .. are about to
+	 * be asked for again).  A stream's first chunk has nothing in front of it: zeros, as the stager's pair of zeros would have been */
+	static __device__ __forceinline__ void shift_history(Raw &raw)
+	{
+#pragma unroll
+		for (int g = 0; g < NG; g++)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				raw.lo[g][k] = raw.lo[g][k + NSW];
+				raw.hi[g][k] = raw.hi[g][k + NSW];
+			}
+	}
+	static __device__ __forceinline__ void zero_history(Raw &raw)
+	{
+		const v4u_t z = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int g = 0; g < NG; g++)
+#pragma unroll
+			for (int k = 0; k < 2; k++)
+				raw.lo[g][k] = raw.hi[g][k] = z;
+	}
 
 	static __device__ __forceinline__ v4i_t mfma(const v4u_t data, const v4i_t coef, const v4i_t acc)
 	{
@@ -2076,14 +2112,14 @@ struct FirstPassZ {
 	/*
 	 * rowval[k] = val << SHIFT of chunk row k - 2 (k < TR + 2), as scalars.  in_front: rows of the stream in front of the chunk (0, 1, or 2
 	 * for "two or more").
-	 * WORDS: some pair of the chunk is stored at 16 bits (mask[k]: all ones where this lane's row k is - else it has no high bytes,
-	 *        and what was loaded in their place counts as zeros).
+	 * WORDS: some pair of the chunk is stored at 16 bits (run() has put zeros where a row of this lane is not: it has no high bytes, and what
+	 *        was loaded in their place is its neighbour's low ones).
 	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
 	 *        and scaled one by one; else they are one accumulator chain and one multiply.
 	 */
 	template <bool WORDS, bool SPLIT>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
-						     const uint32_t in_front, const uint32_t (&mask)[NX])
+						     const uint32_t in_front)
 	{
 		const v4i_t zero = { 0, 0, 0, 0 };
 		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker, output q = 16 mt + lane % 16 */
@@ -2107,18 +2143,13 @@ struct FirstPassZ {
 			else
 				return rrd ? rowval[NSW + s - j + 2] : rowval[s - j + 2];
 		};
-		v4u_t hi[NG][NX];
-		if constexpr (WORDS) {
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int k = 0; k < NX; k++)
-					hi[g][k] = raw.hi[g][k] & mask[k];
-		}
+		const auto &hi = raw.hi;
 #ifndef ACM_K3_MT_UNROLL
 #define ACM_K3_MT_UNROLL 1              /* (unrolled further the loop wants more registers than a wave of four per SIMD has) */
 #endif
-#pragma unroll ACM_K3_MT_UNROLL
+#define ACM_PRAGMA_(x) _Pragma(#x)
+#define ACM_UNROLL(n) ACM_PRAGMA_(unroll n)
+		ACM_UNROLL(ACM_K3_MT_UNROLL)
 		for (int mt = 0; mt < NM; mt++) {
 			const v4i_t cf0 = cf[0], cf1 = cf[NM * 64], cf2 = cf[2 * NM * 64];
 #pragma unroll
@@ -2176,9 +2207,12 @@ struct FirstPassZ {
 		}
 	}
 
-	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
+	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const Tables &t, const int lane_, const int32_t (&rowval)[TR + 2],
 						   const Desc &d, const uint32_t in_front, const uint32_t odd)
 	{
+		/* what a lane derives from its number (LDS places, table offsets) is worked out again per chunk - a handful of instructions - instead
+		 * of living in registers through the LDS passes, which are what the kernel is short of */
+		const int lane = opaque_v(lane_);
 		uint32_t any_word = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++)
@@ -2187,24 +2221,25 @@ struct FirstPassZ {
 #pragma unroll
 		for (int k = 1; k < TR + 2; k++)
 			one_val = one_val && rowval[k] == rowval[0];
-		uint32_t mask[NX];
-#pragma unroll
-		for (int k = 0; k < NX; k++)
-			mask[k] = 0u;
 		if (any_word) {
+			/* in place: the rows that stay in their registers for the next chunk (HISTORY_IN_REGISTERS) stay what they are */
 			const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
 #pragma unroll
-			for (int k = 0; k < NX; k++)
-				mask[k] = (entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+			for (int k = 0; k < NX; k++) {
+				const uint32_t mask = (entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+				for (int g = 0; g < NG; g++)
+					raw.hi[g][k] &= mask;
+			}
 			if (one_val)
-				run_t<true, false>(raw, tile, t, lane, rowval, in_front, mask);
+				run_t<true, false>(raw, tile, t, lane, rowval, in_front);
 			else
-				run_t<true, true>(raw, tile, t, lane, rowval, in_front, mask);
+				run_t<true, true>(raw, tile, t, lane, rowval, in_front);
 		} else {
 			if (one_val)
-				run_t<false, false>(raw, tile, t, lane, rowval, in_front, mask);
+				run_t<false, false>(raw, tile, t, lane, rowval, in_front);
 			else
-				run_t<false, true>(raw, tile, t, lane, rowval, in_front, mask);
+				run_t<false, true>(raw, tile, t, lane, rowval, in_front);
 		}
 	}
 };
@@ -2220,13 +2255,13 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	constexpr int L = L_, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST, NW = 16;
 	constexpr int WTILE = 8 + NELEM + (NELEM >> C::PS);
 	constexpr int NCARRY_WORDS = carry_total<C, FP::G, Gs...>();
-	constexpr int PASS_ABL = (ABL & ~MODE_WAVE) | MODE_WAVE;
+	constexpr int PASS_ABL = ABL | MODE_WAVE | (FP::NG > 1 ? MODE_LEAN : 0);
 
 	__shared__ uint32_t tile_mem[NW][WTILE];
 	__shared__ uint32_t carry_all[NW][NCARRY_WORDS];
 	__shared__ typename FP::Tables tables;
 
-	const int lane = threadIdx.x & 63;
+	const int lane0 = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	FP::fill_tables(tables, threadIdx.x, NW * 64);
 	__syncthreads();                                /* the only one: the coefficient tables are shared */
@@ -2251,8 +2286,8 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	auto rows_in_front = [](const AcmTile2 &r) -> uint32_t { return (r.flags & ACM_TILE_FRESH) ? 0u : (r.flags & ACM_TILE_ROW1) ? 1u : 2u; };
 	/* row values: lane lr < TR + 2 fetches the val of chunk row lr - 2 (decode.c:589; the record counts from that row, or from row 0 of the
 	 * stream where it does not exist); every lane issues the load */
-	const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
-	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
+	auto fetch_val = [&](const AcmTile2 &r, const int lane) -> uint32_t {
+		const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
 		const uint32_t missing = 2u - rows_in_front(r);
 		const uint32_t q = r.rowpos + (lr_fetch < missing ? 0u : lr_fetch - missing);
 		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;
@@ -2265,18 +2300,32 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / 64;
 	static_assert(NVEC % 64 == 0, "whole rounds");
 	const uint8_t *const arena = reinterpret_cast<const uint8_t *>(idx);
-	AcmTile2 cur = tiles[__builtin_amdgcn_readfirstlane(t)];
+	/* chunk records and pair-table entries come through the scalar cache, TWO chunks ahead: a scalar load is waited for with every LDS
+	 * wait behind it (one counter, and scalar loads return in any order), so a record asked for at the end of an iteration and the
+	 * entries it names were a chain of two memory latencies in front of every first pass (profiles/ubench/phases_k3.hip: 13 % of a
+	 * wavefront's time).  Asked for a whole iteration before they are looked at, they cost nothing.  The last chunks of a run name
+	 * themselves as their successors */
+	auto record_at = [&](const uint32_t k) -> AcmTile2 { return tiles[__builtin_amdgcn_readfirstlane(k < t_end ? k : t_end - 1)]; };
+	AcmTile2 cur = record_at(t);
 	typename FP::Desc dcur = FP::fetch_desc(pairs, cur);
 	typename FP::Raw raw;
-	uint32_t hv = fetch_val(cur);
-	FP::issue(raw, arena, dcur, lane, (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
+	uint32_t hv = fetch_val(cur, lane0);
+	FP::template issue<false>(raw, arena, dcur, lane0, (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
 	k2_wait<0>();
 	bool fresh = true;
-	AcmTile2 nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
+	AcmTile2 nxt = record_at(t + 1), nx2 = record_at(t + 2);
 	typename FP::Desc dnxt = FP::fetch_desc(pairs, nxt);
+#ifdef ACM_STAMPS
+	unsigned long long acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long last_ = stamp_now();
+#endif
 	for (;;) {
 		const uint32_t tn = t + 1;
 		const bool more = tn < t_end;
+		/* whatever a lane works out from its number is worked out per chunk: registers are what the LDS passes are short of, and a
+		 * loop-invariant value would sit in one through all of them */
+		int lane = lane0;
+		asm volatile("" : "+v"(lane));
 		if (fresh)
 			for (int k = lane; k < NCARRY_WORDS; k += 64)
 				carry_mem[k] = 0u;
@@ -2284,15 +2333,31 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 #pragma unroll
 		for (int k = 0; k < TR + 2; k++)
 			rowval[k] = (int32_t)(__builtin_amdgcn_readlane(hv, k) << OutScale<L>::SHIFT);
+		ACM_STAMP(0);
 		phase_prio<true, PRIO_FIRST_PASS>();
 		FP::run(raw, tile, tables, lane, rowval, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
 		phase_prio<true, PRIO_IDLE>();
+		ACM_STAMP(1);
 
-		hv = fetch_val(nxt);                            /* the last chunk of a run fetches its own again: no branch around the loads */
-		FP::issue(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+		hv = fetch_val(nxt, lane);                            /* the last chunk of a run fetches its own again: no branch around the loads */
+		if constexpr (FP::HISTORY_IN_REGISTERS) {
+			/* the rows in front of the next chunk's walk are in this lane's registers already - unless that chunk starts a stream
+			 * (nothing in front of it: zeros).  (The last chunk of a run, which names itself, is never looked at again.) */
+			FP::shift_history(raw);
+			if (nxt.flags & ACM_TILE_FRESH)
+				FP::zero_history(raw);
+			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+		} else {
+			FP::template issue<false>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+		}
+		/* (asked for here, looked at from the end of this iteration on: behind the LDS passes' own waits) */
+		const AcmTile2 nx3 = record_at(t + 3);
+		const typename FP::Desc dnx2 = FP::fetch_desc(pairs, nx2);
+		ACM_STAMP(2);
 		phase_prio<true, PRIO_LDS_PASSES>();
 		run_lds_passes<C, PASS_ABL, true, FP::G, Gs...>(tile, lane, fmt, carry_mem);
 		tile_barrier<MODE_WAVE>();
+		ACM_STAMP(3);
 		{
 			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 			v4u *out = discard ? reinterpret_cast<v4u *>(sink) : reinterpret_cast<v4u *>(reinterpret_cast<uint16_t *>(pcm) + cur.pcm_off);
@@ -2304,8 +2369,10 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 				__builtin_nontemporal_store(o, &out[vec]);
 			}
 		}
+		ACM_STAMP(5);
 		phase_prio<true, PRIO_IDLE>();
 		k2_wait<NSTORE>();                              /* the next chunk's indices are here; only this chunk's PCM stores may still be on their way */
+		ACM_STAMP(6);
 		tile_barrier<MODE_WAVE>();                      /* (the next first pass overwrites what the stores have just read) */
 		if (!more)
 			break;
@@ -2314,9 +2381,15 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		cur = nxt;
 		dcur = dnxt;
 		t = tn;
-		nxt = tiles[__builtin_amdgcn_readfirstlane(t + 1 < t_end ? t + 1 : t)];
-		dnxt = FP::fetch_desc(pairs, nxt);
+		nxt = nx2;
+		dnxt = dnx2;
+		nx2 = nx3;
 	}
+#ifdef ACM_STAMPS
+	if (lane0 == 0 && vw < 2048)
+		for (int k = 0; k < 8; k++)
+			g_acm_stamps[vw][k] = acc_[k];
+#endif
 }
 
 struct Tile2Entry {
