@@ -2050,7 +2050,7 @@ struct FirstPassZ {
 	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd)
 	{
 		static_assert(!KEEP || HISTORY_IN_REGISTERS, "the rows in front belong to another lane");
-		const uint32_t i = (uint32_t)opaque_v(lane) & 15u, ks = (uint32_t)opaque_v(lane) >> 4;
+		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4;
 		const uint32_t c = class_of(i), rr = RR == 1 ? 0u : i / SIGMA;
 		const uint32_t e0 = d.e[0];
 		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
@@ -2114,10 +2114,14 @@ struct FirstPassZ {
 	 * for "two or more").
 	 * WORDS: some pair of the chunk is stored at 16 bits (run() has put zeros where a row of this lane is not: it has no high bytes, and what
 	 *        was loaded in their place is its neighbour's low ones).
-	 * SPLIT: the rows a lane combines do not all have one val (a block boundary within reach): the three terms are kept apart
-	 *        and scaled one by one; else they are one accumulator chain and one multiply.
+	 * The three terms of an output row r are one accumulator chain, oldest row first: P1 = T2 x[r-2], P2 = P1 + T1 x[r-1], A = P2 + T0 x[r].
+	 * With one val over the rows in reach (the usual case) the output is val A.  Across a block boundary
+	 *     val[r] T0 x[r] + val[r-1] T1 x[r-1] + val[r-2] T2 x[r-2] = val[r] A + (val[r-1] - val[r]) P2 + (val[r-2] - val[r-1]) P1,
+	 * so a chunk that sees a change of val keeps the partial sums of the chain and pays one multiply-add per plane for each of the two
+	 * differences that is not zero in SOME lane of the set (step2 / step1, decided per set from the scalar row values) - no matrix
+	 * instruction more, and nothing for the chunks in the middle of a block.
 	 */
-	template <bool WORDS, bool SPLIT>
+	template <bool WORDS>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
 						     const uint32_t in_front)
 	{
@@ -2130,19 +2134,31 @@ struct FirstPassZ {
 		/* the "+1" of decode.c:561-564, six stages on: the lane that owns residue 0 adds it to its first output; rows in front of a
 		 * stream do not exist and add nothing */
 		uint32_t bias_at[NSW];          /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
+		/* per walk row s: val of the lane's row, the two differences, and whether any lane of the set has one */
+		int32_t val[NSW], dv2[NSW], dv1[NSW];
+		bool step2[NSW], step1[NSW];
 #pragma unroll
 		for (int s = 0; s < NSW; s++) {
 			const uint32_t row = in_front + rrd * NSW + s;
 			bias_at[s] = ((row < 2 ? row : 2u) * 2u + (c0 == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
+			/* chunk row of walker w's output: w * NSW + s; rowval is indexed from row -2 */
+			const int32_t a0 = rowval[s + 2], a1 = rowval[s + 1], a2 = rowval[s];
+			if constexpr (RR == 1) {
+				val[s] = a0;
+				dv2[s] = a1 - a0;
+				dv1[s] = a2 - a1;
+				step2[s] = a1 != a0;
+				step1[s] = a2 != a1;
+			} else {
+				const int32_t b0 = rowval[NSW + s + 2], b1 = rowval[NSW + s + 1], b2 = rowval[NSW + s];
+				val[s] = rrd ? b0 : a0;
+				dv2[s] = rrd ? b1 - b0 : a1 - a0;
+				dv1[s] = rrd ? b2 - b1 : a2 - a1;
+				step2[s] = a1 != a0 || b1 != b0;
+				step1[s] = a2 != a1 || b2 != b1;
+			}
 		}
 		const v4i_t *cf = &t.coef[0][0][lane];
-		/* val of the row this lane's outputs of walk row s, term j come from: chunk row rrd * NSW + s - j */
-		auto val_of = [&](const int s, const int j) -> int32_t {
-			if constexpr (RR == 1)
-				return rowval[s - j + 2];
-			else
-				return rrd ? rowval[NSW + s - j + 2] : rowval[s - j + 2];
-		};
 		const auto &hi = raw.hi;
 #ifndef ACM_K3_MT_UNROLL
 #define ACM_K3_MT_UNROLL 1              /* (unrolled further the loop wants more registers than a wave of four per SIMD has) */
@@ -2156,43 +2172,50 @@ struct FirstPassZ {
 			for (int e = 0; e < NSET; e++) {
 				const int g = e / NSW, s = e % NSW;
 				/* rows of this set: x[r] = raw[g][s + 2], x[r - 1] = raw[g][s + 1], x[r - 2] = raw[g][s] */
-				v4i_t y;
 				const int32_t b = g == 0 ? (&t.bias[0][0][0])[bias_at[s] + 16u * (uint32_t)mt] : 0;     /* (residue 0 is in group 0) */
-				if constexpr (!SPLIT) {
-					const int32_t val = rowval[2];
-					v4i_t lo = mfma(raw.lo[g][s + 2], cf0, zero);
-					lo = mfma(raw.lo[g][s + 1], cf1, lo);
-					lo = mfma(raw.lo[g][s], cf2, lo);
-					if constexpr (WORDS) {
-						const int32_t valh = opaque_s(val);
-						v4i_t hh = mfma(hi[g][s + 2], cf0, zero);
-						hh = mfma(hi[g][s + 1], cf1, hh);
-						hh = mfma(hi[g][s], cf2, hh);
+				const v4i_t l1 = mfma(raw.lo[g][s], cf2, zero);
+				const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
+				const v4i_t la = mfma(raw.lo[g][s + 2], cf0, l2);
+				v4i_t y;
+#pragma unroll
+				for (int v = 0; v < 4; v++)
+					y[v] = __mul24(la[v], val[s]) + (v == 0 ? b : 0);
+				if (step2[s]) {
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						y[v] += __mul24(l2[v], dv2[s]);
+				}
+				if (step1[s]) {
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						y[v] += __mul24(l1[v], dv1[s]);
+				}
+				if constexpr (WORDS) {
+					const v4i_t h1 = mfma(hi[g][s], cf2, zero);
+					const v4i_t h2 = mfma(hi[g][s + 1], cf1, h1);
+					const v4i_t ha = mfma(hi[g][s + 2], cf0, h2);
+					/* (opaque copies of the multipliers: or the optimiser adds the planes first and multiplies a sum beyond 24 bits at
+					 * a quarter of the rate; an opaque sum: or it moves the shift into the multipliers) */
+					v4i_t yh;
+					const int32_t wv = opaque_v(val[s]);
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						yh[v] = __mul24(ha[v], wv);
+					if (step2[s]) {
+						const int32_t w2 = opaque_v(dv2[s]);
 #pragma unroll
 						for (int v = 0; v < 4; v++)
-							y[v] = (int32_t)(((uint32_t)opaque_v(__mul24(hh[v], valh)) << 8) + (uint32_t)(__mul24(lo[v], val) + (v == 0 ? b : 0)));
-					} else {
-#pragma unroll
-						for (int v = 0; v < 4; v++)
-							y[v] = __mul24(lo[v], val) + (v == 0 ? b : 0);
+							yh[v] += __mul24(h2[v], w2);
 					}
-				} else {
-					const int32_t v0 = val_of(s, 0), v1 = val_of(s, 1), v2 = val_of(s, 2);
-					const v4i_t l0 = mfma(raw.lo[g][s + 2], cf0, zero), l1 = mfma(raw.lo[g][s + 1], cf1, zero), l2 = mfma(raw.lo[g][s], cf2, zero);
-					if constexpr (WORDS) {
-						const int32_t w0 = opaque_v(v0), w1 = opaque_v(v1), w2 = opaque_v(v2);
-						const v4i_t h0 = mfma(hi[g][s + 2], cf0, zero), h1 = mfma(hi[g][s + 1], cf1, zero), h2 = mfma(hi[g][s], cf2, zero);
-#pragma unroll
-						for (int v = 0; v < 4; v++) {
-							const int32_t yl = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
-							const int32_t yh = opaque_v(__mul24(h0[v], w0) + __mul24(h1[v], w1) + __mul24(h2[v], w2));      /* (or the shift moves into the vals) */
-							y[v] = (int32_t)(((uint32_t)yh << 8) + (uint32_t)yl);
-						}
-					} else {
+					if (step1[s]) {
+						const int32_t w1 = opaque_v(dv1[s]);
 #pragma unroll
 						for (int v = 0; v < 4; v++)
-							y[v] = __mul24(l0[v], v0) + __mul24(l1[v], v1) + __mul24(l2[v], v2) + (v == 0 ? b : 0);
+							yh[v] += __mul24(h1[v], w1);
 					}
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << 8) + (uint32_t)y[v]);
 				}
 				/* the constant parts of the address: multiples of 32, or (16 g) small enough to stay inside the lane's group of 32 - the pad rule splits */
 				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0 && (NG == 1 || (GSTEP * (NG - 1) + CB + 7 < (1 << PS) && SIGMA % (1 << PS) == 0)),
@@ -2212,15 +2235,15 @@ struct FirstPassZ {
 	{
 		/* what a lane derives from its number (LDS places, table offsets) is worked out again per chunk - a handful of instructions - instead
 		 * of living in registers through the LDS passes, which are what the kernel is short of */
+#ifdef ACM_K3_OPAQUE_LANE
 		const int lane = opaque_v(lane_);
+#else
+		const int lane = lane_;
+#endif
 		uint32_t any_word = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++)
 			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
-		bool one_val = true;
-#pragma unroll
-		for (int k = 1; k < TR + 2; k++)
-			one_val = one_val && rowval[k] == rowval[0];
 		if (any_word) {
 			/* in place: the rows that stay in their registers for the next chunk (HISTORY_IN_REGISTERS) stay what they are */
 			const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
@@ -2231,15 +2254,9 @@ struct FirstPassZ {
 				for (int g = 0; g < NG; g++)
 					raw.hi[g][k] &= mask;
 			}
-			if (one_val)
-				run_t<true, false>(raw, tile, t, lane, rowval, in_front);
-			else
-				run_t<true, true>(raw, tile, t, lane, rowval, in_front);
+			run_t<true>(raw, tile, t, lane, rowval, in_front);
 		} else {
-			if (one_val)
-				run_t<false, false>(raw, tile, t, lane, rowval, in_front);
-			else
-				run_t<false, true>(raw, tile, t, lane, rowval, in_front);
+			run_t<false>(raw, tile, t, lane, rowval, in_front);
 		}
 	}
 };
@@ -2325,7 +2342,9 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		/* whatever a lane works out from its number is worked out per chunk: registers are what the LDS passes are short of, and a
 		 * loop-invariant value would sit in one through all of them */
 		int lane = lane0;
+#ifdef ACM_K3_OPAQUE_LANE
 		asm volatile("" : "+v"(lane));
+#endif
 		if (fresh)
 			for (int k = lane; k < NCARRY_WORDS; k += 64)
 				carry_mem[k] = 0u;
