@@ -207,7 +207,7 @@ def test_chunk_kernel_keeps_its_tables_in_lds(kernel_asm):
         text = "\n".join(l.split(";")[0] for l in lines)
         assert "flat_" not in text and "scratch_" not in text and "buffer_load" not in text, name[:60]
         assert text.count("s_barrier") == 1, name[:60]
-        assert text.count("v_mfma_i32_16x16x64_i8") >= 36 and "v_mul_lo_u32" not in text, name[:60]
+        assert text.count("v_mfma_i32_16x16x64_i8") >= 18 and "v_mul_lo_u32" not in text, name[:60]
     assert n >= 1
 
 
