@@ -71,6 +71,12 @@ def parse_args():
                          "byteplane where the level has it, else int16.  The other forms are timed as side measurements")
     ap.add_argument("--packed", action="store_true", help="= --form packed")
     ap.add_argument("--no-packed", action="store_true", help="skip the packed-form side measurement")
+    ap.add_argument("--control", choices=["nccl", "gloo"], default="nccl",
+                    help="backend of the N > 1 control collectives and of the PCM gather leg: nccl (= RCCL over xGMI, the real thing) or gloo "
+                         "(host memory; for rehearsing the N > 1 plumbing on a box without N GPUs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses GPU 0 (with --control gloo: the rank spawn, CPU pinning, per-rank lines and the gather leg run with "
+                         "world > 1 on a one-GPU box; the numbers of such a run mean nothing)")
     ap.add_argument("--workload", choices=["uniform", "corpus"], default="uniform",
                     help="uniform = one shape for every stream (default); corpus = configs[2]: --files mixed "
                          "mono/stereo files, levels 7-9, 1-60 s (sharded by file over the ranks with --gpus N)")
@@ -101,7 +107,7 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (this process never touches a GPU)."""
     n = args.gpus
     have = visible_gpus()
-    if have < n:
+    if have < (1 if args.share_device else n):
         raise SystemExit("bench.py: %d GPUs requested, %d visible" % (n, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -213,10 +219,31 @@ def copy_ceiling():
     lib.acm_copy_ceiling_gbs.argtypes = [C.c_size_t, C.c_char_p, C.c_size_t]
     name = C.create_string_buffer(96)
     gbs = lib.acm_copy_ceiling_gbs(4 << 30, name, 96)
-    return (round(gbs, 1), name.value.decode()) if gbs > 0 else None
+    if gbs <= 0:
+        return None
+    one_way = (C.c_double * 2)()
+    lib.acm_one_way_gbs.argtypes = [C.c_size_t, C.POINTER(C.c_double)]
+    if lib.acm_one_way_gbs(4 << 30, one_way) != 0:
+        one_way = (None, None)
+    return round(gbs, 1), name.value.decode(), [round(v, 1) if v else None for v in one_way]
 
 
-def live_traffic(args, kernel_words=("acm_tile2", "acm_fused")):          # "acm_tile2" also matches the packed build, acm_tile2p
+_POISON = None
+
+
+def poison(d_ptr, nbytes):
+    """fill a device buffer with a pattern no decode leaves behind (0xA5 bytes) before another staged form is timed and verified: a
+    form whose kernel skipped or mis-addressed tiles must not find the previous form's correct samples in its place"""
+    global _POISON
+    if _POISON is None:
+        lib = C.CDLL(os.path.join(ROOT, "profiles", "ubench", "libcopybw.so"))
+        lib.acm_poison.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        _POISON = lib.acm_poison
+    if _POISON(d_ptr, nbytes, 0xA5) != 0:
+        raise SystemExit("bench.py: could not poison the PCM buffer")
+
+
+def live_traffic(args, kernel_words=("acm_tile2", "acm_fused", "acm_chunk")):          # "acm_tile2" also matches the packed build, acm_tile2p
     """HBM bytes per launch of the tile kernel, measured on THIS box in THIS run: two child runs of this command under
     rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else enabled - MI355X_MICROARCH.md "HBM"),
     a handful of launches each with the same staged input.  FETCH_SIZE is doubled (gfx950 tallies its 128-byte requests at
@@ -453,7 +480,7 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
         return len(ok)
 
     def timed(pl):
-        dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+        poison(bufs[2], 2 * b.pcm_words)
         precondition(dev, pl, bufs, 0.2)
         _, ms = time_plan(dev, pl, bufs, steps, 5, lambda: None)
         rate = b.samples * steps / (ms * 1e-3)
@@ -496,9 +523,13 @@ def main():
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     have = visible_gpus()
-    if have < local_world:
+    if have < (1 if args.share_device else local_world):
         raise SystemExit("bench.py: %d GPUs requested, %d visible" % (local_world, have))
     pin_rank_cpus(local, local_world)
+    if args.share_device:
+        local = 0                                          # every rank on GPU 0 (a rehearsal of the N > 1 plumbing, not a measurement)
+    if args.control == "gloo" and not args.share_device and world > 1:
+        raise SystemExit("bench.py: --control gloo is for rehearsals (--share-device); real N > 1 runs use RCCL")
 
     import torch
     dist = None
@@ -510,14 +541,18 @@ def main():
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
             s.close()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.control == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from libacm_amd import capi, workload
     if capi.device_count() <= 0:
         raise SystemExit("bench.py: no HIP device - the hot path has no CPU fallback")
     dev = capi.Device(local)
 
-    sync_t = torch.zeros(1, device="cuda:%d" % local) if dist is not None else None
+    cdev = "cpu" if args.control == "gloo" else "cuda:%d" % local          # where the control tensors (and, with gloo, the gathered PCM) live
+    sync_t = torch.zeros(1, device=cdev) if dist is not None else None
 
     def barrier():
         if dist is not None:
@@ -613,7 +648,7 @@ def main():
         nsteps = max(args.steps, min(SUSTAINED_STEPS, 100))
 
         def time_form(name, pl, extra):
-            dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+            poison(bufs[2], 2 * batch.pcm_words)        # nothing of the previous form's (correct) PCM may survive a launch that skips tiles
             _, oev = time_plan(dev, pl, bufs, nsteps, 5, lambda: None)
             oms = oev / nsteps
             o = {"form": name, "launch_ms": round(oms, 4), "steps": nsteps,
@@ -676,15 +711,15 @@ def main():
 
     # max over ranks of the bracketed wall time
     if dist is not None:
-        t = torch.tensor([wall], device="cuda:%d" % local, dtype=torch.float64)
+        t = torch.tensor([wall], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t.item())
-        s = torch.tensor([float(batch.samples), float(n_verified)], device="cuda:%d" % local, dtype=torch.float64)
+        s = torch.tensor([float(batch.samples), float(n_verified)], device=cdev, dtype=torch.float64)
         dist.all_reduce(s)
         total_samples, n_verified = float(s[0].item()), int(s[1].item())
         # why the N-rank number is what it is: every rank's own launch time and sample count (the corpus is sharded
         # longest-first by header weight; a rank that got more samples, or a slower chip, sets the job's time)
-        mine = torch.tensor([ev_ms / args.steps, float(batch.samples), float(len(batch.descs))], device="cuda:%d" % local, dtype=torch.float64)
+        mine = torch.tensor([ev_ms / args.steps, float(batch.samples), float(len(batch.descs))], device=cdev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [{"rank": r, "launch_ms": round(float(e[0]), 4), "msamples": round(float(e[1]) / 1e6, 1), "streams": int(e[2])}
@@ -696,11 +731,13 @@ def main():
     # ---- C2 (N > 1): gather of every rank's PCM into rank 0's HBM over RCCL/xGMI, reported beside the headline
     gather = None
     if dist is not None and world > 1 and not args.no_gather:
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda:%d" % local) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([batch.pcm_words], dtype=torch.int64, device="cuda:%d" % local))
+        sizes = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([batch.pcm_words], dtype=torch.int64, device=cdev))
         sizes = [int(x.item()) for x in sizes]
         wire = pcm_t.view(torch.uint8)
-        recv = [torch.empty(2 * sizes[r], dtype=torch.uint8, device="cuda:%d" % local) for r in range(1, world)] if rank == 0 else []
+        if args.control == "gloo":
+            wire = wire.cpu()                              # (a rehearsal: gloo moves host memory)
+        recv = [torch.empty(2 * sizes[r], dtype=torch.uint8, device=cdev) for r in range(1, world)] if rank == 0 else []
         gt = []
         for rep in range(3):
             barrier()
@@ -778,24 +815,37 @@ def main():
                    "staged_form": ("packed: width class per column pair and 16-row group + residuals at 0/4/8/16 bits (%.3f B/sample), "
                                    "{val, pwr} per block; written by the host stager (acmhip_pack_tiles)" % (pk.nbytes / batch.samples))
                                   if pk else
-                                  ("byteplane: every row pair's indices at the narrowest of 4 / 8 / 16 bits that holds them (%.3f B/sample here; "
+                                  ("byteplane: every row pair's indices at the narrowest of 4 / 8 / 16 bits that holds them (8 / 16 at a level of the chunk "
+                                   "kernel, where a 16-bit index is two signed bytes; %.3f B/sample here; "
                                    "pairs at 4 / 8 / 16 bits: %d / %d / %d), per row in groups of %s columns a residue class apart (the order the "
                                    "matrix cores read operands in) + a 4-byte entry per pair + {val, pwr} per block; written by the host stager "
                                    "(acm_stage_file + acmhip_mform_rows, %.2f s for this batch)" % (
                                        (mf.nbytes / batch.samples,) + tuple(int(x) for x in mf.class_counts()[1:4]) +
-                                       ("8 or 16" if args.workload == "corpus" else str(capi.lib().acmhip_mform_group(args.level)), t_mform))) if mf else
+                                       ("8, 16 or 64" if args.workload == "corpus" else str(capi.lib().acmhip_mform_group(args.level)), t_mform))) if mf else
                                   "int16 index per sample + {val, pwr} per block, written by the host stager (acm_stage_file)",
                    "untimed_precondition_launches": pre},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_committed_profile": traffic_committed, "frac_of_peak_on_measured_traffic": frac_measured,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": ("acm_tile2%s<TileCfg<%s,%d,%d>%s> (+ acm_fused_tile on ragged tails)" % (
+                     "kernel": (("acm_chunk<%s>: six stages on v_mfma_i32_16x16x64_i8, one wavefront per 2048-sample chunk, one LDS pass group behind "
+                                 "(+ acm_fused_tile on ragged tails)" % lv_txt)
+                                if mf and args.workload == "uniform" and capi.lib().acmhip_mform_group(args.level) == 64 else
+                                "acm_tile2%s<TileCfg<%s,%d,%d>%s> (+ acm_fused_tile on ragged tails)" % (
                                     ("p" if pk else "", lv_txt) + K2_GEOMETRY.get(args.level, (256, 8192)) +
-                                    (", first pass on v_mfma_i32_16x16x32_i8" if mf else "",))
+                                    (", first pass on the matrix cores (acm_chunk at the levels that have it)" if mf and args.workload == "corpus" else
+                                     ", first pass on v_mfma_i32_16x16x32_i8" if mf else "",))
                                 if args.workload == "corpus" or 6 <= args.level <= 14 else "see DESIGN.md section 2 for level %s" % lv_txt),
-                     "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
+                     "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE,
+                     # the same launch on the bytes it really moved (task 6): `achieved` / `frac` price SURVEY's canonical 4 B/sample
+                     "achieved_real_gbs": round(traffic / (launch_ms * 1e-3) / 1e9, 1) if traffic else None},
     }
+    if args.share_device or args.control == "gloo":
+        out["rehearsal"] = ("every rank on GPU 0, control and gather through gloo: the N > 1 plumbing (rank spawn, CPU slices, per-rank lines, "
+                            "gather leg) is exercised, the numbers mean nothing")
+    if world == 1:
+        out["multi_gpu"] = ("no N > 1 run on hardware exists for this code: the pool it is developed on hands out one GPU at a time "
+                            "(N > 1 is covered by gloo tests on CPU with up to eight ranks and by a two-rank rehearsal on one GPU)")
     if per_rank:
         ms = [p["launch_ms"] for p in per_rank]
         sm = [p["msamples"] for p in per_rank]
@@ -845,6 +895,10 @@ def main():
                     out["roofline"]["d2d_copy_gbs"] = best[0]
                     out["roofline"]["d2d_copy_kernel"] = best[1] + " (profiles/ubench/copy_bw.hip, best of five 16-B-per-lane copy kernels)"
                     out["roofline"]["frac_of_d2d_copy"] = round(achieved / best[0], 4)
+                    # ... and the honest one: measured bytes against the copy kernel's measured bytes
+                    out["roofline"]["frac_of_d2d_copy_on_measured_traffic"] = (
+                        round(traffic / (launch_ms * 1e-3) / 1e9 / best[0], 4) if traffic else None)
+                    out["roofline"]["read_only_gbs"], out["roofline"]["write_only_gbs"] = best[2]
             except Exception as e:
                 out["roofline"]["d2d_copy_gbs"] = None
                 out["roofline"]["d2d_copy_error"] = str(e)[:120]
@@ -852,7 +906,9 @@ def main():
             extra = []
             # configs[1] and a level-11 batch with the headline's sample count; configs[4] at its full size (65 536 distinct stereo
             # streams, 17.2 Gsamples, 34 GB of staged indices + 34 GB of PCM in HBM; ~1 min of staging)
-            for (lv, rw, bl, ns, ch) in ((7, 16, 1000, 1024, 1), (11, 64, 16, 1024, 1), (11, 64, 2, 65536, 2)):
+            # ... and levels 10, 12, 13, 14 with the headline's sample count (task 2: a driver-side number for each)
+            for (lv, rw, bl, ns, ch) in ((7, 16, 1000, 1024, 1), (11, 64, 16, 1024, 1), (10, 16, 125, 1024, 1), (12, 64, 8, 1024, 1), (13, 64, 4, 1024, 1),
+                                         (14, 8, 16, 1024, 1), (11, 64, 2, 65536, 2)):
                 if (lv, rw, bl, ns, ch) == (args.level, args.rows, args.blocks, args.streams, args.channels):
                     continue
                 try:
@@ -909,6 +965,8 @@ def main():
 
     plan.destroy()
     for p in pk_ptrs or ():
+        dev.free(p)
+    for p in d_mf or ():
         dev.free(p)
     if dist is not None:
         dev.free(bufs[0])

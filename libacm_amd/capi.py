@@ -83,7 +83,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
-    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
+    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
@@ -136,6 +136,7 @@ def lib():
     L.acmhip_plan_destroy.restype = None
     L.acmhip_plan_launch.argtypes = [vp, vp, vp, vp, C.c_uint]
     L.acmhip_plan_get_stats.argtypes = [vp, C.POINTER(PlanStats)]
+    L.acmhip_plan_form_rows.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint64)]
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
     L.acm_stage_probe.argtypes = [vp, sz, C.c_int, C.POINTER(StageInfo)]
     L.acm_stage_file.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp, sz, C.POINTER(StageInfo)]
@@ -497,6 +498,12 @@ class Plan:
         st = PlanStats()
         _check(lib().acmhip_plan_get_stats(self.h, C.byref(st)), "acmhip_plan_get_stats")
         return st
+
+    def form_rows(self, stream):
+        """rows of stream `stream` this plan reads from the stream's second staged form (0: none of them)"""
+        rows = C.c_uint64()
+        _check(lib().acmhip_plan_form_rows(self.h, stream, C.byref(rows)), "acmhip_plan_form_rows")
+        return rows.value
 
     def destroy(self):
         if self.h:

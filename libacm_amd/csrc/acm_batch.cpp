@@ -1244,10 +1244,18 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				 * the blocks of the streams that have one); of the int16 arena only what the other kernels read - streams without
 				 * a second form, and behind a stream's whole tiles its ragged tail with the two rows in front of it */
 				if (stage_mform) {
+					size_t in_plan_mf = 0;
 					for (size_t i = ch.first; i < ch.last; i++) {
 						const Slot &s = slots[i];
-						if (!s.ok || !s.pk_ntiles)
+						if (!s.ok || items[i].words == 0)
 							continue;
+						const size_t at = in_plan_mf++;
+						if (!s.pk_ntiles)
+							continue;
+						uint64_t rows2 = 0;
+						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
+						if (!rows2)
+							continue;               /* the plan reads this stream's int16 rows (see below): its byte-plane block stays here */
 						const uint64_t npairs = acmhip_mform_pairs((uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level));
 						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, s.mf_used, hipMemcpyHostToDevice, st_main));
 						HTRY(hipMemcpyAsync(reinterpret_cast<acmhip_mform_pair *>(d_pkchunk) + s.mf_pair_off,
@@ -1266,20 +1274,22 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						HTRY(hipMemcpyAsync(d_pkchunk + ch.pk_chunk_begin, h_pkchunk + ch.pk_chunk_begin,
 								    (ch.pk_chunk_end - ch.pk_chunk_begin) * sizeof(acmhip_packed_chunk), hipMemcpyHostToDevice, st_main));
 				}
+				size_t in_plan = 0;            /* position among the descriptors build_plan() made the chunk's plan from */
 				for (size_t i = ch.first; i < ch.last; i++) {
 					const Slot &s = slots[i];
-					if (!s.ok || s.info.blocks == 0)
+					if (!s.ok || items[i].words == 0)
+						continue;
+					const size_t at = in_plan++;
+					if (s.info.blocks == 0)
 						continue;
 					const uint64_t cols = s.info.cols, nrows = (uint64_t)s.info.blocks * s.info.rows;
 					uint64_t from_row = 0;
 					if (s.pk_ntiles) {
-						/* what the plan takes from the second form: whole tiles of the lean kernel's own height (a byte-plane tile may
-						 * be a fraction of one) */
-						uint64_t rows2 = (uint64_t)s.pk_ntiles * (uint64_t)(stage_mform ? acmhip_mform_tile_rows(s.info.level)
-														    : acmhip_packed_tile_rows(s.info.level));
-						if (stage_mform && acmk_tile2_rows(s.info.level) > 0)
-							rows2 = rows2 / (uint64_t)acmk_tile2_rows(s.info.level) * (uint64_t)acmk_tile2_rows(s.info.level);
-						if (rows2 * cols >= items[i].words)
+						/* what the plan really takes from the second form - asked of the plan, not assumed: a level-13 / 14 stream of a
+						 * small plan (or with ACM_PREFIX=0) goes to kernels that read the int16 rows from row 0 on */
+						uint64_t rows2 = 0;
+						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
+						if (rows2 && rows2 * cols >= items[i].words)
 							continue;               /* nothing behind the whole tiles is emitted */
 						from_row = rows2 >= 2 ? rows2 - 2 : 0;
 					}

@@ -97,6 +97,7 @@ struct acmhip_plan {
 	AcmDevStream *d_streams = nullptr;
 	std::vector<LevelGroup> fused, stagewise, small, prefix;   /* small: levels 0-4, one register-cascade launch; prefix: levels 13-15 */
 	int16_t *d_sink = nullptr;             /* acm_tile2: where lead-in tiles store the PCM nobody wants */
+	std::vector<uint64_t> form_rows;       /* per stream: rows the plan reads from the stream's second staged form (acmhip_plan_form_rows) */
 	uint32_t *d_sw_all = nullptr;          /* every stage-wise stream, for the unpack launch */
 	uint32_t n_sw_all = 0;
 	uint64_t sw_max_elems = 0;
@@ -497,6 +498,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	for (auto &v : patch_rows)
 		std::sort(v.begin(), v.end());
 	std::vector<std::vector<AcmTile2>> tiles2(16), tiles2p(16), tiles2p_plain(16), tiles2m(16), tiles2m_plain(16);
+	std::vector<uint64_t> form_rows(n, 0);         /* rows of every stream the plan reads from its second staged form */
 	/* rows [0, rows2) of stream i as records of the lean tile kernel (T2 rows each), and, where the stream came with a second staged form,
 	 * once more as records of the build that reads it */
 	auto cut_lean = [&](size_t i, uint64_t rows2, uint32_t T2) -> int {
@@ -515,6 +517,8 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				(unsigned long long)(rows2 / (mf ? T2M : T2)));
 			return ACMHIP_ERR_ARG;
 		}
+		if (pk || mf)
+			form_rows[i] = rows2;
 		std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : mf ? tiles2m_plain[s.level] : tiles2[s.level];
 		for (uint64_t r = 0; r < rows2; r += T2) {
 			const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
@@ -775,6 +779,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		return ACMHIP_ERR_NOMEM;
 	pl->dev = dev;
 	pl->variant = variant;
+	pl->form_rows = std::move(form_rows);
 	int rc = to_device(pl, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
 		if (!tiles[lv].empty() || !tiles_extra[lv].empty() || !tiles2[lv].empty() || !tiles2p[lv].empty() || !tiles2m[lv].empty()) {
@@ -907,6 +912,14 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	}
 	pl->stats = st;
 	*out = pl;
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_plan_form_rows(const acmhip_plan *plan, size_t stream, uint64_t *rows)
+{
+	if (!plan || !rows || stream >= plan->form_rows.size())
+		return ACMHIP_ERR_ARG;
+	*rows = plan->form_rows[stream];
 	return ACMHIP_OK;
 }
 

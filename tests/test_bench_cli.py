@@ -39,3 +39,23 @@ def test_no_gpu_no_number():
     r = run_bench(["--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "visible" in r.stderr or "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu():
+    """VERDICT r4, task 4 (ii): `bench.py --gpus 2 --control gloo --share-device` - two fresh rank processes on GPU 0, control collectives and
+    the gather leg through gloo - exercises what the first real N > 1 run will: the rank spawn, the CPU slices, the barrier / max-over-ranks
+    timing, `per_rank`, `imbalance`, `gather_c2` and the ONE JSON line from rank 0, with every stream of both ranks verified"""
+    import json
+    r = run_bench(["--gpus", "2", "--control", "gloo", "--share-device", "--streams", "48", "--blocks", "12", "--steps", "3", "--warmup", "1",
+                   "--no-extra", "--no-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["verified_vs_oracle"] is True and j["verified_streams"] == 96
+    assert [p["rank"] for p in j["per_rank"]] == [0, 1] and all(p["streams"] == 48 and p["launch_ms"] > 0 for p in j["per_rank"])
+    assert j["imbalance"]["samples_max_over_mean"] == 1.0
+    assert j["gather_c2"]["bytes_into_rank0"] > 0 and j["gather_c2"]["seconds"] > 0
+    assert "rehearsal" in j and "multi_gpu" not in j
+    assert j["value"] > 0 and j["scaling"] == "weak"

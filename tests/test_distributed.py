@@ -237,6 +237,77 @@ def test_two_ranks_gloo(by_path, product_parser, chunks, tmp_path):
     assert q.get(timeout=5) == "ok"
 
 
+def mini_corpus(n=40):
+    """enough small files for three chunks and more on each of eight ranks"""
+    # (about equal weights - the shards are cut longest first by weight, and every rank is to get five files - but every file its own shape)
+    shapes = [(5, 16, 8), (7, 16, 2), (6, 8, 8), (8, 5, 3), (7, 3, 11)]
+    return [make_stream(4500 + i, shapes[i % 5][0], shapes[i % 5][1], shapes[i % 5][2], channels=1 + i % 2, cut=i % 3) for i in range(n)]
+
+
+def _worker8(rank, world, port, q, paths):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        trace = []
+        out = batch.decode_sharded(paths if rank == 0 else None, oracle_decoder, dist=dist, root=0, device=torch.device("cpu"), chunks=3, ring=2,
+                                   trace=trace)
+        nch = sum(1 for e in trace if e[0] == "decode")
+        assert nch == 3, (rank, trace)                  # 40 files over 8 ranks: five each, three chunks
+        check_pipeline_trace(trace, rank, nch, 2)
+        if rank == 0:
+            h = hashlib.sha256()
+            for st, pcm in out:
+                h.update(np.int32(st).tobytes() + pcm.tobytes())
+            q.put(("digest", h.hexdigest()))
+        else:
+            assert out is None
+            q.put(("ok", rank))
+    except Exception as e:
+        q.put(("error", "rank %d: %r" % (rank, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_gloo(tmp_path):
+    """the configs[3] shape in miniature, without hardware (task 4): eight ranks, the file list on rank 0 only, three chunks per
+    rank through a receive ring of two on the root.  The concatenated (status, PCM) digest on the root equals the one-process digest, every
+    file's PCM equals the oracle's, and the order of events holds on every rank: send of chunk k posted before decode k + 1 and first
+    waited for behind it; receives posted before the root's first decode and never more than two outstanding"""
+    import hashlib
+    import torch.multiprocessing as mp
+    files = mini_corpus()
+    paths = []
+    for k, f in enumerate(files):
+        p = tmp_path / ("m%02d.acm" % k)
+        p.write_bytes(bytes(f))
+        paths.append(str(p))
+    single = batch.decode_sharded(paths, oracle_decoder)
+    check(single, files)
+    h = hashlib.sha256()
+    for st, pcm in single:
+        h.update(np.int32(st).tobytes() + pcm.tobytes())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, paths)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = [q.get(timeout=5) for _ in range(8)]
+    assert not [g for g in got if g[0] == "error"], got
+    assert ("digest", h.hexdigest()) in got and sorted(g[1] for g in got if g[0] == "ok") == list(range(1, 8))
+
+
 def test_bytes_on_root_only_is_refused():
     """file contents are never scattered: images passed on the root alone cannot reach the other ranks"""
     class FakeDist:

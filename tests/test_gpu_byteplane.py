@@ -205,6 +205,41 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
             assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
 
 
+def test_batch_first_call_on_a_fresh_device_with_small_high_level_streams():
+    """a byte-plane batch must not rely on int16 rows an EARLIER call left in the device arena.  A few level-13 / 14 streams are
+    too few tiles for the lean kernel (the plan sends them to the prefix + plane pair, which reads the int16 arena from row 0): their
+    int16 rows have to travel although a byte-plane block was staged for them.  First call on a device handle of its own, nothing decoded
+    before it; then once more behind a decoy batch of other files of the same sizes."""
+    import oracle_api as O
+    files = [make_stream(27500 + i, [13, 14, 13, 9, 14, 11][i % 6], [4, 2, 6, 16, 3, 8][i % 6], 6 + i % 3, pwr_max=9) for i in range(12)]
+    decoy = [make_stream(27600 + i, [13, 14, 13, 9, 14, 11][i % 6], [4, 2, 6, 16, 3, 8][i % 6], 6 + i % 3, pwr_max=9) for i in range(12)]
+    fresh = capi.Device(0)
+    try:
+        for batch in (files, decoy, files):
+            res, tm = capi.batch_decode(fresh, batch, threads=2, byteplane=True)
+            assert tm.packed_streams >= 4
+            for k, f in enumerate(batch):
+                assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
+    finally:
+        fresh.close()
+
+
+def test_plan_says_which_rows_it_reads_from_the_second_form(dev, monkeypatch):
+    """acmhip_plan_form_rows: whole tiles of the lean kernel for a stream that came with the form, 0 for one without, and 0 for a level-14
+    stream of a plan too small for the lean kernel (its rows are read from the int16 arena)"""
+    monkeypatch.delenv("ACM_K2", raising=False)
+    files = [make_stream(27700, 9, 16, 12), make_stream(27701, 6, 16, 40), make_stream(27702, 14, 2, 9)]
+    staged = [capi.stage_file(f) for f in files]
+    ar = capi.Arena(staged)
+    mf = capi.mform_streams(ar.idx, ar.descs)
+    assert mf.streams[0].ntiles > 0 and mf.streams[1].ntiles == 0 and mf.streams[2].ntiles > 0
+    plan = capi.Plan(dev, ar.descs, packed=mf.streams)
+    assert plan.form_rows(0) == 12 * 16 and plan.form_rows(1) == 0 and plan.form_rows(2) == 0
+    with pytest.raises(capi.AcmHipError):
+        plan.form_rows(3)
+    plan.destroy()
+
+
 @pytest.mark.parametrize("g0", [3, 4])
 def test_byteplane_both_first_pass_depths(g0):
     """every level has its measured default (three or four stages on the matrix cores); ACM_K2M_G0 forces the other build and the
