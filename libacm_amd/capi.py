@@ -83,7 +83,7 @@ ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
     "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
-    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file",
+    "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file", "acm_stage_file_mform",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
     "acmhip_plan_create_packed", "acmhip_plan_bind_packed",
@@ -140,6 +140,7 @@ def lib():
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
     L.acm_stage_probe.argtypes = [vp, sz, C.c_int, C.POINTER(StageInfo)]
     L.acm_stage_file.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp, sz, C.POINTER(StageInfo)]
+    L.acm_stage_file_mform.argtypes = [vp, sz, C.c_int, vp, vp, sz, C.POINTER(StageInfo), vp, C.c_uint64, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acm_batch_decode.argtypes = [vp, C.POINTER(BatchItem), sz, C.POINTER(BatchOpts), C.POINTER(BatchTiming)]
     L.acm_batch_pcm_words.argtypes = [C.POINTER(BatchItem), sz, C.c_int]
     L.acm_batch_pcm_words.restype = C.c_uint64
@@ -242,6 +243,29 @@ def stage_file(data, force_chans=0, idx_out=None, hdr_out=None):
         rc = lib().acm_stage_file(a.ctypes.data, a.size, force_chans, idx.ctypes.data, hdr.ctypes.data, need,
                                   patches, info2.npatches, C.byref(info2))
     return Staged(idx[:info2.blocks * bl], hdr[:info2.blocks], patches, info2)
+
+
+def stage_file_mform(data, force_chans=0, mf_base=0):
+    """acm_stage_file_mform: the byte-plane form written by the parsing pass itself.  Returns (info, idx, hdr, blob, pairs, mf_rows, mf_bytes);
+    idx is filled with -12345 beforehand, so the rows the call leaves alone show."""
+    a = _as_u8(data)
+    rc, info = probe(a, force_chans)
+    if rc != 0:
+        raise ValueError("not an ACM stream (%d)" % rc)
+    bl = info.rows * info.cols
+    need = (info.total_values + bl - 1) // bl
+    idx = np.full(need * bl, -12345, dtype=np.int16)
+    hdr = np.zeros((need, 2), dtype=np.uint32)
+    nrows = (need * info.rows) & ~1
+    blob = np.zeros(int(lib().acmhip_mform_bytes(info.level, nrows)) + 256, dtype=np.uint8)
+    pairs = np.zeros(int(lib().acmhip_mform_pairs(nrows)) + 32, dtype=np.uint32)
+    info2 = StageInfo()
+    rows, nbytes = C.c_uint64(), C.c_uint64()
+    rc = lib().acm_stage_file_mform(a.ctypes.data, a.size, force_chans, idx.ctypes.data, hdr.ctypes.data, need, C.byref(info2),
+                                    blob.ctypes.data, mf_base, pairs.ctypes.data, C.byref(rows), C.byref(nbytes))
+    if rc != 0:
+        raise ValueError("acm_stage_file_mform failed (%d)" % rc)
+    return info2, idx, hdr, blob, pairs, rows.value, nbytes.value
 
 
 # --------------------------------------------------------------------------- host staging, packed half

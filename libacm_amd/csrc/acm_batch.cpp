@@ -166,6 +166,7 @@ struct Slot {
 	/* ACM_BATCH_STAGE_BYTEPLANE: where the stream's byte-plane block sits in the blob arena (bytes) and how many rows it may hold;
 	 * pk_ntiles = the whole tiles the pool staged that way */
 	uint64_t mf_off = 0, mf_rows_cap = 0, mf_used = 0;
+	bool mf_fused = false;                          /* the form was written by the parsing pass itself (acm_stage_file_mform) */
 	uint64_t mf_pair_off = 0;       /* its first entry in the pair table */
 };
 
@@ -189,6 +190,7 @@ struct Chunk {
 	std::atomic<uint64_t> pk_used{ 0 };     /* ACM_BATCH_STAGE_PACKED: bytes of this chunk's blob region handed out so far */
 	uint64_t pk_chunk_begin = 0, pk_chunk_end = 0;  /* its range of the chunk table (entries) */
 	uint64_t mf_begin = 0, mf_end = 0;              /* ACM_BATCH_STAGE_BYTEPLANE: its range of the blob arena (bytes) */
+	uint64_t mf_pair_begin = 0, mf_pair_end = 0;    /* ... and of the pair table (entries) */
 	std::atomic<int> back{ 0 };             /* 1 = PCM is in the pinned arena, -1 = the read-back failed */
 	acmhip_plan *plan = nullptr;
 	hipEvent_t ev[5] = {};                  /* h2d begin, h2d end, kernel end (device stream); d2h begin, d2h end (copy stream) */
@@ -501,6 +503,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		stage_packed = false;           /* one second form per batch */
 		for (size_t c = 0; c < chunks.size(); c++) {
 			chunks[c].mf_begin = mf_total;
+			chunks[c].mf_pair_begin = mf_pairs_total;
 			for (size_t i = chunks[c].first; i < chunks[c].last; i++) {
 				Slot &s = slots[i];
 				if (!s.ok || acmhip_mform_tile_rows(s.info.level) <= 0)
@@ -512,6 +515,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				mf_pairs_total += acmhip_mform_pairs(s.mf_rows_cap);
 			}
 			chunks[c].mf_end = mf_total;
+			chunks[c].mf_pair_end = mf_pairs_total;
 		}
 	}
 
@@ -755,7 +759,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	/* the byte-plane half: the whole tiles of a clean stream, re-ordered from the int16 rows the reader has just written */
 	auto host_mform = [&](size_t i) {
 		Slot &s = slots[i];
-		if (!stage_mform || !s.ok || !s.mf_rows_cap || !s.patches.empty() || items[i].words == 0)
+		if (!stage_mform || !s.ok || !s.mf_rows_cap || !s.patches.empty() || items[i].words == 0 || s.mf_fused)
 			return;
 		const int tr = acmhip_mform_tile_rows(s.info.level);
 		const uint64_t full_rows = std::min<uint64_t>((uint64_t)s.info.blocks * s.info.rows, items[i].words >> s.info.level);
@@ -797,9 +801,22 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			it.words = deliverable_words(ps.info.total_values, bl, ps.info.channels, ps.info.blocks);
 			return;
 		}
-		/* first pass counts patches (normally zero), second only if there are any */
-		int r = acm_stage_file(it.data, it.len, opts.force_chans, h_idx + s.idx_off, h_hdr + s.hdr_off,
-				       s.need_blocks, nullptr, 0, &info);
+		/* first pass counts patches (normally zero), second only if there are any.  With ACM_BATCH_STAGE_BYTEPLANE the first pass also
+		 * writes the byte-plane form, block by block out of the cache (acm_stage_file_mform), where the stream can have it */
+		int r;
+		if (stage_mform && s.mf_rows_cap) {
+			uint64_t mf_rows = 0, mf_bytes = 0;
+			r = acm_stage_file_mform(it.data, it.len, opts.force_chans, h_idx + s.idx_off, h_hdr + s.hdr_off, s.need_blocks, &info,
+						 h_pkblob + s.mf_off, s.mf_off, reinterpret_cast<acmhip_mform_pair *>(h_pkchunk) + s.mf_pair_off, &mf_rows,
+						 &mf_bytes);
+			if (r == ACM_OK && mf_rows && mf_rows <= s.mf_rows_cap) {
+				s.pk_ntiles = (uint32_t)(mf_rows / (uint64_t)acmhip_mform_tile_rows(info.level));
+				s.mf_used = mf_bytes;
+				s.mf_fused = true;
+			}
+		} else {
+			r = acm_stage_file(it.data, it.len, opts.force_chans, h_idx + s.idx_off, h_hdr + s.hdr_off, s.need_blocks, nullptr, 0, &info);
+		}
 		if (r == ACM_OK && info.npatches) {
 			s.patches.resize(info.npatches);
 			r = acm_stage_file(it.data, it.len, opts.force_chans, h_idx + s.idx_off, h_hdr + s.hdr_off,
@@ -1256,12 +1273,16 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
 						if (!rows2)
 							continue;               /* the plan reads this stream's int16 rows (see below): its byte-plane block stays here */
-						const uint64_t npairs = acmhip_mform_pairs((uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level));
 						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, s.mf_used, hipMemcpyHostToDevice, st_main));
-						HTRY(hipMemcpyAsync(reinterpret_cast<acmhip_mform_pair *>(d_pkchunk) + s.mf_pair_off,
-								    reinterpret_cast<acmhip_mform_pair *>(h_pkchunk) + s.mf_pair_off, npairs * sizeof(acmhip_mform_pair),
-								    hipMemcpyHostToDevice, st_main));
-						tm.h2d_bytes += s.mf_used + npairs * sizeof(acmhip_mform_pair);
+						tm.h2d_bytes += s.mf_used;
+					}
+					/* the chunk's pair-table entries in one piece (a few bytes per thousand samples; entries of streams without the form
+					 * travel with them unread) instead of a transfer per stream */
+					if (ch.mf_pair_end > ch.mf_pair_begin) {
+						HTRY(hipMemcpyAsync(reinterpret_cast<acmhip_mform_pair *>(d_pkchunk) + ch.mf_pair_begin,
+								    reinterpret_cast<acmhip_mform_pair *>(h_pkchunk) + ch.mf_pair_begin,
+								    (ch.mf_pair_end - ch.mf_pair_begin) * sizeof(acmhip_mform_pair), hipMemcpyHostToDevice, st_main));
+						tm.h2d_bytes += (ch.mf_pair_end - ch.mf_pair_begin) * sizeof(acmhip_mform_pair);
 					}
 					tm.h2d_bytes += (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr);
 				} else {
@@ -1289,6 +1310,15 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						 * small plan (or with ACM_PREFIX=0) goes to kernels that read the int16 rows from row 0 on */
 						uint64_t rows2 = 0;
 						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
+						if (s.mf_fused && rows2 != (uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level)) {
+							/* the parsing pass wrote only the int16 rows behind the tiles it put into the form: a plan that reads fewer of
+							 * them from the form would decode rows that were never staged (cannot happen for the levels it is used at) */
+							fprintf(stderr, "acm_batch_decode: stream %zu: the plan reads %llu rows from the byte-plane form, %llu were staged that way\n",
+								i, (unsigned long long)rows2, (unsigned long long)s.pk_ntiles * (unsigned long long)acmhip_mform_tile_rows(s.info.level));
+							rc = ACMHIP_ERR_ARG;
+							cleanup();
+							return rc;
+						}
 						if (rows2 && rows2 * cols >= items[i].words)
 							continue;               /* nothing behind the whole tiles is emitted */
 						from_row = rows2 >= 2 ? rows2 - 2 : 0;

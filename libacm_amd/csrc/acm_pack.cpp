@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "acm_device.h"
+#include "acm_mform.h"
 #include "acm_hip.h"
 
 namespace {
@@ -400,43 +401,105 @@ void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, bool spl
 inline bool split_form(size_t qn) { return qn == 64; }
 } // namespace
 
-extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,
-				 uint64_t *bytes_used)
+int acm_mform_begin(AcmMformWriter *w, uint32_t level, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs)
 {
 	const size_t qn = (size_t)acmhip_mform_group(level);
-	if (!qn || (!idx && nrows) || !out || !pairs || (nrows & 1) || (blob_base & 63))
+	if (!w || !qn || !out || !pairs || (blob_base & 63))
 		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / qn;
-	uint64_t at = 0;
-	const bool split = split_form(qn);
+	w->level = level;
+	w->qn = qn;
+	w->cols = (size_t)1 << level;
+	w->sigma = w->cols / qn;
+	w->split = split_form(qn);
+	w->out = out;
+	w->blob_base = blob_base;
+	w->pairs = pairs;
+	w->at = 0;
 	/* the pair in front of the stream: index 0 everywhere, at 4 bits (8 in the chunk kernel's form, which has no narrower class) */
 	if ((blob_base >> 6) >= (1ull << 30))
 		return ACMHIP_ERR_ARG;                  /* more than 64 GB in front of this block: the pair table counts 64-byte units in 30 bits */
-	const uint32_t cls_front = split ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE;
-	pairs[0] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | cls_front);
-	memset(out, split ? 0 : 0x88, pair_bytes(level, cls_front));
-	at += pair_bytes(level, cls_front);
-	for (uint64_t p = 0; p < nrows / 2; p++) {
-		const int16_t *src = idx + 2 * p * cols;
-		int lo = 0, hi = 0;
-		for (size_t m = 0; m < 2 * cols; m++) {
-			lo = src[m] < lo ? src[m] : lo;
-			hi = src[m] > hi ? src[m] : hi;
+	const uint32_t cls_front = w->split ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE;
+	pairs[0] = (acmhip_mform_pair)((blob_base >> 6) << 2 | cls_front);
+	memset(out, w->split ? 0 : 0x88, pair_bytes(level, cls_front));
+	w->at = pair_bytes(level, cls_front);
+	w->npairs = 1;
+	return ACMHIP_OK;
+}
+
+int acm_mform_put_pair(AcmMformWriter *w, const int16_t *src)
+{
+	int lo = 0, hi = 0;
+#if defined(__SSE2__)
+	{
+		__m128i vlo = _mm_setzero_si128(), vhi = _mm_setzero_si128();
+		for (size_t m = 0; m < 2 * w->cols; m += 8) {
+			const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + m));
+			vlo = _mm_min_epi16(vlo, x);
+			vhi = _mm_max_epi16(vhi, x);
 		}
-		if (split && hi >= 32640)
-			return ACMHIP_ERR_RANGE;          /* 256 hi + lo with two signed bytes ends at 32639: such a stream stays in the int16 form */
-		const uint32_t cls = (!split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
-		if (((blob_base + at) >> 6) >= (1ull << 30))
-			return ACMHIP_ERR_ARG;
-		pairs[p + 1] = (acmhip_mform_pair)(((blob_base + at) >> 6) << 2 | cls);
-		const size_t rowb = pair_bytes(level, cls) / 2;
-		put_row(src, sigma, qn, cls, split, out + at);
-		put_row(src + cols, sigma, qn, cls, split, out + at + rowb);
-		at += 2 * rowb;
+		int16_t a[8], b[8];
+		_mm_storeu_si128(reinterpret_cast<__m128i *>(a), vlo);
+		_mm_storeu_si128(reinterpret_cast<__m128i *>(b), vhi);
+		for (int k = 0; k < 8; k++) {
+			lo = a[k] < lo ? a[k] : lo;
+			hi = b[k] > hi ? b[k] : hi;
+		}
 	}
-	memset(out + at, 0, kMformSlack);
+#else
+	for (size_t m = 0; m < 2 * w->cols; m++) {
+		lo = src[m] < lo ? src[m] : lo;
+		hi = src[m] > hi ? src[m] : hi;
+	}
+#endif
+	if (w->split && hi >= 32640)
+		return ACMHIP_ERR_RANGE;          /* 256 hi + lo with two signed bytes ends at 32639: such a stream stays in the int16 form */
+	const uint32_t cls = (!w->split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
+	if (((w->blob_base + w->at) >> 6) >= (1ull << 30))
+		return ACMHIP_ERR_ARG;
+	w->pairs[w->npairs++] = (acmhip_mform_pair)(((w->blob_base + w->at) >> 6) << 2 | cls);
+	const size_t rowb = pair_bytes(w->level, cls) / 2;
+	put_row(src, w->sigma, w->qn, cls, w->split, w->out + w->at);
+	put_row(src + w->cols, w->sigma, w->qn, cls, w->split, w->out + w->at + rowb);
+	w->at += 2 * rowb;
+	return ACMHIP_OK;
+}
+
+uint64_t acm_mform_end(AcmMformWriter *w)
+{
+	memset(w->out + w->at, 0, kMformSlack);
+	return w->at + kMformSlack;
+}
+
+int acm_mform_get_pair(uint32_t level, const uint8_t *blob, acmhip_mform_pair entry, int16_t *two_rows)
+{
+	const size_t qn = (size_t)acmhip_mform_group(level);
+	if (!qn || !blob || !two_rows)
+		return ACMHIP_ERR_ARG;
+	const size_t cols = (size_t)1 << level, sigma = cols / qn;
+	const uint32_t cls = entry & 3;
+	if (cls < (split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
+		return ACMHIP_ERR_ARG;
+	const uint8_t *src = blob + ((uint64_t)(entry >> 2) << 6);
+	const size_t rowb = pair_bytes(level, cls) / 2;
+	get_row(src, sigma, qn, cls, split_form(qn), two_rows);
+	get_row(src + rowb, sigma, qn, cls, split_form(qn), two_rows + cols);
+	return ACMHIP_OK;
+}
+
+extern "C" int acmhip_mform_rows(uint32_t level, const int16_t *idx, uint64_t nrows, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs,
+				 uint64_t *bytes_used)
+{
+	if ((!idx && nrows) || (nrows & 1))
+		return ACMHIP_ERR_ARG;
+	AcmMformWriter w;
+	int rc = acm_mform_begin(&w, level, out, blob_base, pairs);
+	for (uint64_t p = 0; rc == ACMHIP_OK && p < nrows / 2; p++)
+		rc = acm_mform_put_pair(&w, idx + 2 * p * w.cols);
+	if (rc != ACMHIP_OK)
+		return rc;
+	const uint64_t used = acm_mform_end(&w);
 	if (bytes_used)
-		*bytes_used = at + kMformSlack;
+		*bytes_used = used;
 	return ACMHIP_OK;
 }
 
@@ -445,17 +508,13 @@ extern "C" int acmhip_mform_unrows(uint32_t level, const uint8_t *blob, const ac
 	const size_t qn = (size_t)acmhip_mform_group(level);
 	if (!qn || !blob || !pairs || (!idx && nrows) || (nrows & 1))
 		return ACMHIP_ERR_ARG;
-	const size_t cols = (size_t)1 << level, sigma = cols / qn;
+	const size_t cols = (size_t)1 << level;
 	std::vector<int16_t> front(2 * cols);
 	for (uint64_t p = 0; p <= nrows / 2; p++) {
-		const uint32_t cls = pairs[p] & 3;
-		if (cls < (split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
-			return ACMHIP_ERR_ARG;
-		const uint8_t *src = blob + ((uint64_t)(pairs[p] >> 2) << 6);
-		const size_t rowb = pair_bytes(level, cls) / 2;
 		int16_t *dst = p ? idx + 2 * (p - 1) * cols : front.data();
-		get_row(src, sigma, qn, cls, split_form(qn), dst);
-		get_row(src + rowb, sigma, qn, cls, split_form(qn), dst + cols);
+		const int rc = acm_mform_get_pair(level, blob, pairs[p], dst);
+		if (rc != ACMHIP_OK)
+			return rc;
 		if (!p)
 			for (size_t m = 0; m < 2 * cols; m++)
 				if (front[m] != 0)

@@ -751,3 +751,91 @@ extern "C" int acm_stage_file(const uint8_t *data, size_t len, int force_chans,
 		memcpy(patches, found.data(), ncopy * sizeof(acmhip_patch));
 	return ACM_OK;
 }
+
+/*
+ * The same with the byte-plane form written while the parsed block is still in the cache: a block is parsed into a buffer of its own
+ * (16 KB at level 9: the first-level cache, where the column scatter of the parser costs nothing), its row pairs go to the byte-plane
+ * writer from there, and only the rows the int16 kernels still read - from two rows in front of the ragged tail on - are copied to
+ * idx.  Against acm_stage_file + acmhip_mform_rows this drops the 2 B per sample written to and read back from the int16 arena.
+ * *mf_rows = rows [0, *mf_rows) are in the form (whole tiles of the lean kernel); 0: the stream has none (a level without the form, an
+ * odd acm_rows, H1 patches, an index beyond the form's range, a file that ends early) and idx holds every row as acm_stage_file
+ * leaves it - except that with patches (info->npatches != 0) the caller stages once more with room for them.
+ */
+#include "acm_device.h"
+#include "acm_mform.h"
+
+extern "C" int acm_stage_file_mform(const uint8_t *data, size_t len, int force_chans, int16_t *idx, acmhip_blkhdr *hdr, size_t max_blocks,
+				    acm_stage_info *info, uint8_t *mf_out, uint64_t mf_base, acmhip_mform_pair *pairs, uint64_t *mf_rows,
+				    uint64_t *mf_bytes)
+{
+	if (!data || !info || !mf_rows || !mf_bytes || (max_blocks && (!idx || !hdr)))
+		return ACMHIP_ERR_ARG;
+	*mf_rows = *mf_bytes = 0;
+	auto plain = [&]() { return acm_stage_file(data, len, force_chans, idx, hdr, max_blocks, nullptr, 0, info); };
+	memset(info, 0, sizeof(*info));
+	StageCtx c;
+	int rc = c.open(data, len, force_chans);
+	if (rc < 0)
+		return rc;
+	fill_stage_info(&c.a, info);
+	const uint32_t level = info->level, rows = info->rows;
+	const int T2 = acmk_tile2_rows(level), TM = acmhip_mform_tile_rows(level);
+	/* (levels 13 / 14: whether a plan takes such a stream's form is known only from the whole plan - acmhip_plan_form_rows - so its
+	 * int16 rows may all be needed: the plain way) */
+	if (!mf_out || !pairs || T2 <= 0 || TM <= 0 || (rows & 1) || T2 % TM || level > ACM_K1_MAX_LEVEL)
+		return plain();
+	const size_t bl = c.a.block_len, cols = (size_t)1 << level;
+	const uint64_t need = ((uint64_t)c.a.total_values + bl - 1) / bl;
+	const uint64_t want = std::min<uint64_t>(need, max_blocks);
+	/* what a complete file delivers (decode.c:853-857: whole blocks, the last one cut at total_values, rounded to whole frames) */
+	auto deliverable = [&](uint64_t blocks) {
+		uint64_t pos = 0;
+		for (uint64_t b = 0; b < blocks && pos < c.a.total_values; b++) {
+			uint64_t take = std::min<uint64_t>(bl, c.a.total_values - pos);
+			if (info->channels > 1)
+				take -= take % info->channels;
+			pos += take;
+			if (take != bl)
+				break;
+		}
+		return pos;
+	};
+	const uint64_t rows2 = std::min<uint64_t>(want * rows, deliverable(want) >> level) / (uint64_t)T2 * (uint64_t)T2;
+	if (rows2 == 0)
+		return plain();
+	const uint64_t tail_from = rows2 >= 2 ? rows2 - 2 : 0;
+	std::vector<int16_t> block(bl);
+	AcmMformWriter w;
+	if (acm_mform_begin(&w, level, mf_out, mf_base, pairs) != ACMHIP_OK)
+		return plain();
+	std::vector<acmhip_patch> found;
+	acmfill::PatchSink sink{ &found, 0, 0, 0 };
+	uint64_t b = 0;
+	int status = 0;
+	for (; b < want; b++) {
+		sink.base_sample = b * bl;
+		rc = acmfill::parse_block(&c.a, &c.tab, block.data(), hdr + b, &sink);
+		if (rc != 1) {
+			status = (rc == kCleanEof) ? 0 : rc;
+			break;
+		}
+		if (!found.empty())
+			return plain();                 /* H1: the stream keeps the int16 form (and the caller stages again, for the patches) */
+		const uint64_t r0 = b * rows;
+		for (uint32_t r = 0; r < rows; r += 2)
+			if (r0 + r < rows2 && acm_mform_put_pair(&w, block.data() + (size_t)r * cols) != ACMHIP_OK)
+				return plain();         /* an index beyond the form's range */
+		if (r0 + rows > tail_from) {
+			const uint32_t from = r0 >= tail_from ? 0u : (uint32_t)(tail_from - r0);
+			memcpy(idx + (r0 + from) * cols, block.data() + (size_t)from * cols, (size_t)(rows - from) * cols * sizeof(int16_t));
+		}
+	}
+	if (b != want || deliverable(b) != deliverable(want))
+		return plain();                         /* the file ends early: fewer whole tiles than its header promised - the plain way */
+	info->blocks = (uint32_t)b;
+	info->end_status = status;
+	info->npatches = 0;
+	*mf_rows = rows2;
+	*mf_bytes = acm_mform_end(&w);
+	return ACM_OK;
+}

@@ -27,6 +27,15 @@ int acmhip_download(acmhip_device *, void *, const void *, size_t) { device_call
 int acmhip_plan_create(acmhip_device *, const acmhip_stream_desc *, size_t, const acmhip_patch *, size_t, unsigned, acmhip_plan **) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
 void acmhip_plan_destroy(acmhip_plan *) {}
 int acmhip_plan_launch(acmhip_plan *, const int16_t *, const acmhip_blkhdr *, int16_t *, unsigned) { device_calls++; return ACMHIP_ERR_NO_DEVICE; }
+/* tile geometries the stagers ask the kernels' translation unit for (acm_kernels.hip is not in this build): the shipped ones */
+int acmk_tile2_rows(uint32_t level) { return level >= 6 && level <= 11 ? 8192 >> level : level == 12 || level == 13 ? 4 : level == 14 ? 2 : 0; }
+int acmk_tile2m_rows(uint32_t level) { return level >= 9 && level <= 11 ? 2048 >> level : level == 7 || level == 8 ? 8192 >> level : level == 12 ? 4 : level == 13 || level == 14 ? 2 : 0; }
+int acmk_tile2m_stages(uint32_t level) { return level >= 9 && level <= 11 ? 6 : level == 7 || level == 8 ? 3 : level >= 12 && level <= 14 ? 4 : 0; }
+int acmk_tile2p_rows(uint32_t level) { return level >= 6 && level <= 9 ? 8192 >> level : 0; }
+int acmk_tile2p_group_rows(uint32_t level) { return level == 6 ? 32 : 16; }
+int acmk_tile2p_slots(uint32_t) { return 28; }
+int acmk_tile2p_waves(uint32_t) { return 4; }
+int acmk_tile2p_pad_shift(uint32_t) { return 5; }
 }
 
 struct Mem { const uint8_t *p; size_t len, pos; unsigned max_read; };
@@ -57,6 +66,22 @@ static void exercise(const std::vector<uint8_t> &img)
 			std::vector<acmhip_blkhdr> hdr(need);
 			std::vector<acmhip_patch> pt(4096);
 			acm_stage_file(img.data(), img.size(), (int)(rnd() % 4) - 1, idx.data(), hdr.data(), need, pt.data(), pt.size(), &si);
+			/* the fused staging: the byte-plane form written by the parsing pass (and every way it falls back) */
+			const uint64_t nrows = (need * si.rows) & ~1ull;
+			if (acmhip_mform_tile_rows(si.level) > 0 || (rnd() & 7) == 0) {
+				std::vector<uint8_t> blob(acmhip_mform_bytes(si.level, nrows) + 256);
+				std::vector<acmhip_mform_pair> pairs(acmhip_mform_pairs(nrows) + 32);
+				uint64_t mf_rows = 0, mf_bytes = 0;
+				acm_stage_file_mform(img.data(), img.size(), (int)(rnd() % 4) - 1, idx.data(), hdr.data(), need, &si, blob.data(), 4096, pairs.data(),
+						     &mf_rows, &mf_bytes);
+				if (mf_rows) {
+					std::vector<int16_t> back(mf_rows * si.cols);
+					if (mf_bytes > blob.size() || acmhip_mform_unrows(si.level, blob.data() - 4096, pairs.data(), mf_rows, back.data()) != ACMHIP_OK) {
+						fprintf(stderr, "fused staging wrote a form that does not read back\n");
+						abort();
+					}
+				}
+			}
 		}
 	}
 	Mem m{ img.data(), img.size(), 0, (rnd() & 3) ? 0u : 1u + rnd() % 9 };

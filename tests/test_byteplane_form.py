@@ -262,6 +262,50 @@ def test_toeplitz_tables_reproduce_the_first_six_stages(level):
     assert np.array_equal(t["T"][1], T * sign[None, :, None]) and np.array_equal(t["BIAS"][1], BIAS * sign[None, :])
 
 
+@pytest.mark.parametrize("level,rows,blocks,cut", [(9, 16, 7, 0), (9, 16, 5, 3), (7, 16, 20, 0), (10, 8, 11, 5), (11, 64, 2, 0), (12, 4, 9, 1), (8, 2, 70, 0)])
+def test_fused_staging_equals_the_two_pass_staging(level, rows, blocks, cut):
+    """acm_stage_file_mform (the byte-plane form written block by block by the parsing pass) leaves exactly what acm_stage_file +
+    acmhip_mform_rows leave: the same pair table and bytes for the whole tiles, the same int16 rows from two rows in front of the ragged
+    tail on - and touches no int16 row in front of that"""
+    L = capi.lib()
+    f = make_stream(46000 + level * 10 + rows, level, rows, blocks, cut=cut, pwr_max=12)
+    s = capi.stage_file(f)
+    info, idx, hdr, blob, pairs, mf_rows, mf_bytes = capi.stage_file_mform(f, mf_base=4096)
+    cols = 1 << level
+    t2 = L.acmk_tile2_rows(level)
+    words = min(s.info.blocks * rows * cols, s.info.total_values)
+    want_rows = min(s.info.blocks * rows, words >> level) // t2 * t2
+    assert mf_rows == want_rows and mf_rows > 0 and info.blocks == s.info.blocks and info.end_status == s.info.end_status
+    assert np.array_equal(hdr[:info.blocks], s.hdr)
+    # the two-pass form of the same rows
+    buf = np.zeros(L.acmhip_mform_bytes(level, mf_rows) + 256, dtype=np.uint8)
+    pr = np.zeros(mf_rows // 2 + 33, dtype=np.uint32)
+    used = C.c_uint64()
+    assert L.acmhip_mform_rows(level, s.idx.ctypes.data, mf_rows, buf.ctypes.data, 4096, pr.ctypes.data, C.byref(used)) == 0
+    assert used.value == mf_bytes and np.array_equal(pairs[:mf_rows // 2 + 1], pr[:mf_rows // 2 + 1])
+    assert np.array_equal(blob[:mf_bytes], buf[:mf_bytes])
+    tail = max(mf_rows - 2, 0) * cols
+    n = info.blocks * rows * cols
+    assert np.array_equal(idx[tail:n], s.idx[tail:n]) and (idx[:tail] == -12345).all()
+
+
+def test_fused_staging_falls_back():
+    """no form for: a level without one, an odd block height, H1 patches (npatches says so), an index the chunk kernel's form cannot hold,
+    a file that ends early, levels 13 / 14 - each time idx holds every row as acm_stage_file leaves it"""
+    cases = [make_stream(46500, 5, 16, 9), make_stream(46501, 9, 3, 40),
+             make_stream(46502, 9, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6),
+             make_stream(46503, 9, 16, 8, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535),
+             make_stream(46504, 9, 16, 9)[:9000], make_stream(46505, 13, 4, 6)]
+    for k, f in enumerate(cases):
+        s = capi.stage_file(f)
+        info, idx, hdr, blob, pairs, mf_rows, mf_bytes = capi.stage_file_mform(f)
+        assert mf_rows == 0 and mf_bytes == 0, k
+        assert info.blocks == s.info.blocks and info.end_status == s.info.end_status and info.npatches == s.info.npatches, k
+        n = info.blocks * info.rows * info.cols
+        assert np.array_equal(idx[:n], s.idx[:n]), k
+    assert capi.stage_file(cases[2]).info.npatches > 0 and int(capi.stage_file(cases[3]).idx.max()) >= 32640
+
+
 def test_stager_rejects_what_the_kernel_could_not_read():
     """odd row counts (a unit is a row pair), a block that would not start on 16 bytes, offsets beyond the pair table's 30 bits, levels
     without the form; the inverse refuses a table with an unknown width class or a non-zero pair in front"""
