@@ -531,7 +531,10 @@ class Plan:
 
     def destroy(self):
         if self.h:
-            lib().acmhip_plan_destroy(self.h)
+            # a plan that outlived its device handle (a test that failed before its destroy(), collected at interpreter exit) is the
+            # handle's memory gone with it: nothing left to hand back, and the handle must not be touched
+            if getattr(self.dev, "h", None):
+                lib().acmhip_plan_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -94,7 +94,7 @@ def test_full_size_config_4(dev):
     try:
         plan = capi.Plan(dev, descs, packed=[mf.streams[k % distinct] for k in range(len(descs))])
         st = plan.stats()
-        assert st.samples == 65536 * per and st.fused_streams == 65536 and st.mform_tiles == 65536 * 128 // 4
+        assert st.samples == 65536 * per and st.fused_streams == 65536 and st.mform_tiles == 65536 * 128 // capi.lib().acmhip_mform_tile_rows(11)
         for bind in ((None, None), mf_ptrs):                  # the int16 form (vector-ALU first pass), then the byte-plane form
             plan.bind_mform(*bind)
             plan.launch(d_idx, d_hdr, d_pcm)
