@@ -766,7 +766,7 @@ def main():
     # collect counters on itself.  The file records the kernel source it was measured on; another source -> null.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r4_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r5_traffic.json")) as f:
             tj = json.load(f)
         key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
         if args.channels != 1:
@@ -775,7 +775,7 @@ def main():
             key += "_" + args.form
         if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
             traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r4_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
+            traffic_src = "profiles/r5_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
     except Exception:
         traffic = None
 
