@@ -1974,7 +1974,7 @@ struct FirstPassZ {
 	static constexpr int NW = 32768 / NELEM;                /* wavefronts per workgroup = per CU */
 	static constexpr int L = L_, COLS = C::COLS, TR = C::TR, PS = C::PS;
 	static constexpr int G = 6, QN = 1 << G, SIGMA = COLS / QN;            /* QN columns of a residue class per row, SIGMA classes */
-	static_assert(SIGMA >= 8 && TR >= 1, "sixteen instances per matrix instruction: sixteen classes of one row, or the eight of two rows");
+	static_assert(SIGMA >= 2 && TR >= 1, "sixteen instances per matrix instruction: sixteen classes of one row, or all the classes of 2 / 4 / 8 rows");
 	static constexpr int RR = SIGMA >= 16 ? 1 : 16 / SIGMA; /* row walkers among the sixteen instances */
 	static constexpr int NG = SIGMA >= 16 ? SIGMA / 16 : 1; /* groups of sixteen classes per row */
 	static constexpr int NSW = TR / RR;                     /* rows a walker walks */
@@ -1995,6 +1995,8 @@ struct FirstPassZ {
 	static constexpr uint32_t CB = SIGMA >= 32 ? 16 : 8;
 	static constexpr uint32_t group_at(const int g) { return 8u * (uint32_t)(g & 1) + 32u * (uint32_t)(g >> 1); }
 	static_assert(NG <= 8 && (NG == 1 || SIGMA >= 32), "groups of sixteen classes");
+	/* the four instances a lane receives: one walker's four adjacent classes - or, with two classes per row (level 7), two walkers' */
+	static constexpr int NH = SIGMA >= 4 ? 1 : 4 / SIGMA, NVH = 4 / NH;
 	static __device__ __forceinline__ uint32_t class_of(const uint32_t i)
 	{
 		if constexpr (RR > 1)
@@ -2126,43 +2128,87 @@ struct FirstPassZ {
 	 * differences that is not zero in SOME lane of the set (step2 / step1, decided per set from the scalar row values) - no matrix
 	 * instruction more, and nothing for the chunks in the middle of a block.
 	 */
+	/* hvs: lane k holds val << SHIFT of chunk row k - 2 (k < TR + 2) */
 	template <bool WORDS>
-	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const int32_t (&rowval)[TR + 2],
+	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const uint32_t hvs,
 						     const uint32_t in_front)
 	{
 		const v4i_t zero = { 0, 0, 0, 0 };
-		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker, output q = 16 mt + lane % 16 */
+		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker (two classes each of two walkers
+		 * where a row has only two), output q = 16 mt + lane % 16 */
 		const uint32_t h = (uint32_t)lane >> 4, qd = (uint32_t)lane & 15u;
-		const uint32_t c0 = class_of(4u * h), rrd = RR == 1 ? 0u : (4u * h) / SIGMA;
-		const uint32_t m_lane = rrd * (uint32_t)(NSW * COLS) + c0 + (uint32_t)SIGMA * qd;
-		uint32_t *o_lane = tile + (m_lane + (m_lane >> PS));
-		/* the "+1" of decode.c:561-564, six stages on: the lane that owns residue 0 adds it to its first output; rows in front of a
-		 * stream do not exist and add nothing */
-		uint32_t bias_at[NSW];          /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
-		/* per walk row s: val of the lane's row, the two differences, and whether any lane of the set has one */
-		int32_t val[NSW], dv2[NSW], dv1[NSW];
-		bool step2[NSW], step1[NSW];
+		uint32_t c0[NH], rrd[NH];
+		uint32_t o_lane[NH];            /* (dword offsets into the tile, not pointers: see bias_at) */
 #pragma unroll
-		for (int s = 0; s < NSW; s++) {
-			const uint32_t row = in_front + rrd * NSW + s;
-			bias_at[s] = ((row < 2 ? row : 2u) * 2u + (c0 == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
-			/* chunk row of walker w's output: w * NSW + s; rowval is indexed from row -2 */
-			const int32_t a0 = rowval[s + 2], a1 = rowval[s + 1], a2 = rowval[s];
-			if constexpr (RR == 1) {
-				val[s] = a0;
-				dv2[s] = a1 - a0;
-				dv1[s] = a2 - a1;
-				step2[s] = a1 != a0;
-				step1[s] = a2 != a1;
-			} else {
-				const int32_t b0 = rowval[NSW + s + 2], b1 = rowval[NSW + s + 1], b2 = rowval[NSW + s];
-				val[s] = rrd ? b0 : a0;
-				dv2[s] = rrd ? b1 - b0 : a1 - a0;
-				dv1[s] = rrd ? b2 - b1 : a2 - a1;
-				step2[s] = a1 != a0 || b1 != b0;
-				step1[s] = a2 != a1 || b2 != b1;
+		for (int hf = 0; hf < NH; hf++) {
+			const uint32_t i = 4u * h + (uint32_t)(hf * NVH);
+			c0[hf] = RR == 1 ? class_of(i) : i % SIGMA;
+			rrd[hf] = RR == 1 ? 0u : i / SIGMA;
+			const uint32_t m_lane = rrd[hf] * (uint32_t)(NSW * COLS) + c0[hf] + (uint32_t)SIGMA * qd;
+			o_lane[hf] = m_lane + (m_lane >> PS);
+		}
+		/* the "+1" of decode.c:561-564, six stages on: the lane that owns residue 0 adds it to that output; rows in front of a stream do
+		 * not exist and add nothing */
+		uint32_t bias_at[NSW][NH];      /* (an index, not a pointer: a pointer picked at run time loses its address space and the load becomes a flat one) */
+		/* per walk row s (and walker of the lane): val of the row, the two differences, and whether any lane of the set has one */
+		int32_t val[NSW][NH], dv2[NSW][NH], dv1[NSW][NH];
+		bool step2[NSW], step1[NSW];
+		if constexpr (RR <= 2) {
+			int32_t rowval[TR + 2];
+#pragma unroll
+			for (int k = 0; k < TR + 2; k++)
+				rowval[k] = (int32_t)__builtin_amdgcn_readlane(hvs, k);
+#pragma unroll
+			for (int s = 0; s < NSW; s++) {
+				/* chunk row of walker w's output: w * NSW + s; rowval is indexed from row -2 */
+				const int32_t a0 = rowval[s + 2], a1 = rowval[s + 1], a2 = rowval[s];
+				if constexpr (RR == 1) {
+					val[s][0] = a0;
+					dv2[s][0] = a1 - a0;
+					dv1[s][0] = a2 - a1;
+					step2[s] = a1 != a0;
+					step1[s] = a2 != a1;
+				} else {
+					const int32_t b0 = rowval[NSW + s + 2], b1 = rowval[NSW + s + 1], b2 = rowval[NSW + s];
+					val[s][0] = rrd[0] ? b0 : a0;
+					dv2[s][0] = rrd[0] ? b1 - b0 : a1 - a0;
+					dv1[s][0] = rrd[0] ? b2 - b1 : a2 - a1;
+					step2[s] = a1 != a0 || b1 != b0;
+					step1[s] = a2 != a1 || b2 != b1;
+				}
+			}
+		} else {
+			/* four or eight walkers: a lane fetches the values of its walker's rows from the lanes that hold them */
+			const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(hvs);
+			const bool one_val = __builtin_amdgcn_ballot_w64(lane < TR + 2 && hvs != first) == 0;
+#pragma unroll
+			for (int s = 0; s < NSW; s++)
+				step2[s] = step1[s] = false;
+#pragma unroll
+			for (int hf = 0; hf < NH; hf++) {
+				int32_t g[NSW + 2];
+#pragma unroll
+				for (int k = 0; k < NSW + 2; k++)
+					g[k] = one_val ? (int32_t)first : __builtin_amdgcn_ds_bpermute((int)(4u * (rrd[hf] * NSW + (uint32_t)k)), (int32_t)hvs);
+#pragma unroll
+				for (int s = 0; s < NSW; s++) {
+					val[s][hf] = g[s + 2];
+					dv2[s][hf] = g[s + 1] - g[s + 2];
+					dv1[s][hf] = g[s] - g[s + 1];
+					if (!one_val) {
+						step2[s] = step2[s] || __builtin_amdgcn_ballot_w64(dv2[s][hf] != 0) != 0;
+						step1[s] = step1[s] || __builtin_amdgcn_ballot_w64(dv1[s][hf] != 0) != 0;
+					}
+				}
 			}
 		}
+#pragma unroll
+		for (int s = 0; s < NSW; s++)
+#pragma unroll
+			for (int hf = 0; hf < NH; hf++) {
+				const uint32_t row = in_front + rrd[hf] * NSW + s;
+				bias_at[s][hf] = ((row < 2 ? row : 2u) * 2u + (c0[hf] == 0 ? 0u : 1u)) * (uint32_t)QN + qd;
+			}
 		const v4i_t *cf = &t.coef[0][0][lane];
 		const auto &hi = raw.hi;
 #ifndef ACM_K3_MT_UNROLL
@@ -2177,23 +2223,26 @@ struct FirstPassZ {
 			for (int e = 0; e < NSET; e++) {
 				const int g = e / NSW, s = e % NSW;
 				/* rows of this set: x[r] = raw[g][s + 2], x[r - 1] = raw[g][s + 1], x[r - 2] = raw[g][s] */
-				const int32_t b = g == 0 ? (&t.bias[0][0][0])[bias_at[s] + 16u * (uint32_t)mt] : 0;     /* (residue 0 is in group 0) */
+				int32_t b[NH];
+#pragma unroll
+				for (int hf = 0; hf < NH; hf++)
+					b[hf] = g == 0 ? (&t.bias[0][0][0])[bias_at[s][hf] + 16u * (uint32_t)mt] : 0;   /* (residue 0 is in group 0) */
 				const v4i_t l1 = mfma(raw.lo[g][s], cf2, zero);
 				const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
 				const v4i_t la = mfma(raw.lo[g][s + 2], cf0, l2);
 				v4i_t y;
 #pragma unroll
 				for (int v = 0; v < 4; v++)
-					y[v] = __mul24(la[v], val[s]) + (v == 0 ? b : 0);
+					y[v] = __mul24(la[v], val[s][v / NVH]) + (v % NVH == 0 ? b[v / NVH] : 0);
 				if (step2[s]) {
 #pragma unroll
 					for (int v = 0; v < 4; v++)
-						y[v] += __mul24(l2[v], dv2[s]);
+						y[v] += __mul24(l2[v], dv2[s][v / NVH]);
 				}
 				if (step1[s]) {
 #pragma unroll
 					for (int v = 0; v < 4; v++)
-						y[v] += __mul24(l1[v], dv1[s]);
+						y[v] += __mul24(l1[v], dv1[s][v / NVH]);
 				}
 				if constexpr (WORDS) {
 					const v4i_t h1 = mfma(hi[g][s], cf2, zero);
@@ -2202,21 +2251,25 @@ struct FirstPassZ {
 					/* (opaque copies of the multipliers: or the optimiser adds the planes first and multiplies a sum beyond 24 bits at
 					 * a quarter of the rate; an opaque sum: or it moves the shift into the multipliers) */
 					v4i_t yh;
-					const int32_t wv = opaque_v(val[s]);
+					int32_t wv[NH], w2[NH], w1[NH];
+#pragma unroll
+					for (int hf = 0; hf < NH; hf++) {
+						wv[hf] = opaque_v(val[s][hf]);
+						w2[hf] = opaque_v(dv2[s][hf]);
+						w1[hf] = opaque_v(dv1[s][hf]);
+					}
 #pragma unroll
 					for (int v = 0; v < 4; v++)
-						yh[v] = __mul24(ha[v], wv);
+						yh[v] = __mul24(ha[v], wv[v / NVH]);
 					if (step2[s]) {
-						const int32_t w2 = opaque_v(dv2[s]);
 #pragma unroll
 						for (int v = 0; v < 4; v++)
-							yh[v] += __mul24(h2[v], w2);
+							yh[v] += __mul24(h2[v], w2[v / NVH]);
 					}
 					if (step1[s]) {
-						const int32_t w1 = opaque_v(dv1[s]);
 #pragma unroll
 						for (int v = 0; v < 4; v++)
-							yh[v] += __mul24(h1[v], w1);
+							yh[v] += __mul24(h1[v], w1[v / NVH]);
 					}
 #pragma unroll
 					for (int v = 0; v < 4; v++)
@@ -2225,17 +2278,22 @@ struct FirstPassZ {
 				/* the constant parts of the address: multiples of 32, or (16 g) small enough to stay inside the lane's group of 32 - the pad rule splits */
 				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0 &&
 					      (NG == 1 || (group_at(NG - 1) % (1 << PS) + CB + 7 < (1 << PS) && SIGMA % (1 << PS) == 0)), "address split");
-				uint32_t *const o = o_lane + (s * COLS + ((s * COLS) >> PS)) + (group_at(g) + (group_at(g) >> PS));
 #pragma unroll
-				for (int v = 0; v < 4; v++)
-					o[v] = (uint32_t)y[v];
+				for (int hf = 0; hf < NH; hf++) {
+					uint32_t *const o = tile + (o_lane[hf] + (uint32_t)((s * COLS + ((s * COLS) >> PS)) + (group_at(g) + (group_at(g) >> PS))));
+#pragma unroll
+					for (int v = 0; v < NVH; v++)
+						o[v] = (uint32_t)y[hf * NVH + v];
+				}
 			}
 			cf += 64;
-			o_lane += SIGMA * 16 + ((SIGMA * 16) >> PS);
+#pragma unroll
+			for (int hf = 0; hf < NH; hf++)
+				o_lane[hf] += SIGMA * 16 + ((SIGMA * 16) >> PS);
 		}
 	}
 
-	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const Tables &t, const int lane_, const int32_t (&rowval)[TR + 2],
+	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const Tables &t, const int lane_, const uint32_t hvs,
 						   const Desc &d, const uint32_t in_front, const uint32_t odd)
 	{
 		/* what a lane derives from its number (LDS places, table offsets) is worked out again per chunk - a handful of instructions - instead
@@ -2259,9 +2317,9 @@ struct FirstPassZ {
 				for (int g = 0; g < NG; g++)
 					raw.hi[g][k] &= mask;
 			}
-			run_t<true>(raw, tile, t, lane, rowval, in_front);
+			run_t<true>(raw, tile, t, lane, hvs, in_front);
 		} else {
-			run_t<false>(raw, tile, t, lane, rowval, in_front);
+			run_t<false>(raw, tile, t, lane, hvs, in_front);
 		}
 	}
 };
@@ -2353,13 +2411,10 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		if (fresh)
 			for (int k = lane; k < NCARRY_WORDS; k += 64)
 				carry_mem[k] = 0u;
-		int32_t rowval[TR + 2];
-#pragma unroll
-		for (int k = 0; k < TR + 2; k++)
-			rowval[k] = (int32_t)(__builtin_amdgcn_readlane(hv, k) << OutScale<L>::SHIFT);
+		const uint32_t hvs = hv << OutScale<L>::SHIFT;
 		ACM_STAMP(0);
 		phase_prio<true, PRIO_FIRST_PASS>();
-		FP::run(raw, tile, tables, lane, rowval, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
+		FP::run(raw, tile, tables, lane, hvs, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
 		phase_prio<true, PRIO_IDLE>();
 		ACM_STAMP(1);
 
@@ -2517,8 +2572,11 @@ constexpr Tile2MEntry entry_k3()
 	return Tile2MEntry{ Tile2Entry{ acm_chunk<L, 0, Gs...>, 64 * FirstPassZ<L>::NW, FirstPassZ<L>::TR, 1 }, 6 };
 }
 const Tile2MEntry g_chunk[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
+	/* level 7 (two classes per row: eight row walkers per matrix set, a lane's four outputs belong to two of them) was built, is bit-exact
+	 * (tests/test_gpu_byteplane.py at the time) and SLOWER than acm_tile2's matrix build, 0.616 against 0.680: the matrix work per sample
+	 * is the same at every level while the LDS passes it replaces are few at level 7.  Level 8 (four walkers): 0.680 against 0.668. */
 	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
-	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	entry_k3<8, 2>(),
 	entry_k3<9, 3>(),
 	entry_k3<10, 2, 2>(),
 	entry_k3<11, 3, 2>(),
