@@ -372,13 +372,9 @@ __device__ __forceinline__ uint32_t sub_twice(uint32_t t, uint32_t z)
 	if constexpr (EXACT32) {
 		return t - (z << 1);
 	} else {
-#ifdef ACM_NO_ASM
-		return (uint32_t)(__mul24((int32_t)z, -2) + (int32_t)t);
-#else
 		int32_t y;
 		asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(y) : "v"((int32_t)z), "v"((int32_t)t));
 		return (uint32_t)y;
-#endif
 	}
 }
 
@@ -389,11 +385,6 @@ __device__ __forceinline__ uint32_t mul_idx_val(uint32_t loaded, int32_t val, in
 {
 	/* SDWA: operand 0 = one sign-extended 16-bit word of the loaded register (low word, or either word of a
 	 * 4-byte load holding two adjacent columns), so no extraction / extension op is needed */
-#ifdef ACM_NO_ASM
-	if (PAIR && word == 1)
-		return (uint32_t)__mul24((int32_t)loaded >> 16, val);
-	return (uint32_t)__mul24((int32_t)(int16_t)(uint16_t)loaded, val);
-#endif
 	uint32_t y;
 	if (PAIR && word == 1)
 		asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
@@ -423,9 +414,6 @@ __device__ __forceinline__ void mul_idx_val_x4(const uint32_t r0, const uint32_t
 /* t + 2*z as exactly one VALU op (kept opaque so that the compiler does not re-associate the butterfly) */
 __device__ __forceinline__ uint32_t add_twice(uint32_t t, uint32_t z)
 {
-#ifdef ACM_NO_ASM
-	return t + (z << 1);
-#endif
 	uint32_t y;
 	asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(y) : "v"(z), "v"(t));
 	return y;
@@ -2545,24 +2533,29 @@ constexpr Tile2Entry entry_k2mw()
 #ifndef ACM_K2M_L13
 #define ACM_K2M_L13 entry_k2mw<TileCfg<13, 512, 16384>, 2, 4, 3, 3, 3>(), 4
 #endif
-/* [level][first pass of three / four stages]; the staged form differs between the two (8 or 16 columns of a residue class side by side),
- * so the choice is made once per process: the measured default below, or ACM_K2M_G0=3|4 (experiments) */
+/* [level][first pass of three / four stages]; the staged form differs between the two (8 or 16 columns of a residue class side by side).
+ * The library ships ONE of them per level, the measured better one (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box:
+ * level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12 four stages +5.5 / +6.6 / +5 %: one LDS pass, or one of its stages, less);
+ * the other depth is a tuning build (-DACM_TUNING, chosen per process with ACM_K2M_G0=3|4) */
 struct Tile2MEntry { Tile2Entry e; int g0; };
+#ifdef ACM_TUNING
+#define ACM_K2M_ALT(...) __VA_ARGS__
+#else
+#define ACM_K2M_ALT(...) Tile2Entry{ nullptr, 0, 0, 0 }, 0
+#endif
 const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 	{ { entry_k2m<TileCfg<7, 256, 8192>, 3, 2, 2>(), 3 }, { Tile2Entry{ nullptr, 0, 0, 0 }, 0 } },        /* 8 residue classes of stride 8: less than one operand tile */
-	{ { entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(), 3 }, { entry_k2m<TileCfg<8, 256, 8192>, 4, 2, 2>(), 4 } },
-	{ { entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(), 3 }, { entry_k2m<TileCfg<9, 256, 8192>, 4, 3, 2>(), 4 } },
-	{ { entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(), 3 }, { entry_k2m<TileCfg<10, 256, 8192>, 4, 3, 3>(), 4 } },
-	{ { entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3 }, { ACM_K2M_L11 } },
-	{ { entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3 }, { ACM_K2M_L12 } },
+	{ { entry_k2m<TileCfg<8, 256, 8192>, 3, 3, 2>(), 3 }, { ACM_K2M_ALT(entry_k2m<TileCfg<8, 256, 8192>, 4, 2, 2>(), 4) } },
+	{ { entry_k2m<TileCfg<9, 256, 8192>, 3, 3, 3>(), 3 }, { ACM_K2M_ALT(entry_k2m<TileCfg<9, 256, 8192>, 4, 3, 2>(), 4) } },
+	{ { ACM_K2M_ALT(entry_k2m<TileCfg<10, 256, 8192>, 3, 3, 2, 2>(), 3) }, { entry_k2m<TileCfg<10, 256, 8192>, 4, 3, 3>(), 4 } },
+	{ { ACM_K2M_ALT(entry_k2m<TileCfg<11, 256, 8192>, 3, 3, 3, 2>(), 3) }, { ACM_K2M_L11 } },
+	{ { ACM_K2M_ALT(entry_k2mw<TileCfg<12, 512, 16384>, 2, 3, 3, 3, 3>(), 3) }, { ACM_K2M_L12 } },
 	/* level 13: the vector-ALU build needs 128 KB tiles (its first pass re-runs two rows per segment); here the rows in front cost a second
 	 * read through L2 and nothing else, so a tile may be one row pair.  Level 14: a row pair IS 128 KB, sixteen waves of 128 registers;
 	 * (4,3,3,2,2) and (4,3,2,3,2) spill seven of them, (4,2,3,3,2) none */
 	{ { Tile2Entry{ nullptr, 0, 0, 0 }, 0 }, { ACM_K2M_L13 } },
 	{ { Tile2Entry{ nullptr, 0, 0, 0 }, 0 }, { entry_k2mw<TileCfg<14, 1024, 32768>, 1, 4, 2, 3, 3, 2>(), 4 } },
 };
-/* measured (profiles/r4_mfma_first_pass.txt, 2.1 Gsamples per level, one box): level 8 equal, level 9 three stages +1.6 %, levels 10 / 11 / 12
- * four stages +5.5 / +6.6 / +5 % (one LDS pass, or one of its stages, less) */
 constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4, 4 };
 /* levels whose byte-plane tiles go to the chunk kernel (acm_chunk: six stages on the matrix cores, a wavefront per chunk of 2048 samples)
  * unless ACM_K3=0 asks for acm_tile2's matrix build; the staged form follows the choice (64 columns of a residue class side by side) */
@@ -2592,8 +2585,12 @@ inline const Tile2MEntry &tile2m_entry(uint32_t level)
 	static const bool k3 = !(getenv("ACM_K3") && atoi(getenv("ACM_K3")) == 0);
 	if (k3 && g_chunk[level - ACM_K2M_MIN_LEVEL].g0)
 		return g_chunk[level - ACM_K2M_MIN_LEVEL];
-	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;
 	const Tile2MEntry *row = g_tile2m[level - ACM_K2M_MIN_LEVEL];
+#ifdef ACM_TUNING
+	static const int forced = getenv("ACM_K2M_G0") ? atoi(getenv("ACM_K2M_G0")) : 0;
+#else
+	constexpr int forced = 0;
+#endif
 	const int want = forced ? forced : g_tile2m_default[level - ACM_K2M_MIN_LEVEL];
 	return ((want == 4 || row[0].g0 == 0) && row[1].g0 == 4) ? row[1] : row[0];
 }

@@ -240,11 +240,10 @@ def test_plan_says_which_rows_it_reads_from_the_second_form(dev, monkeypatch):
     plan.destroy()
 
 
-@pytest.mark.parametrize("g0", [3, 4])
-def test_byteplane_both_first_pass_depths(g0):
-    """every level has its measured default (three or four stages on the matrix cores); ACM_K2M_G0 forces the other build and the
-    form that goes with it, read once per process - so this runs in a child: parity with the oracle over levels 7-12, even, odd
-    and single block heights, 16-bit indices"""
+def test_byteplane_without_the_chunk_kernel():
+    """ACM_K3=0 (read once per process, so this runs in a child): no level goes to the chunk kernel, every level's byte-plane tiles run
+    acm_tile2's matrix build (three or four stages on the matrix cores: the one depth per level the library ships) on the form that goes
+    with it - parity with the oracle over levels 7-14, even, odd and single block heights, 16-bit indices"""
     import os
     import subprocess
     import sys
@@ -257,7 +256,7 @@ from libacm_amd import capi
 dev = capi.Device(0)
 bad = 0
 for level in range(7, 15):
-    assert capi.lib().acmhip_mform_group(level) == (16 if (%d == 4 and level >= 8) or level >= 13 else 8)
+    assert capi.lib().acmhip_mform_group(level) == (16 if level >= 10 else 8)
     tr = max(capi.lib().acmhip_mform_tile_rows(level), capi.lib().acmk_tile2_rows(level), 4)
     for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
         f = make_stream(28000 + level * 100 + rows, level, rows, (5 * tr + rows - 1) // rows + 1, cut=3, pwr_min=min(4, pm), pwr_max=pm,
@@ -267,7 +266,7 @@ for level in range(7, 15):
         bad += not np.array_equal(got[0], oracle_pcm(f)[0])
 print("BAD", bad)
 sys.exit(1 if bad else 0)
-""" % (os.path.dirname(os.path.abspath(__file__)), g0)
-    env = dict(os.environ, ACM_K2M_G0=str(g0), ACM_K2="1", ACM_K3="0")          # (ACM_K3=0: no level goes to the chunk kernel and its form)
+""" % (os.path.dirname(os.path.abspath(__file__)),)
+    env = dict(os.environ, ACM_K2="1", ACM_K3="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]

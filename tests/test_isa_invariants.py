@@ -131,7 +131,7 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
         # prologue + in-loop sets of staged-index loads (the matrix-core builds: 8 + the row values; the chunk kernel asks for as few as four
         # in its loop where the rows in front of a walk stay in registers)
         assert n_loads >= (12 if "acm_chunk" in name else 2 * 9), (name, n_loads)
-    assert n_kernels >= 31                                 # five levels of the chunk kernel, nine levels of acm_tile2, thirteen matrix-core builds of it (levels 7-14, two depths where both exist), four of acm_tile2p
+    assert n_kernels >= 26                                 # nine levels of acm_tile2, its matrix build at eight (one depth each), five levels of the chunk kernel, four of acm_tile2p
 
 
 def test_every_wait_is_written_by_hand(kernel_asm):
