@@ -256,9 +256,10 @@ typedef struct acmhip_plan_stats {
 	uint32_t packed_tiles;   /* tiles that have records of the packed build too (read in packed form while arenas are bound: acmhip_plan_bind_packed) */
 } acmhip_plan_stats;
 int  acmhip_plan_get_stats(const acmhip_plan *plan, acmhip_plan_stats *out);
-/* rows [0, *rows) of stream `stream` (its position among the descriptors the plan was created from) are read from the stream's second
- * staged form by this plan's launches while one is bound - every other row it decodes, and the two rows in front of them, from the int16
- * arena.  0 for a stream without a second form, and for one whose form the plan does not use (a level-13 / 14 stream of a small plan, a
+/* rows [row_begin, row_begin + *rows) of stream `stream` (its position among the descriptors the plan was created from) are read from the
+ * stream's second staged form by this plan's launches while one is bound - every other row it decodes, and the two rows in front of them,
+ * from the int16 arena.  (row_begin > 0: a window that starts on a tile boundary of a stream with a byte-plane form - the form must hold
+ * the stream's rows from row 0 to the window's last whole tile.)  0 for a stream without a second form, and for one whose form the plan does not use (a level-13 / 14 stream of a small plan, a
  * stage-wise plan): a caller that stages both forms uploads the int16 rows from max(*rows - 2, 0) on. */
 int  acmhip_plan_form_rows(const acmhip_plan *plan, size_t stream, uint64_t *rows);
 

@@ -39,8 +39,10 @@ struct AcmTile {
 #define ACM_TILE_ROW1    4u    /* the chunk is row 1 of its stream: one row in front of it */
 #define ACM_TILE_ODD     8u    /* the chunk starts on the second row of a pair (idx_off still names the entry of the pair in front of that pair) */
 
-/* one tile of the lean kernel (acm_tile2): tile_rows consecutive rows of a stream decoded from its row 0, all of them
- * present and emitted.  Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH. */
+/* one tile of the lean kernels (acm_tile2, acm_chunk): tile_rows consecutive rows of a stream, all of them present and emitted.
+ * Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH when it is the stream's row 0 - or, for a
+ * window into a stream (rows from a tile boundary on), it is a record of the tile IN FRONT of the window carrying ACM_TILE_DISCARD:
+ * decoded like any other to build the carries, its PCM dropped. */
 struct AcmTile2 {
 	uint64_t idx_off;      /* int16 units: staged index of (tile row 0, column 0) */
 	uint64_t pcm_off;      /* int16 units: where sample (tile row 0, column 0) goes */
@@ -138,6 +140,7 @@ int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);
 /* the byte-plane staged form: the same tile records as acm_tile2 except that idx_off is the pair-table entry of the row pair in front of the tile */
 int acmk_tile2m_rows(uint32_t level);                           /* = acmk_tile2_rows, 0 if the level has no such build */
+int acmk_tile2m_lead_in(uint32_t level);                        /* tiles of this build in front of a window into a stream (ACM_TILE_DISCARD records) */
 int acmk_tile2m_stages(uint32_t level);                         /* stages of its first pass (3 or 4): the form keeps 2^stages columns of a residue class side by side */
 int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs,
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);

@@ -501,41 +501,57 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	std::vector<uint64_t> form_rows(n, 0);         /* rows of every stream the plan reads from its second staged form */
 	/* rows [0, rows2) of stream i as records of the lean tile kernel (T2 rows each), and, where the stream came with a second staged form,
 	 * once more as records of the build that reads it */
-	auto cut_lean = [&](size_t i, uint64_t rows2, uint32_t T2) -> int {
+	/* rows [row0, row0 + rows2) of stream i as records of the lean tile kernel (T2 rows each), and, where the stream came with a second
+	 * staged form, once more as records of the build that reads it.  row0 = 0: the stream from its first row (the first record is
+	 * ACM_TILE_FRESH); row0 > 0 (a multiple of T2; byte-plane streams only): a window - the records start with one for the tile in front
+	 * of row0, marked ACM_TILE_DISCARD, which builds the carries and stores nothing */
+	auto cut_lean = [&](size_t i, uint64_t row0, uint64_t rows2, uint32_t T2) -> int {
 		const acmhip_stream_desc &s = streams[i];
 		const uint32_t magic = s.rows == 1 ? 0u : (uint32_t)(((1ull << 32) + s.rows - 1) / s.rows);
 		if (packed && packed[i].ntiles && packed[i].form > ACMHIP_FORM_BYTEPLANE) {
 			set_err("stream %zu: staged form %u", i, packed[i].form);
 			return ACMHIP_ERR_ARG;
 		}
-		const bool pk = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_PACKED && acmk_tile2p_rows(s.level) == (int)T2;
+		const bool pk = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_PACKED && acmk_tile2p_rows(s.level) == (int)T2 && row0 == 0;
 		/* the matrix-core build may cut the same rows into smaller tiles (its rows in front cost nothing): T2M divides T2 */
 		const uint32_t T2M = (uint32_t)acmk_tile2m_rows(s.level);
 		const bool mf = packed && packed[i].ntiles && packed[i].form == ACMHIP_FORM_BYTEPLANE && T2M && T2 % T2M == 0;
-		if ((pk && packed[i].ntiles < rows2 / T2) || (mf && packed[i].ntiles < rows2 / T2M)) {
+		if ((pk && packed[i].ntiles < rows2 / T2) || (mf && packed[i].ntiles < (row0 + rows2) / T2M)) {
 			set_err("stream %zu: %u tiles in its second staged form, %llu whole tiles to decode", i, packed[i].ntiles,
-				(unsigned long long)(rows2 / (mf ? T2M : T2)));
+				(unsigned long long)((row0 + rows2) / (mf ? T2M : T2)));
+			return ACMHIP_ERR_ARG;
+		}
+		if (row0 && (!mf || row0 % T2 || row0 < T2)) {
+			set_err("stream %zu: a window on the lean kernels starts on a tile boundary of a stream with a byte-plane form", i);
 			return ACMHIP_ERR_ARG;
 		}
 		if (pk || mf)
 			form_rows[i] = rows2;
 		std::vector<AcmTile2> &plain = pk ? tiles2p_plain[s.level] : mf ? tiles2m_plain[s.level] : tiles2[s.level];
-		for (uint64_t r = 0; r < rows2; r += T2) {
+		auto flags_of = [&](uint64_t r, bool lead_in) -> uint32_t {
+			/* (a lead-in that is the stream's first tile has nothing in front of it either: both flags) */
+			return (lead_in ? ACM_TILE_DISCARD : 0u) | (r == 0 ? ACM_TILE_FRESH : 0u);
+		};
+		/* where sample (row r, column 0) goes: rows count from the window's first row (a lead-in stores into the sink) */
+		auto pcm_of = [&](uint64_t r) -> uint64_t { return s.pcm_off + ((r >= row0 ? r - row0 : 0) << s.level); };
+		for (uint64_t r = row0 ? row0 - T2 : 0; r < row0 + rows2; r += T2) {
+			const bool lead_in = r < row0;
 			const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
-			plain.push_back(AcmTile2{ s.idx_off + (r << s.level), s.pcm_off + (r << s.level),
-						  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic,
-						  r == 0 ? ACM_TILE_FRESH : 0u });
+			plain.push_back(AcmTile2{ s.idx_off + (r << s.level), pcm_of(r),
+						  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic, flags_of(r, lead_in) });
 			if (pk)
 				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
 								     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
 								     r == 0 ? ACM_TILE_FRESH : 0u });
-			/* a byte-plane tile is named by the pair-table entry of the row pair in front of it (entry 0 of a stream: the pair of zeros) */
-			for (uint64_t rm = r; mf && rm < r + T2; rm += T2M) {
+			/* a byte-plane tile is named by the pair-table entry of the row pair in front of it (entry 0 of a stream: the pair of zeros).
+			 * (chunks of one row - T2M == 1, the chunk kernel at levels 11 and 12 - also say whether they start a pair and whether they
+			 * are row 1; of a lead-in tile only the last chunks are needed, acmk_tile2m_lead_in of them) */
+			const uint64_t lead_rows = (uint64_t)T2M * (uint64_t)acmk_tile2m_lead_in(s.level);      /* (<= T2: two rows more at most) */
+			for (uint64_t rm = lead_in ? r + T2 - std::min<uint64_t>(T2, lead_rows) : r; mf && rm < r + T2; rm += T2M) {
 				const uint64_t rhm = rm >= 2 ? rm - 2 : 0;
-				/* (chunks of one row - T2M == 1, the chunk kernel at level 11 - also say whether they start a pair and whether they are row 1) */
-				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + rm / 2, s.pcm_off + (rm << s.level),
+				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + rm / 2, pcm_of(rm),
 								     (uint32_t)(s.hdr_off + rhm / s.rows), (uint32_t)(rhm % s.rows), magic,
-								     (rm == 0 ? ACM_TILE_FRESH : 0u) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
+								     flags_of(rm, lead_in) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
 			}
 		}
 		return ACMHIP_OK;
@@ -642,9 +658,20 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			if (k2_allowed && T2 && s.row_begin == 0) {
 				const uint64_t full_rows = std::min<uint64_t>(s.nrows, s.n_emit >> s.level);
 				rows2 = full_rows / T2 * T2;
-				const int cr = cut_lean(i, rows2, T2);
+				const int cr = cut_lean(i, 0, rows2, T2);
 				if (cr != ACMHIP_OK)
 					return cr;
+			} else if (k2_allowed && T2 && s.row_begin >= T2 && s.row_begin % T2 == 0 && packed && packed[i].ntiles &&
+				   packed[i].form == ACMHIP_FORM_BYTEPLANE && acmk_tile2m_rows(s.level) > 0 && T2 % (uint32_t)acmk_tile2m_rows(s.level) == 0) {
+				/* a window that starts on a tile boundary of a stream with a byte-plane form (a block range of a device-parsed batch):
+				 * its whole tiles go to the lean kernels too, behind a lead-in record for the tile in front of it */
+				const uint64_t full_rows = std::min<uint64_t>(s.nrows - s.row_begin, s.n_emit >> s.level);
+				rows2 = full_rows / T2 * T2;
+				if (rows2) {
+					const int cr = cut_lean(i, s.row_begin, rows2, T2);
+					if (cr != ACMHIP_OK)
+						return cr;
+				}
 			}
 			for (uint64_t r = rows2; r < emit_rows; r += T)
 				tiles_rest[s.level].push_back(AcmTile{ (uint32_t)i, (int32_t)(s.row_begin + r), 0u, 0u });
@@ -672,7 +699,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				 * stream (a pseudo stream behind the n real ones) for the prefix + plane pair */
 				const uint32_t T2 = (uint32_t)acmk_tile2_rows(s.level);
 				const uint64_t rows2 = std::min<uint64_t>(s.nrows, s.n_emit >> s.level) / T2 * T2;
-				const int cr = cut_lean(i, rows2, T2);
+				const int cr = cut_lean(i, 0, rows2, T2);
 				if (cr != ACMHIP_OK)
 					return cr;
 				if (rows2 > 0) {

@@ -1797,11 +1797,17 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	const uint32_t t_end = t + per < ntiles ? t + per : ntiles;
 	if (t >= t_end)
 		return;
-	/* a run that starts inside a stream first replays the tile in front of it without storing PCM */
+	/* a run that starts inside a stream first replays the tile in front of it without storing PCM - unless the table says so itself: a
+	 * window into a stream (rows from row_begin on) starts with a record of the tile in front of it, marked ACM_TILE_DISCARD */
 	bool discard = false;
-	if (!(tiles[__builtin_amdgcn_readfirstlane(t)].flags & ACM_TILE_FRESH)) {
-		discard = true;
-		t--;
+	{
+		const uint32_t f0 = tiles[__builtin_amdgcn_readfirstlane(t)].flags;
+		if (f0 & ACM_TILE_DISCARD) {
+			discard = true;
+		} else if (!(f0 & ACM_TILE_FRESH)) {
+			discard = true;
+			t--;
+		}
 	}
 
 	const uint32_t voff = FP::lane_offset(tid);
@@ -1910,8 +1916,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(6);
 		if (!more)
 			break;
-		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
-		discard = false;
+		fresh = (nxt.flags & (ACM_TILE_FRESH | ACM_TILE_DISCARD)) != 0;          /* (a window's lead-in starts from zero carries like a run's) */
+		discard = (nxt.flags & ACM_TILE_DISCARD) != 0;
 		cur = nxt;
 		dcur = dnxt;
 		t = tn;
@@ -2345,9 +2351,14 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	if (t >= t_end)
 		return;
 	bool discard = false;
-	if (!(tiles[__builtin_amdgcn_readfirstlane(t)].flags & ACM_TILE_FRESH)) {
-		discard = true;                         /* a run that starts inside a stream replays the chunk in front of it without storing PCM */
-		t--;
+	{
+		const uint32_t f0 = tiles[__builtin_amdgcn_readfirstlane(t)].flags;
+		if (f0 & ACM_TILE_DISCARD) {
+			discard = true;                 /* the lead-in record of a window into a stream: the table names the chunk in front itself */
+		} else if (!(f0 & ACM_TILE_FRESH)) {
+			discard = true;                 /* a run that starts inside a stream replays the chunk in front of it without storing PCM */
+			t--;
+		}
 	}
 
 	/* rows of the stream in front of a chunk: 0, 1 (chunks of one row only), or 2 for "two or more" */
@@ -2410,6 +2421,10 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		if constexpr (FP::HISTORY_IN_REGISTERS) {
 			/* the rows in front of the next chunk's walk are in this lane's registers already - unless that chunk starts a stream
 			 * (nothing in front of it: zeros).  (The last chunk of a run, which names itself, is never looked at again.) */
+			/* (the first lead-in chunk of a window - ACM_TILE_DISCARD, not the successor of this chunk - finds another stream's rows there:
+			 * its output is wrong and dropped, and the planner puts enough lead-in chunks in front of a window that the last of them has
+			 * its own stream's rows in front of it, acmk_tile2m_lead_in.  A second load sequence for that case, in a branch, makes the
+			 * compiler join the two with copies of registers whose loads are still in flight: tests/test_isa_invariants.py) */
 			FP::shift_history(raw);
 			if (nxt.flags & ACM_TILE_FRESH)
 				FP::zero_history(raw);
@@ -2443,8 +2458,8 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		tile_barrier<MODE_WAVE>();                      /* (the next first pass overwrites what the stores have just read) */
 		if (!more)
 			break;
-		fresh = (nxt.flags & ACM_TILE_FRESH) != 0;
-		discard = false;
+		fresh = (nxt.flags & (ACM_TILE_FRESH | ACM_TILE_DISCARD)) != 0;
+		discard = (nxt.flags & ACM_TILE_DISCARD) != 0;
 		cur = nxt;
 		dcur = dnxt;
 		t = tn;
@@ -3103,6 +3118,21 @@ extern "C" int acmk_tile2m_rows(uint32_t level)
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)
 		return 0;
 	return tile2m_entry(level).e.tile_rows;
+}
+
+/* tiles of this build the planner puts in front of a window into a stream (ACM_TILE_DISCARD records): one - every pass reaches back less
+ * than a tile - except where the chunk kernel keeps the two rows in front of a walk in registers from the chunk before: there the
+ * last lead-in chunk needs lead-in chunks of its own for those rows (levels 10: one more; 11, 12 - chunks of one row -: two more) */
+extern "C" int acmk_tile2m_lead_in(uint32_t level)
+{
+	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL || tile2m_entry(level).g0 != 6)
+		return 1;
+	switch (level) {
+	case 10: return FirstPassZ<10>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<10>::NSW - 1) / FirstPassZ<10>::NSW : 1;
+	case 11: return FirstPassZ<11>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<11>::NSW - 1) / FirstPassZ<11>::NSW : 1;
+	case 12: return FirstPassZ<12>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<12>::NSW - 1) / FirstPassZ<12>::NSW : 1;
+	default: return 1;
+	}
 }
 
 extern "C" int acmk_tile2m_stages(uint32_t level)

@@ -116,6 +116,55 @@ def test_byteplane_extreme_indices(dev, force_k2):
     check(dev, files)
 
 
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("rows", [16, 2])
+def test_byteplane_windows(dev, force_k2, level, rows):
+    """windows into a stream that came with a byte-plane form (what a block range of a device-parsed batch is): a window that starts on a
+    tile boundary goes to the lean kernels behind a lead-in record for the tile in front of it (ACM_TILE_DISCARD: decoded for its carries,
+    stored into the sink), its ragged tail and every other window to the general tile kernel - same PCM as the oracle's from that row on,
+    with the form bound and, through the int16 twins of the same records, without"""
+    t2 = capi.lib().acmk_tile2_rows(level)
+    nblocks = (9 * t2 + 5 + rows - 1) // rows
+    f = make_stream(25500 + level * 10 + rows, level, rows, nblocks, cut=3, pwr_max=11)
+    st = capi.stage_file(f)
+    if level > 12:
+        pytest.skip("levels 13 / 14 leave the lean kernels to whole-stream plans")
+    cols = 1 << level
+    ar = capi.Arena([st])
+    mf = capi.mform_streams(ar.idx, ar.descs)
+    assert mf.streams[0].ntiles > 0
+    want, _ = oracle_pcm(f)
+    nrows = st.info.blocks * rows
+    begins = [0, t2, 2 * t2, 5 * t2, t2 + 1, 8 * t2]
+    descs, at = [], 0
+    for rb in begins:
+        ne = want.size - rb * cols
+        descs.append(capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=at, n_emit=ne, level=level, rows=rows, nrows=nrows, row_begin=rb))
+        at += (ne + 63) // 64 * 64
+    d_idx, d_hdr, d_pcm = dev.malloc(ar.idx.nbytes), dev.malloc(ar.hdr.nbytes), dev.malloc(at * 2)
+    d_mf = mf.upload(dev)
+    dev.upload(d_idx, ar.idx)
+    dev.upload(d_hdr, ar.hdr)
+    plan = capi.Plan(dev, descs, packed=[mf.streams[0]] * len(descs))
+    try:
+        for k, rb in enumerate(begins):
+            whole = (min(nrows - rb, (want.size - rb * cols) >> level) // t2) * t2
+            assert plan.form_rows(k) == (whole if rb % t2 == 0 else 0), (k, rb)
+        for bind in (d_mf, (None, None)):
+            plan.bind_mform(*bind)
+            dev.upload(d_pcm, np.full(at, 0xA5A5, dtype=np.uint16))
+            plan.launch(d_idx, d_hdr, d_pcm)
+            got = np.zeros(at, dtype=np.uint16)
+            dev.download(got, d_pcm)
+            for k, rb in enumerate(begins):
+                d = descs[k]
+                assert np.array_equal(got[d.pcm_off:d.pcm_off + d.n_emit].view(np.int16), want[rb * cols:].view(np.int16)), (bind[0] is not None, k, rb)
+    finally:
+        plan.destroy()
+        for p_ in (d_idx, d_hdr, d_pcm) + d_mf:
+            dev.free(p_)
+
+
 def test_byteplane_streams_with_h1_patches_keep_the_int16_form(dev, force_k2):
     files = [make_stream(25000, 9, 16, 12, pwr_max=12),
              make_stream(25001, 9, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6),
