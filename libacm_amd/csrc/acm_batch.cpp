@@ -532,8 +532,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		const uint64_t per_thread = n <= 1024 ? 5 : n <= 32768 ? 9 : 16;
 		dev_parse = longest > 0 && idx_total / longest >= per_thread * (uint64_t)threads_wanted;
 	}
-	if (dev_parse)
-		stage_packed = stage_mform = false;     /* the device parser stages int16 */
+	/* the device parser writes the byte-plane form itself where a stream can have it (the chunk kernel's levels, even acm_rows): rows the
+	 * lean kernels take never exist as int16 then (acm_parse.hip: acm_parse_columns); the host pool's second forms are host-parsing only */
+	bool dev_mform = false;
+	if (dev_parse) {
+		dev_mform = stage_mform && !(getenv("ACM_BATCH_DEV_MFORM") && atoi(getenv("ACM_BATCH_DEV_MFORM")) == 0);
+		stage_packed = stage_mform = false;
+	}
 	uint64_t files_total = 0, cols_total = 0;
 	std::vector<uint64_t> file_off;
 	std::vector<size_t> dev_ids;                    /* streams handed to the device parser */
@@ -675,6 +680,16 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKCHUNK, (mf_pairs_total + 32) * sizeof(acmhip_mform_pair), (void **)&d_pkchunk));
 	} else {
 		stage_mform = false;
+	}
+	uint32_t *d_blkoff = nullptr;
+	if (dev_mform && mf_total && (mf_total >> 6) < (1ull << 30) && dev_ids.size() <= ACM_PARSE_RANGE_MAX_STREAMS) {
+		/* (+ 128 KB: a stream whose walk stops early has its unwritten pair-table entries parked right behind its last staged block,
+		 * acm_parse.hip, and a chunk read from there may reach two pairs on - behind the last stream that is behind the arena's contents) */
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKBLOB, mf_total + (128u << 10), (void **)&d_pkblob));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_PKCHUNK, (mf_pairs_total + 32) * sizeof(acmhip_mform_pair), (void **)&d_pkchunk));
+		BTRY(acmhip_arena_get(dev, ACM_ARENA_D_BLKOFF, hdr_total * sizeof(uint32_t), (void **)&d_blkoff));
+	} else {
+		dev_mform = false;
 	}
 	if (!keep_on_device && !direct_out)
 		BTRY(acmhip_arena_get(dev, ACM_ARENA_H_PCM, pcm_arena_words * sizeof(int16_t), (void **)&h_pcm));
@@ -867,6 +882,25 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			j.rows = s.info.rows;
 			j.blocks = (uint32_t)s.need_blocks;
 			j.pad = 0;
+			j.mf_off = j.mf_pair_off = j.mf_rows = 0;
+			if (dev_mform && s.mf_rows_cap) {
+				/* rows [0, mf_rows) - the whole tiles of the lean kernel, as the plan will cut them - are staged in the byte-plane form.
+				 * With block ranges every range must end on a tile boundary (it does when a block is whole tiles), or its ragged end
+				 * would need int16 rows nobody writes */
+				const int T2 = acmk_tile2_rows(s.info.level), TM = acmk_tile2m_rows(s.info.level);
+				if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && !(s.info.rows & 1) && s.info.level <= ACM_K1_MAX_LEVEL &&
+				    (R == 1 || s.info.rows % (uint32_t)T2 == 0)) {
+					const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
+					const uint64_t words = deliverable_words(s.info.total_values, bl, s.info.channels, s.need_blocks);
+					const uint64_t rows2 = std::min<uint64_t>(s.need_blocks * s.info.rows, words >> s.info.level) / (uint64_t)T2 * (uint64_t)T2;
+					if (rows2 && rows2 <= s.mf_rows_cap && rows2 < (1ull << 32)) {
+						j.mf_off = s.mf_off;
+						j.mf_pair_off = (uint32_t)s.mf_pair_off;
+						j.mf_rows = (uint32_t)rows2;
+						slots[i].pk_ntiles = (uint32_t)(rows2 / (uint64_t)TM);
+					}
+				}
+			}
 			col_off += s.need_blocks << s.info.level;
 			ParseGroup &g = groups[group_of_chunk[s.chunk]];
 			if (g.k_first == dev_ids.size()) {
@@ -1010,7 +1044,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			Slot &s = slots[i];
 			if (!s.ok || items[i].words == 0)
 				continue;
-			if (stage_mform)
+			if (stage_mform || dev_mform)
 				packed.push_back(acmhip_packed_stream{ s.mf_pair_off, s.pk_ntiles, ACMHIP_FORM_BYTEPLANE });
 			else
 				packed.push_back(acmhip_packed_stream{ s.pk_chunk_off, s.pk_ntiles, ACMHIP_FORM_PACKED });
@@ -1037,11 +1071,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		}
 		if (descs.empty())
 			return ACMHIP_OK;
-		if (!stage_packed && !stage_mform)
+		if (!stage_packed && !stage_mform && !dev_mform)
 			return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
 		if (r == ACMHIP_OK)
-			r = stage_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk))
+			r = stage_mform || dev_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk))
 					: acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
 		return r;
 	};
@@ -1053,10 +1087,12 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * the staged rows in front of it are on the device by then: earlier ranges) */
 	for (size_t r = 0; r < rchunks.size(); r++) {
 		std::vector<acmhip_stream_desc> descs;
+		std::vector<acmhip_packed_stream> packed;
 		for (size_t i = 0; i < n; i++) {
 			const Slot &s = slots[i];
 			if (!s.ok || piece_len[r * n + i] == 0)
 				continue;
+			packed.push_back(acmhip_packed_stream{ s.mf_pair_off, s.pk_ntiles, ACMHIP_FORM_BYTEPLANE });
 			acmhip_stream_desc d{};
 			d.idx_off = s.idx_off;
 			d.hdr_off = s.hdr_off;
@@ -1068,8 +1104,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			d.n_emit = piece_len[r * n + i];
 			descs.push_back(d);
 		}
-		if (!descs.empty())
+		if (!descs.empty() && dev_mform) {
+			/* every range is a plan of windows; a window of a stream the device stages in the byte-plane form goes to the lean kernels */
+			BTRY(acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), nullptr, 0, opts.plan_flags, &rchunks[r].plan));
+			BTRY(acmhip_plan_bind_mform(rchunks[r].plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk)));
+		} else if (!descs.empty()) {
 			BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), nullptr, 0, opts.plan_flags, &rchunks[r].plan));
+		}
 	}
 	if (!groups.empty() && R == 1) {
 		for (size_t c = 0; c < chunks.size(); c++) {
@@ -1119,8 +1160,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_res + dev_ids.size());
 		/* one block range: the walk + column kernels, and with R > 1 the synthesis and the read-back of what they staged */
 		auto launch_range = [&](size_t r, size_t stripes_up) -> int {
-			const int e = acmk_launch_parse_range(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx,
-							      d_hdr, d_res, d_flags, max_columns, (uint32_t)r, (uint32_t)R, (uint32_t)stripes_up, st_parse);
+			const int e = acmk_launch_parse_range_mf(reinterpret_cast<const AcmParseJob *>(d_jobs), (uint32_t)dev_ids.size(), d_files, d_colpos, d_idx,
+								 d_hdr, d_res, d_flags, max_columns, (uint32_t)r, (uint32_t)R, (uint32_t)stripes_up,
+								 dev_mform ? d_pkblob : nullptr, dev_mform ? reinterpret_cast<uint32_t *>(d_pkchunk) : nullptr,
+								 dev_mform ? d_blkoff : nullptr, st_parse);
 			if (e != 0)
 				return acmhip_report_hip(e, "acmk_launch_parse_range");
 			if (R == 1)
@@ -1211,6 +1254,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			const size_t i = dev_ids[k];
 			Slot &s = slots[i];
 			if (R > 1 && (results[k].status != 0 || results[k].blocks_done != s.need_blocks || flags[k] != 0)) {
+				s.pk_ntiles = 0;
 				redo.push_back(i);
 				continue;
 			}
@@ -1222,6 +1266,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 					if (r != ACMHIP_OK)
 						return r;
 				}
+				s.pk_ntiles = 0;                /* whatever the device wrote of its byte-plane form is not to be read: the host stages int16 */
 				host_stage(i);
 				tm.host_parsed++;
 				replan[s.chunk] = 1;

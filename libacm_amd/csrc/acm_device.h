@@ -71,12 +71,18 @@ struct AcmParseJob {
 	uint32_t rows;
 	uint32_t blocks;       /* blocks to parse */
 	uint32_t pad;
+	/* byte-plane staging by the device parser (the chunk kernel's form: levels whose acmk_tile2m_stages is 6, even acm_rows): rows
+	 * [0, mf_rows) of the stream are written into the byte-plane arena at mf_off (bytes; the pair of zeros first), their pair-table
+	 * entries from mf_pair_off on; only the rows from mf_rows - 2 on are written to the int16 arena.  mf_rows = 0: int16 throughout */
+	uint64_t mf_off;
+	uint32_t mf_pair_off;
+	uint32_t mf_rows;
 };
 struct AcmParseResult {
 	uint32_t blocks_done;
 	uint32_t status;       /* 0 = the scan walked every block it was asked for; else the host must re-parse this stream */
 	uint32_t end_bit;      /* bit offset behind the last block walked: where the next block range of the stream resumes */
-	uint32_t pad;
+	uint32_t mf_at;        /* ... and where its next block starts in the stream's byte-plane region, in 64-byte units (width from pwr) */
 };
 
 /* levels the fused tile kernel covers; its tile geometry is owned by acm_kernels.hip (acmk_fused_tile_rows) */
@@ -105,7 +111,7 @@ extern "C" {
 enum {
 	ACM_ARENA_H_IDX = 0, ACM_ARENA_H_HDR, ACM_ARENA_H_PCM, ACM_ARENA_H_FILES, ACM_ARENA_H_JOBS, ACM_ARENA_H_PKBLOB, ACM_ARENA_H_PKCHUNK,
 	ACM_ARENA_D_IDX, ACM_ARENA_D_HDR, ACM_ARENA_D_PCM, ACM_ARENA_D_FILES, ACM_ARENA_D_COLPOS, ACM_ARENA_D_JOBS, ACM_ARENA_D_STAGE,
-	ACM_ARENA_D_PKBLOB, ACM_ARENA_D_PKCHUNK,
+	ACM_ARENA_D_PKBLOB, ACM_ARENA_D_PKCHUNK, ACM_ARENA_D_BLKOFF,
 	ACM_ARENA_SLOTS
 };
 int acmhip_arena_get(acmhip_device *dev, int slot, size_t bytes, void **out);
@@ -164,6 +170,12 @@ int acmk_launch_parse(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *
 int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 			    acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,
 			    uint32_t stripes_up, void *stream);
+/* the same with byte-plane staging for the jobs that ask for it (mf_rows != 0): d_mf = the byte-plane arena, d_pairs = its pair table,
+ * d_blkoff = one word per block (indexed like d_hdr): where the block starts in its stream's region, in 64-byte units.  Streams are walked
+ * by the wave-per-stream kernel only (njobs <= ACM_PARSE_RANGE_MAX_STREAMS) */
+int acmk_launch_parse_range_mf(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
+			       acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,
+			       uint32_t stripes_up, uint8_t *d_mf, uint32_t *d_pairs, uint32_t *d_blkoff, void *stream);
 /* Striped upload of a block-range batch: every file's arena slot (the file padded to 16 bytes + 16 zero bytes) is cut into R
  * stripes at acmk_stripe_bound(len, s, R); stripe s of all files travels as ONE transfer into a staging arena and a scatter
  * kernel puts the pieces in place, so the first ranges are walked, synthesised and read back while the later stripes are

@@ -373,7 +373,8 @@ constexpr int WAVE_SCAN_WAVES = 4;      /* streams per workgroup: one per SIMD o
 __global__ void __launch_bounds__(64 * WAVE_SCAN_WAVES)
 acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ files,
 		    uint32_t *__restrict__ colpos, acmhip_blkhdr *__restrict__ hdr, AcmParseResult *__restrict__ res,
-		    const uint32_t range, const uint32_t nranges, const uint32_t stripes_up)
+		    const uint32_t range, const uint32_t nranges, const uint32_t stripes_up, uint32_t *__restrict__ blkoff,
+		    uint32_t *__restrict__ mf_pairs)
 {
 	const uint32_t jobno = blockIdx.x * WAVE_SCAN_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (jobno >= njobs)
@@ -395,11 +396,33 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	/* block range `range` of `nranges` (1 of 1: the whole stream): a later range resumes where the one before stopped */
 	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges), b_hi = (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges);
 	uint32_t bit = job.data_start * 8u;
+	/* byte-plane staging (job.mf_rows != 0): where block b starts in the stream's region - behind the pair of zeros, every block at
+	 * one or two bytes per index by its pwr (an index lies in [-2^pwr, 2^pwr): decode.c:592-600) - is a running sum only this walk knows */
+	uint32_t mf_at = (2u * cols) >> 6;
+	/* Byte-plane staging and block ranges: the synthesis of a range is queued behind its walk without the host looking at the result, on
+	 * a plan cut from what the headers promised.  A stream whose walk stops early leaves the pair-table entries of the blocks it did not
+	 * reach unwritten - and an entry is a PLACE: the chunk kernel would load from wherever the garbage points.  Those entries are
+	 * therefore all made to name the place right behind the last block that was staged (inside the stream's region, at or behind
+	 * every entry in front of them: the kernel's offsets stay small and positive).  What is decoded from there is garbage the host
+	 * reader's redo replaces; it is only not allowed to fault. */
+	auto park_entries = [&](const uint32_t first_block, const uint32_t at64) {
+		if (!mf_pairs || !job.mf_rows)
+			return;
+		const uint32_t safe = (uint32_t)(((job.mf_off >> 6) + at64) << 2) | ACMHIP_BP_BYTE;
+		const uint32_t p_end = min(b_hi * rows, job.mf_rows) / 2u;
+		for (uint32_t p = first_block * rows / 2u + lane; p < p_end; p += 64u)
+			mf_pairs[job.mf_pair_off + 1u + p] = safe;
+		if (lane == 0 && range == 0)
+			mf_pairs[job.mf_pair_off] = (uint32_t)((job.mf_off >> 6) << 2) | ACMHIP_BP_BYTE;     /* (the column kernel writes it again with block 0) */
+	};
 	if (range > 0) {
 		const AcmParseResult prev = res[jobno];
-		if (prev.status != 0 || prev.blocks_done != b_lo)
+		if (prev.status != 0 || prev.blocks_done != b_lo) {
+			park_entries(b_lo, prev.mf_at);
 			return;                                 /* the stream failed earlier: its record stays as it is */
+		}
 		bit = prev.end_bit;
+		mf_at = prev.mf_at;
 	}
 	ww.load(bit >> 5);
 	uint32_t done = b_lo, status = 1;
@@ -441,15 +464,21 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 			if (lane < n)
 				cp[c0 + lane] = cpv;
 		}
-		if (lane == 0)
+		if (lane == 0) {
 			hdr[job.hdr_off + b] = acmhip_blkhdr{ h20 >> 4, h20 & 15u };
+			if (blkoff)
+				blkoff[job.hdr_off + b] = mf_at;
+		}
+		mf_at += ((rows * cols) >> 6) << ((h20 & 15u) >= 8u ? 1 : 0);
 		cp += cols;
 		done++;
 	}
 	status = 0;
 out:
+	if (status != 0 || range == 0)
+		park_entries(done, mf_at);
 	if (lane == 0)
-		res[jobno] = AcmParseResult{ done, status, bit, 0u };
+		res[jobno] = AcmParseResult{ done, status, bit, mf_at };
 }
 
 /* ---- kernel 2: decode the columns ---- */
@@ -527,7 +556,8 @@ __global__ void __launch_bounds__(COL_THREADS)
 acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__restrict__ res,
 		  const uint8_t *__restrict__ files, const uint32_t *__restrict__ colpos,
 		  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ idx, uint32_t *__restrict__ flags,
-		  const uint32_t range, const uint32_t nranges)
+		  const uint32_t range, const uint32_t nranges, uint8_t *__restrict__ mf, uint32_t *__restrict__ mf_pairs,
+		  const uint32_t *__restrict__ blkoff)
 {
 	__shared__ uint32_t lut[LUT_CLASSES * 128];
 	const AcmParseJob job = jobs[blockIdx.y];
@@ -552,13 +582,39 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 	const uint64_t bl = (uint64_t)rows << level;
 	const uint32_t *base = reinterpret_cast<const uint32_t *>(files + job.file_off);
 	uint32_t bad = 0;
+	/* byte-plane staging (the chunk kernel's form, include/acm_hip.h: 64 columns of a residue class side by side, 8 or 16 bits per
+	 * index, a 16-bit index as two signed bytes): rows [0, mf_rows) go there, only the rows from mf_rows - 2 on to the int16 arena.
+	 * A wavefront takes 64 columns of ONE class - thread t of it column class + SIGMA t - so that its stores of a row are 64
+	 * consecutive bytes */
+	const uint32_t mf_rows = mf && mf_pairs && blkoff ? job.mf_rows : 0u;
+	const uint32_t sigma = cols >> 6;
+	uint8_t *const region = mf + job.mf_off;
 
 	for (uint32_t g = (b_lo << level) + blockIdx.x * COL_THREADS + threadIdx.x; g < ncol; g += gridDim.x * COL_THREADS) {
-		const uint32_t b = g >> level, c = g & (cols - 1);
-		const int lim = 1 << hdr[job.hdr_off + b].pwr;
+		const uint32_t b = g >> level, cg = g & (cols - 1);
+		const uint32_t c = mf_rows ? (cg >> 6) + sigma * (cg & 63u) : cg;
+		const uint32_t pwr = hdr[job.hdr_off + b].pwr;
+		const int lim = 1 << pwr;
 		int16_t *out = idx + job.idx_off + (uint64_t)b * bl + c;
+		const uint32_t row0 = b * rows;                 /* stream row of the block's first row (blocks * rows < 2^32: acmk_parse_supported) */
+		const uint32_t wide = pwr >= 8u ? 1u : 0u;      /* two bytes per index */
+		uint8_t *mo = nullptr;
+		if (row0 < mf_rows) {
+			const uint64_t at = (uint64_t)blkoff[job.hdr_off + b] << 6;
+			mo = region + at + (((uint64_t)(cg >> 6) * 64u) << wide) + (cg & 63u);
+			/* the block's pair-table entries (entry k of a stream = where row pair k - 1 starts; entry 0: the pair of zeros in front),
+			 * written by the block's first threads */
+			for (uint32_t p = cg; p < rows / 2u; p += cols)
+				if (row0 + 2u * p < mf_rows)
+					mf_pairs[job.mf_pair_off + 1u + row0 / 2u + p] =
+						(uint32_t)(((job.mf_off + at + (((uint64_t)p * 2u * cols) << wide)) >> 6) << 2) | (wide ? ACMHIP_BP_WORD : ACMHIP_BP_BYTE);
+			if (b == 0 && cg == 0)
+				mf_pairs[job.mf_pair_off] = (uint32_t)((job.mf_off >> 6) << 2) | ACMHIP_BP_BYTE;
+			if (b == 0 && cg < cols / 8u)
+				reinterpret_cast<uint4 *>(region)[cg] = make_uint4(0u, 0u, 0u, 0u);       /* the pair of zeros: 2 * cols bytes */
+		}
 		DevBits bs;
-		bs.seek(base, colpos[job.col_off + g]);
+		bs.seek(base, colpos[job.col_off + ((uint64_t)b << level) + c]);     /* (c: the column this thread decodes - not its place in the grid, see above) */
 		const uint32_t code = bs.get(5);
 		const uint32_t cls = code_class(code);
 		const bool table = cls >= CLS_TERN;             /* CLS_BAD cannot occur: the scan flagged the stream */
@@ -589,7 +645,18 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 				}
 			}
 			bad |= (v >= lim) | (v < -lim);                 /* hazard H1: the host resolves stale-table reads */
-			out[(uint64_t)r << level] = (int16_t)v;
+			const uint32_t row = row0 + r;
+			if (row < mf_rows) {
+				const int lo = (int)(int8_t)(uint8_t)v;         /* idx = 256 hi + lo, both signed bytes */
+				uint8_t *const at = mo + ((((uint64_t)(r >> 1) * 2u + (r & 1u)) * cols) << wide);
+				at[0] = (uint8_t)lo;
+				if (wide) {
+					at[64] = (uint8_t)((v - lo) >> 8);
+					bad |= v >= 32640;                      /* beyond the form's range: the host stages the stream as int16 */
+				}
+			}
+			if (row + 2u >= mf_rows)
+				out[(uint64_t)r << level] = (int16_t)v;
 		}
 	}
 	if (bad)
@@ -649,10 +716,22 @@ extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs
 				       AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t range, uint32_t nranges,
 				       uint32_t stripes_up, void *stream)
 {
+	return acmk_launch_parse_range_mf(d_jobs, njobs, d_files, d_colpos, d_idx, d_hdr, d_res, d_flags, max_columns, range, nranges, stripes_up,
+					  nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int acmk_launch_parse_range_mf(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files,
+					  uint32_t *d_colpos, int16_t *d_idx, acmhip_blkhdr *d_hdr,
+					  AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t range, uint32_t nranges,
+					  uint32_t stripes_up, uint8_t *d_mf, uint32_t *d_pairs, uint32_t *d_blkoff, void *stream)
+{
 	if (njobs == 0)
 		return 0;
 	if (nranges == 0 || range >= nranges || (nranges > 1 && njobs > ACM_PARSE_RANGE_MAX_STREAMS))
 		return (int)hipErrorInvalidValue;
+	const bool mf = d_mf && d_pairs && d_blkoff;
+	if (mf && njobs > ACM_PARSE_RANGE_MAX_STREAMS)
+		return (int)hipErrorInvalidValue;               /* the block offsets come from the wave-per-stream walk */
 	hipStream_t st = (hipStream_t)stream;
 	const uint32_t full = (njobs + SCAN_THREADS - 1) / SCAN_THREADS;
 	const uint32_t scan_waves = njobs < 8192u ? njobs : full < 8192u ? 8192u : full;
@@ -660,6 +739,8 @@ extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs
 	/* up to ~32 K streams the wave-per-stream walk wins (profiles/r2_parse_probe.txt: 3.0 against 3.4 ms at 32768 streams of
 	 * 8 blocks, 3.9 against 8.5 ms at 4096 of 64); beyond, one stream per lane keeps more streams in flight than waves fit */
 	uint32_t wave_max = 32768;
+	if (mf)
+		wave_max = ACM_PARSE_RANGE_MAX_STREAMS;
 #ifdef ACM_TUNING
 	static const int scan_mode = getenv("ACM_PARSE_SCAN") ? atoi(getenv("ACM_PARSE_SCAN")) : 2;     /* 0 lanes, 1 scalar (r1), 2 wave */
 	if (getenv("ACM_PARSE_WAVE_MAX"))
@@ -677,7 +758,7 @@ extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs
 #endif
 	if (njobs <= wave_max)
 		hipLaunchKernelGGL(acm_parse_scan_wave, dim3((njobs + WAVE_SCAN_WAVES - 1) / WAVE_SCAN_WAVES), dim3(64 * WAVE_SCAN_WAVES), 0, st,
-				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res, range, nranges, stripes_up);
+				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res, range, nranges, stripes_up, mf ? d_blkoff : nullptr, mf ? d_pairs : nullptr);
 	else
 		hipLaunchKernelGGL(acm_parse_scan, dim3(scan_waves), dim3(SCAN_THREADS), scan_lanes * 33 * sizeof(uint32_t), st,
 				   d_jobs, njobs, d_files, d_colpos, d_hdr, d_res);
@@ -692,7 +773,8 @@ extern "C" int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs
 	for (uint32_t at = 0; at < njobs; at += 65535) {
 		const uint32_t n = njobs - at < 65535 ? njobs - at : 65535;
 		hipLaunchKernelGGL(acm_parse_columns, dim3((unsigned)gx, n), dim3(COL_THREADS), 0, st,
-				   d_jobs + at, d_res + at, d_files, d_colpos, d_hdr, d_idx, d_flags + at, range, nranges);
+				   d_jobs + at, d_res + at, d_files, d_colpos, d_hdr, d_idx, d_flags + at, range, nranges, mf ? d_mf : nullptr,
+				   mf ? d_pairs : nullptr, mf ? d_blkoff : nullptr);
 		ACMP_CHECK();
 	}
 	return 0;

@@ -246,9 +246,9 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
         # the batch status is what stopped the parser; an acm_read_loop() caller may see that error swallowed (test_gpu_parity.py)
         assert (res[k][0] == wst or (res[k][0] < 0 and wst <= 0)) and np.array_equal(res[k][1], want), k
         assert plain[k][0] == res[k][0] and np.array_equal(plain[k][1], want), k
-    # the device parser stages int16: the flag is ignored there
+    # the device parser writes the form itself for the streams that can have it there (the chunk kernel's levels, even block heights)
     res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
-    assert tm.packed_streams == 0
+    assert 0 < tm.packed_streams < tm0.packed_streams + 63
     for k, f in enumerate(files):
         if O.Oracle(f).err >= 0:
             assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
@@ -271,6 +271,47 @@ def test_batch_first_call_on_a_fresh_device_with_small_high_level_streams():
                 assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("ranges", [1, 3, 16])
+def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
+    """VERDICT r4, task 3 (i): acm_batch_decode with device parsing AND ACM_BATCH_STAGE_BYTEPLANE - the column kernel writes the chunk kernel's
+    form itself (width from the block's pwr, places from a running sum in the walk; only the rows behind the whole tiles exist as int16) and
+    the batch's plans - one per chunk, or one per block range, whose streams are windows - read it on the lean kernels.  Every valid filler
+    code at levels 8-12, block heights 2 / 16 / 64 / 700, quiet and loud blocks, stereo; truncated, H1, junk and odd-height files fall back.
+    Same PCM and statuses as the oracle; and the same with the int16 staging of the device parser (ACM_BATCH_DEV_MFORM=0)"""
+    import oracle_api as O
+    monkeypatch.setenv("ACM_BATCH_RANGES", str(ranges))
+    valid = [0] + list(range(3, 17)) + [17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29]
+    files = []
+    for j, code in enumerate(valid):
+        lv = 8 + j % 5
+        rows = [16, 2, 64, 16, 700][j % 5]
+        nblocks = max(3, (6 * capi.lib().acmk_tile2_rows(lv) + rows - 1) // rows + 1 + j % 3)
+        files.append(make_stream(30000 + j, lv, rows, nblocks, mix=2, single_code=code, channels=1 + j % 2, cut=j % 4,
+                                 pwr_min=14 if 3 <= code <= 16 else 4, pwr_max=14 if 3 <= code <= 16 else 12))
+    for i in range(30):
+        lv = [9, 11, 10, 7, 12, 8, 13, 9, 5][i % 9]
+        files.append(make_stream(30100 + i, lv, [16, 3, 64, 8][i % 4], 4 + (i * 7) % 23 + (16384 >> lv) // 4, channels=1 + i % 2, cut=i % 5,
+                                 pwr_max=[12, 6, 15][i % 3], val_max=65535 if i % 3 == 2 else 255))
+    files[3] = files[3][:len(files[3]) * 2 // 3]
+    files[9] = b"RIFFnope"
+    files[13] = make_stream(30990, 9, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
+    files[21] = make_stream(30991, 9, 16, 1)
+    res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    # (with block ranges only streams whose blocks are whole tiles of the lean kernel get the form: a range must end on a tile boundary)
+    assert tm.device_parsed >= 40 and tm.packed_streams >= (25 if ranges == 1 else 15), (tm.device_parsed, tm.packed_streams)
+    monkeypatch.setenv("ACM_BATCH_DEV_MFORM", "0")
+    res0, tm0 = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    assert tm0.packed_streams == 0
+    for k, f in enumerate(files):
+        o = O.Oracle(f)
+        if o.err < 0:
+            assert res[k][0] == o.err and res[k][1].size == 0, k
+            continue
+        want, wst = oracle_pcm(f)
+        assert (res[k][0] == wst or (res[k][0] < 0 and wst <= 0)) and np.array_equal(res[k][1], want), k
+        assert res0[k][0] == res[k][0] and np.array_equal(res0[k][1], want), k
 
 
 def test_plan_says_which_rows_it_reads_from_the_second_form(dev, monkeypatch):
