@@ -925,17 +925,18 @@ def main():
             try:
                 files = [f.tobytes() for f in batch.files]
                 e2e = {"streams": len(files), "host_threads": workload_cpus()}
-                for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("host_parse_byteplane_staging", capi.PARSE_HOST, False),
+                for name, mode, pin in (("host_parse", capi.PARSE_HOST, False), ("host_parse_int16_staging", capi.PARSE_HOST, False),
                                         ("host_parse_packed_staging", capi.PARSE_HOST, False),
-                                        ("device_parse", capi.PARSE_DEVICE, False), ("device_parse_byteplane_staging", capi.PARSE_DEVICE, False),
+                                        ("device_parse", capi.PARSE_DEVICE, False), ("device_parse_int16_staging", capi.PARSE_DEVICE, False),
                                         ("device_parse_pinned_out", capi.PARSE_DEVICE, True)):
                     # pinned_out: the caller's PCM buffers are pinned (acmhip_host_alloc), read-back lands in them directly.
                     # The hosts of this pool are shared: single calls show 1.5-2 x outliers in any mode (profiles/pinned_out_probe.py,
                     # VERDICT r3 Weak 5), so every leg is the best of three calls behind one that sizes the arenas, all totals kept
                     pkd = name == "host_parse_packed_staging"        # ACM_BATCH_STAGE_PACKED: the pool packs too, half the upload
-                    # ACM_BATCH_STAGE_BYTEPLANE: the byte-plane form is written by the parsing pass itself - the host pool's (acm_stage_file_mform)
-                    # or the device parser's column kernel - and the batch's plans read it on the chunk kernel
-                    bpl = name in ("host_parse_byteplane_staging", "device_parse_byteplane_staging")
+                    # the library's default: the byte-plane form is written by the parsing pass itself - the host pool's (acm_stage_file_mform)
+                    # or the device parser's column kernel - and the batch's plans read it on the chunk kernel (`packed_streams` = streams
+                    # that travelled so).  *_int16_staging: ACM_BATCH_STAGE_INT16, every row as int16 (the default up to round 4)
+                    bpl = False if name.endswith("_int16_staging") or pkd else None
                     capi.batch_decode(dev, files, threads=0, parse=mode, pinned=pin, packed=pkd, byteplane=bpl)
                     runs = []
                     for _ in range(1 if mode == capi.PARSE_HOST else 3):

@@ -92,6 +92,11 @@ typedef struct acmhip_plan acmhip_plan;       /* device-resident launch tables f
 /* which kernel family a plan may use */
 #define ACMHIP_PLAN_AUTO      0u    /* one-launch kernels where they apply (levels 0-12 without H1 patches), stage-wise kernels elsewhere */
 #define ACMHIP_PLAN_STAGEWISE 1u    /* force the generic stage-wise kernels (bring-up / cross-check) */
+/* modifiers (or-ed in) */
+#define ACMHIP_PLAN_FORM_ONLY    0x100u  /* streams that come with a byte-plane form are never launched without it: their records over the
+                                          * int16 rows are not cut (half the table bytes); a launch with no form bound fails */
+#define ACMHIP_PLAN_UPLOAD_ASYNC 0x200u  /* acmhip_plan_create* returns with the table uploads queued, not done: every launch of the plan
+                                          * waits for them on the device (an event wait: do not capture such a launch into a graph) */
 
 const char *acmhip_last_error(void);          /* thread-local text of the last failure */
 int  acmhip_device_count(void);               /* usable HIP devices, 0 if none (never fails) */
@@ -355,10 +360,11 @@ typedef struct acm_batch_opts {
                                        upload carries the packed form + the int16 rows the other kernels still read (ragged tails) instead
                                        of the whole int16 arena - about half the bytes over PCIe and through HBM, for ~30 % more host
                                        work per stream and a synthesis launch that is 10-18 % slower (acm_tile2p).  Off by default. */
-#define ACM_BATCH_STAGE_BYTEPLANE 4u /* host parsing only: the pool also re-orders the whole tiles of every clean stream of levels 7-14 into the
-                                       byte-plane form (acmhip_mform_rows; same bytes) and the upload carries that + the int16 rows the other
-                                       kernels still read: fewer bytes to upload, and the synthesis launch runs its first pass on the matrix cores (+3 ... +24 % by level).  Wins over
-                                       ACM_BATCH_STAGE_PACKED when both are set. */
+#define ACM_BATCH_STAGE_BYTEPLANE 4u /* the default, spelled out: whoever parses the bits - the host pool (acm_stage_file_mform) or the device parser's
+                                       column kernel - writes the whole tiles of every clean stream of levels 7-14 in the byte-plane form (same bytes as
+                                       int16 rows) and only the rows the other kernels still read as int16; the synthesis launch runs its first pass on
+                                       the matrix cores (+3 ... +24 % by level).  Wins over ACM_BATCH_STAGE_PACKED when both are set. */
+#define ACM_BATCH_STAGE_INT16  8u   /* every row is staged as int16, no second form (the round-1 ... round-4 default; measurements, cross-checks) */
 #define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
                                        the PCM straight into it, stream by stream, instead of through the library's own pinned
                                        arena and a host copy (taken for streams of 64 KB of PCM and more on average) */

@@ -635,17 +635,19 @@ PARSE_HOST, PARSE_DEVICE, PARSE_AUTO = 0, 1, 2
 BATCH_PCM_PINNED = 1
 BATCH_STAGE_PACKED = 2
 BATCH_STAGE_BYTEPLANE = 4
+BATCH_STAGE_INT16 = 8
 
 
 def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN_AUTO, parse=PARSE_HOST, pinned=False, prestage=False,
-                 packed=False, byteplane=False):
+                 packed=False, byteplane=None):
     """acm_batch_decode over a list of bytes objects -> (list of (status, uint16 array), BatchTiming).
 
     pinned=True: the output buffers are carved from one pinned arena (acmhip_host_alloc) and the call is told so
     (ACM_BATCH_PCM_PINNED: the read-back engine writes them directly); the arrays returned are copies.
     prestage=True: the bit parsing runs first, on its own (acm_batch_prestage: no device involved), and the decode gets its result.
     packed=True: ACM_BATCH_STAGE_PACKED - the host pool also packs the whole tiles, the upload carries the packed form.
-    byteplane=True: ACM_BATCH_STAGE_BYTEPLANE - the same with the byte-plane form (first pass on the matrix cores)."""
+    byteplane: None = the library's default (the byte-plane form wherever a stream can have it: first pass on the matrix cores),
+    True = ACM_BATCH_STAGE_BYTEPLANE spelled out, False = ACM_BATCH_STAGE_INT16 (every row staged as int16)."""
     n = len(files)
     bufs = [_as_u8(f) for f in files]
     infos = [probe(b, force_chans) for b in bufs]
@@ -673,7 +675,7 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
         items[k].pcm = outs[k].ctypes.data if outs[k].size else None
         items[k].pcm_cap = outs[k].size
     opts = BatchOpts(force_chans, fmt, threads, flags, parse, (BATCH_PCM_PINNED if pinned else 0) | (BATCH_STAGE_PACKED if packed else 0) |
-                     (BATCH_STAGE_BYTEPLANE if byteplane else 0))
+                     (BATCH_STAGE_BYTEPLANE if byteplane else 0) | (BATCH_STAGE_INT16 if byteplane is False else 0))
     tm = BatchTiming()
     pre = C.c_void_p()
     try:

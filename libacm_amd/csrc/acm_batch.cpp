@@ -494,9 +494,11 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			chunks[c].pk_chunk_end = pk_chunks_total;
 		}
 
-	/* the byte-plane staged form (opt-in, host parsing): every stream of a level the matrix-core build covers gets room for its
+	/* the byte-plane staged form (the default; ACM_BATCH_STAGE_INT16 turns it off): every stream of a level the matrix-core build covers gets room for its
 	 * rows plus the two rows of zeros in front */
-	bool stage_mform = (opts.flags & ACM_BATCH_STAGE_BYTEPLANE) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
+	/* (blocks parsed ahead of time are int16 rows already: re-ordering them is a pass of its own, taken only when asked for) */
+	const bool mform_default = !(opts.flags & (ACM_BATCH_STAGE_INT16 | ACM_BATCH_STAGE_PACKED)) && !pre;
+	bool stage_mform = ((opts.flags & ACM_BATCH_STAGE_BYTEPLANE) || mform_default) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
 			   !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
 	uint64_t mf_total = 0, mf_pairs_total = 0;
 	if (stage_mform) {
@@ -1073,7 +1075,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			return ACMHIP_OK;
 		if (!stage_packed && !stage_mform && !dev_mform)
 			return acmhip_plan_create(dev, descs.data(), descs.size(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
-		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(), opts.plan_flags, &ch.plan);
+		/* (a chunk's byte-plane streams are never launched without their form: no records over int16 rows they may not have) */
+		int r = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), patches.data(), patches.size(),
+						  opts.plan_flags | (stage_mform || dev_mform ? ACMHIP_PLAN_FORM_ONLY : 0u), &ch.plan);
 		if (r == ACMHIP_OK)
 			r = stage_mform || dev_mform ? acmhip_plan_bind_mform(ch.plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk))
 					: acmhip_plan_bind_packed(ch.plan, d_pkchunk, d_pkblob);
@@ -1084,8 +1088,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * uploads otherwise wait behind whatever long walk kernel shares their hardware queue */
 	std::vector<char> planned(chunks.size(), 0), replan(chunks.size(), 0);
 	/* block ranges: one plan per range over every stream's piece (a window of the stream that starts at the range's first row;
-	 * the staged rows in front of it are on the device by then: earlier ranges) */
-	for (size_t r = 0; r < rchunks.size(); r++) {
+	 * the staged rows in front of it are on the device by then: earlier ranges).  Cut right behind the launch of the range's walk,
+	 * which takes the device longer than the tables take the host; their upload is only queued (ACMHIP_PLAN_UPLOAD_ASYNC), so a
+	 * table copy that shares a hardware queue with a walk kernel holds up nothing but the synthesis that waits for that walk anyway */
+	auto cut_range_plan = [&](size_t r) -> int {
 		std::vector<acmhip_stream_desc> descs;
 		std::vector<acmhip_packed_stream> packed;
 		for (size_t i = 0; i < n; i++) {
@@ -1104,14 +1110,15 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			d.n_emit = piece_len[r * n + i];
 			descs.push_back(d);
 		}
-		if (!descs.empty() && dev_mform) {
-			/* every range is a plan of windows; a window of a stream the device stages in the byte-plane form goes to the lean kernels */
-			BTRY(acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), nullptr, 0, opts.plan_flags, &rchunks[r].plan));
-			BTRY(acmhip_plan_bind_mform(rchunks[r].plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk)));
-		} else if (!descs.empty()) {
-			BTRY(acmhip_plan_create(dev, descs.data(), descs.size(), nullptr, 0, opts.plan_flags, &rchunks[r].plan));
-		}
-	}
+		if (descs.empty())
+			return ACMHIP_OK;
+		const unsigned pf = opts.plan_flags | ACMHIP_PLAN_UPLOAD_ASYNC;
+		if (!dev_mform)
+			return acmhip_plan_create(dev, descs.data(), descs.size(), nullptr, 0, pf, &rchunks[r].plan);
+		/* every range is a plan of windows; a window of a stream the device stages in the byte-plane form goes to the lean kernels */
+		const int pr = acmhip_plan_create_packed(dev, descs.data(), descs.size(), packed.data(), nullptr, 0, pf | ACMHIP_PLAN_FORM_ONLY, &rchunks[r].plan);
+		return pr != ACMHIP_OK ? pr : acmhip_plan_bind_mform(rchunks[r].plan, d_pkblob, reinterpret_cast<const acmhip_mform_pair *>(d_pkchunk));
+	};
 	if (!groups.empty() && R == 1) {
 		for (size_t c = 0; c < chunks.size(); c++) {
 			bool all_dev = true;
@@ -1166,10 +1173,17 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 								 dev_mform ? d_blkoff : nullptr, st_parse);
 			if (e != 0)
 				return acmhip_report_hip(e, "acmk_launch_parse_range");
+			BNOTE("range %zu: walk queued", r);
 			if (R == 1)
 				return ACMHIP_OK;
 			/* range r is staged: synthesise it and read it back while the walk goes on */
 			Chunk &rg = rchunks[r];
+			{
+				const int cr = cut_range_plan(r);
+				if (cr != ACMHIP_OK)
+					return cr;
+			}
+			BNOTE("range %zu: plan cut", r);
 #define RTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return acmhip_report_hip((int)e_, #call); } while (0)
 			RTRY(hipEventRecord(rg.ev[1], st_parse));
 			RTRY(hipStreamWaitEvent(st_main, rg.ev[1], 0));
@@ -1179,6 +1193,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 				if (pr != ACMHIP_OK)
 					return pr;
 			}
+			BNOTE("range %zu: synthesis queued", r);
 			RTRY(hipEventRecord(rg.ev[2], st_main));
 			RTRY(hipStreamWaitEvent(st_copy, rg.ev[2], 0));
 			RTRY(hipEventRecord(rg.ev[3], st_copy));
@@ -1211,6 +1226,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 					std::unique_lock<std::mutex> lk(m);
 					cv.wait(lk, [&]() { return stripe_uncopied[sp].load() == 0; });
 				}
+				BNOTE("stripe %zu is in the pinned arena", sp);
 				if (stripe_base[sp + 1] > stripe_base[sp])
 					HTRY(hipMemcpyAsync(d_stage + stripe_base[sp], h_files + stripe_base[sp], stripe_base[sp + 1] - stripe_base[sp],
 							    hipMemcpyHostToDevice, st_up));

@@ -49,6 +49,11 @@ struct acmhip_device {
 	hipStream_t upload = nullptr;           /* plan tables go up on a non-blocking stream of their own (to_device) */
 	hipStream_t aux[ACM_AUX_STREAMS] = {};  /* the batch pipeline's per-group upload + bit-parsing streams, created on first use */
 	std::mutex upload_mutex;
+	/* pinned staging ring of the table uploads: a copy out of pinned memory returns when it is queued, so a plan waits once for all its
+	 * tables (or not at all: ACMHIP_PLAN_UPLOAD_ASYNC) instead of once per table */
+	uint8_t *up_ring = nullptr;
+	size_t up_at = 0;
+	static constexpr size_t UP_RING_BYTES = (size_t)32 << 20;
 	int cus = 0;                            /* compute units, sizes the persistent grids */
 	void *arena[ACM_ARENA_SLOTS] = {};
 	size_t arena_cap[ACM_ARENA_SLOTS] = {};
@@ -115,6 +120,8 @@ struct acmhip_plan {
 	 * over the device stream and two side streams - the ramp-up and the tail of one launch overlap the next one's
 	 * instead of leaving the chip half empty three times (fork / join by events on the device stream) */
 	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
+	hipEvent_t ev_upload = nullptr;         /* ACMHIP_PLAN_UPLOAD_ASYNC: the tables are on the device once this has happened */
+	bool form_only = false;                 /* ACMHIP_PLAN_FORM_ONLY: no int16 twin of the byte-plane records */
 };
 
 extern "C" const char *acmhip_last_error(void)
@@ -197,6 +204,8 @@ extern "C" void acmhip_device_close(acmhip_device *dev)
 		(void)hipStreamDestroy(dev->copy_stream);
 	if (dev->upload)
 		(void)hipStreamDestroy(dev->upload);
+	if (dev->up_ring)
+		(void)hipHostFree(dev->up_ring);
 	for (hipStream_t s : dev->aux)
 		if (s)
 			(void)hipStreamDestroy(s);
@@ -389,15 +398,44 @@ int to_device(acmhip_plan *pl, const std::vector<T> &v, T **out)
 		if (rc != ACMHIP_OK)
 			return rc;
 	}
-	/* done when this returns (the host vector dies with the caller), on a non-blocking stream of the handle's own: neither
-	 * the device stream - which may be the caller's and busy with the chunks of a batch still in flight (acm_batch_decode
-	 * builds the plan of chunk k+1 while chunk k runs) - nor the legacy null stream, whose copies join every blocking
-	 * stream of the process and are refused while another thread captures a graph, is involved */
+	/* on a non-blocking stream of the handle's own: neither the device stream - which may be the caller's and busy with the chunks of a
+	 * batch still in flight (acm_batch_decode builds the plan of chunk k+1 while chunk k runs) - nor the legacy null stream, whose copies
+	 * join every blocking stream of the process and are refused while another thread captures a graph, is involved.  The table goes
+	 * through the pinned ring (the host vector dies with the caller) and is on the device when upload_done() has returned */
+	const size_t bytes = (v.size() * sizeof(T) + 255) & ~(size_t)255;
 	std::lock_guard<std::mutex> g(dev->upload_mutex);
 	if (!dev->upload)
 		HIPTRY(hipStreamCreateWithFlags(&dev->upload, hipStreamNonBlocking));
-	HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
-	HIPTRY(hipStreamSynchronize(dev->upload));
+	if (!dev->up_ring && bytes <= acmhip_device::UP_RING_BYTES)
+		HIPTRY(hipHostMalloc((void **)&dev->up_ring, acmhip_device::UP_RING_BYTES, hipHostMallocDefault));
+	if (bytes > acmhip_device::UP_RING_BYTES) {
+		HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
+		HIPTRY(hipStreamSynchronize(dev->upload));
+		return ACMHIP_OK;
+	}
+	if (dev->up_at + bytes > acmhip_device::UP_RING_BYTES) {
+		HIPTRY(hipStreamSynchronize(dev->upload));     /* the ring is free again once everything queued from it has gone */
+		dev->up_at = 0;
+	}
+	memcpy(dev->up_ring + dev->up_at, v.data(), v.size() * sizeof(T));
+	HIPTRY(hipMemcpyAsync(*out, dev->up_ring + dev->up_at, v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
+	dev->up_at += bytes;
+	return ACMHIP_OK;
+}
+
+/* the tables of a new plan are on the device: waited for here, or (async) left to an event the plan's launches wait for */
+int upload_done(acmhip_plan *pl, bool async)
+{
+	acmhip_device *dev = pl->dev;
+	std::lock_guard<std::mutex> g(dev->upload_mutex);
+	if (!dev->upload)
+		return ACMHIP_OK;
+	if (!async) {
+		HIPTRY(hipStreamSynchronize(dev->upload));
+		return ACMHIP_OK;
+	}
+	HIPTRY(hipEventCreateWithFlags(&pl->ev_upload, hipEventDisableTiming));
+	HIPTRY(hipEventRecord(pl->ev_upload, dev->upload));
 	return ACMHIP_OK;
 }
 
@@ -436,6 +474,10 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	if (plan->dev) {
 		(void)hipSetDevice(plan->dev->ordinal);
 		(void)hipStreamSynchronize(plan->dev->stream);   /* the launches of this plan are done with its tables (side streams join the device stream) */
+	}
+	if (plan->ev_upload) {
+		(void)hipEventSynchronize(plan->ev_upload);      /* (a plan dropped before it was launched: its blocks may be handed on) */
+		(void)hipEventDestroy(plan->ev_upload);
 	}
 	if (plan->ev_fork)
 		(void)hipEventDestroy(plan->ev_fork);
@@ -537,8 +579,9 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		for (uint64_t r = row0 ? row0 - T2 : 0; r < row0 + rows2; r += T2) {
 			const bool lead_in = r < row0;
 			const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
-			plain.push_back(AcmTile2{ s.idx_off + (r << s.level), pcm_of(r),
-						  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic, flags_of(r, lead_in) });
+			if (!(mf && (flags & ACMHIP_PLAN_FORM_ONLY)))
+				plain.push_back(AcmTile2{ s.idx_off + (r << s.level), pcm_of(r),
+							  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic, flags_of(r, lead_in) });
 			if (pk)
 				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
 								     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
@@ -806,6 +849,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		return ACMHIP_ERR_NOMEM;
 	pl->dev = dev;
 	pl->variant = variant;
+	pl->form_only = (flags & ACMHIP_PLAN_FORM_ONLY) != 0;
 	pl->form_rows = std::move(form_rows);
 	int rc = to_device(pl, ds, &pl->d_streams);
 	for (uint32_t lv = 0; lv < 16 && rc == ACMHIP_OK; lv++) {
@@ -920,6 +964,8 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		for (int b = 0; b < 2 && rc == ACMHIP_OK; b++)
 			rc = plan_malloc(pl, (void **)&pl->d_plane[b], plane * sizeof(int32_t));
 	}
+	if (rc == ACMHIP_OK)
+		rc = upload_done(pl, (flags & ACMHIP_PLAN_UPLOAD_ASYNC) != 0);
 	if (rc != ACMHIP_OK) {
 		acmhip_plan_destroy(pl);
 		return rc;
@@ -968,6 +1014,14 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 	if (!pl || fmt > 3)
 		return ACMHIP_ERR_ARG;
 	void *st = (void *)pl->dev->stream;
+	if (pl->ev_upload)
+		HIPTRY(hipStreamWaitEvent(pl->dev->stream, pl->ev_upload, 0));
+	if (pl->form_only && !pl->mform)
+		for (const LevelGroup &g : pl->fused)
+			if (g.ntiles2m) {
+				set_err("a plan cut with ACMHIP_PLAN_FORM_ONLY is launched without its byte-plane form bound");
+				return ACMHIP_ERR_ARG;
+			}
 
 	const bool spread = pl->ev_fork != nullptr;
 	if (spread) {

@@ -233,8 +233,11 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
     files[11] = b"RIFFnope"
     files[17] = make_stream(27990, 7, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
     files[23] = make_stream(27991, 9, 16, 1)                 # one block = one tile exactly: nothing travels as int16
-    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage)
+    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=False)
     res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=True)
+    dflt, tmd = capi.batch_decode(dev, files, threads=4, prestage=prestage)         # the default: the form, unless the blocks were parsed ahead
+    assert tmd.packed_streams == (0 if prestage else tm.packed_streams)
+    assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(dflt, res))
     assert tm0.packed_streams == 0 and tm.packed_streams >= 30, (tm0.packed_streams, tm.packed_streams)
     assert tm.h2d_bytes < 0.95 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)          # quiet blocks travel at 4 or 8 bits per index
     for k, f in enumerate(files):

@@ -122,7 +122,7 @@ def test_batch_decode_stages_packed(dev, prestage):
     files[17] = make_stream(17990, 7, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
     files[23] = make_stream(17991, 9, 16, 1)                 # one block = one tile exactly: nothing travels as int16
     files[29] = make_stream(17992, 9, 16, 64, mix=2, single_code=16, pwr_min=15, pwr_max=15)     # 16-bit indices throughout
-    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage)
+    plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=False)
     res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, packed=True)
     assert tm0.packed_streams == 0 and tm.packed_streams >= 25, (tm0.packed_streams, tm.packed_streams)
     assert tm.h2d_bytes < 0.8 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
