@@ -175,7 +175,10 @@ class PowerSampler:
                 w = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
                 f = [int(v.strip("()Mhz")) for k, v in card.items() if "sclk clock speed" in k]
                 if w and f:
-                    self.samples.append((w[0], f[0]))
+                    # (memory and fabric clocks too: a launch that is slow at a HIGH shader clock and below the cap is waiting for them)
+                    other = {k.split()[0]: int(v.strip("()Mhz")) for k, v in card.items()
+                             if "clock speed" in k and k.split()[0] in ("mclk", "fclk", "socclk") and v.strip("()Mhz").isdigit()}
+                    self.samples.append((w[0], f[0], other))
             except Exception:
                 pass
 
@@ -203,8 +206,13 @@ class PowerSampler:
             pass
         w = sorted(x[0] for x in s)
         f = sorted(x[1] for x in s)
+        other = {}
+        for k in ("mclk", "fclk", "socclk"):
+            v = sorted(x[2][k] for x in s if k in x[2])
+            if v:
+                other[k + "_mhz_median"] = v[len(v) // 2]
         return {"socket_w_median": round(w[len(w) // 2], 1), "socket_w_max": round(w[-1], 1), "power_cap_w": cap,
-                "sclk_mhz_median": f[len(f) // 2], "sclk_mhz_max_of_device": 2400, "samples": len(s),
+                "sclk_mhz_median": f[len(f) // 2], "sclk_mhz_max_of_device": 2400, **other, "samples": len(s),
                 "source": "rocm-smi --showpower --showclocks, sampled during a 2 s run of the same launches behind the timed region"}
 
 
@@ -709,6 +717,22 @@ def main():
         if got != want:
             raise SystemExit("bench.py: PCM after the timed region differs from the oracle - refusing to report a number")
 
+    # the box's copy kernel between THESE arenas (staged input -> PCM arena; garbage PCM, behind the last check): the rate of a launch
+    # follows where its arenas landed in physical memory by +-5 % (profiles/r5_placement.txt: a plain copy between the same two
+    # allocations moves with it), so the like-for-like ceiling is a copy between the very buffers that were timed
+    copy_same = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            cb = C.CDLL(os.path.join(ROOT, "profiles", "ubench", "libcopybw.so"))
+            cb.acm_copy_between_gbs.restype = C.c_double
+            cb.acm_copy_between_gbs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            src, src_bytes = (d_mf[0], mf.data.nbytes) if mf else (bufs[0], 2 * batch.pcm_words)
+            nb = min(src_bytes, 2 * batch.pcm_words) // (1 << 20) * (1 << 20)
+            dev.sync()
+            copy_same = round(cb.acm_copy_between_gbs(bufs[2], src, nb), 1) if nb else None
+        except Exception:
+            copy_same = None
+
     # max over ranks of the bracketed wall time
     if dist is not None:
         t = torch.tensor([wall], device=cdev, dtype=torch.float64)
@@ -899,6 +923,10 @@ def main():
                     out["roofline"]["frac_of_d2d_copy_on_measured_traffic"] = (
                         round(traffic / (launch_ms * 1e-3) / 1e9 / best[0], 4) if traffic else None)
                     out["roofline"]["read_only_gbs"], out["roofline"]["write_only_gbs"] = best[2]
+                if copy_same:
+                    out["roofline"]["d2d_copy_same_arenas_gbs"] = copy_same
+                    out["roofline"]["frac_of_d2d_copy_same_arenas_on_measured_traffic"] = (
+                        round(traffic / (launch_ms * 1e-3) / 1e9 / copy_same, 4) if traffic else None)
             except Exception as e:
                 out["roofline"]["d2d_copy_gbs"] = None
                 out["roofline"]["d2d_copy_error"] = str(e)[:120]

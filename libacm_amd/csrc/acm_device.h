@@ -147,6 +147,7 @@ int acmk_launch_tile2p(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_
 /* the byte-plane staged form: the same tile records as acm_tile2 except that idx_off is the pair-table entry of the row pair in front of the tile */
 int acmk_tile2m_rows(uint32_t level);                           /* = acmk_tile2_rows, 0 if the level has no such build */
 int acmk_tile2m_lead_in(uint32_t level);                        /* tiles of this build in front of a window into a stream (ACM_TILE_DISCARD records) */
+int acmk_tile2m_run_waves(uint32_t level, int cus);             /* wavefronts that share a launch's table (the chunk kernel: one contiguous run each), else 0 */
 int acmk_tile2m_stages(uint32_t level);                         /* stages of its first pass (3 or 4): the form keeps 2^stages columns of a residue class side by side */
 int acmk_launch_tile2m(uint32_t level, int cus, const AcmTile2 *d_tiles, uint32_t ntiles, const uint8_t *d_mform, const acmhip_mform_pair *d_pairs,
 		       const acmhip_blkhdr *d_hdr, int16_t *d_pcm, int16_t *d_sink, unsigned fmt, void *stream);

@@ -809,6 +809,54 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		}
 	}
 
+#ifdef ACM_TUNING
+	/* EXPERIMENT (ACM_K3_SEG=S; measured and not kept, profiles/r5_placement.txt): the chunk kernel's table in time-major order - wavefront v's run is segments v, v + W, v + 2 W, ... of S
+	 * chunks each (W wavefronts), every segment behind lead-in records for the chunks in front of it: at any moment the W wavefronts
+	 * work inside one window of W x S chunks that moves through the arenas, instead of all over them */
+	if (const char *e = getenv("ACM_K3_SEG")) {
+		const size_t S = (size_t)atoi(e);
+		for (uint32_t lv = 0; lv < 16 && S > 0; lv++) {
+			const size_t W = (size_t)acmk_tile2m_run_waves(lv, dev->cus);
+			std::vector<AcmTile2> &T = tiles2m[lv];
+			bool plainly_cut = W > 0 && !T.empty();
+			for (const AcmTile2 &r : T)
+				plainly_cut = plainly_cut && !(r.flags & ACM_TILE_DISCARD);
+			if (!plainly_cut)
+				continue;
+			const size_t lead = (size_t)acmk_tile2m_lead_in(lv);
+			std::vector<size_t> seg;                /* first record of every segment */
+			for (size_t k = 0, in_seg = 0; k < T.size(); k++, in_seg++)
+				if (k == 0 || (T[k].flags & ACM_TILE_FRESH) || in_seg == S) {
+					seg.push_back(k);
+					in_seg = 0;
+				}
+			seg.push_back(T.size());
+			const size_t nseg = seg.size() - 1;
+			std::vector<AcmTile2> N;
+			N.reserve(T.size() + nseg * lead);
+			for (size_t v = 0; v < W; v++)
+				for (size_t g = v; g < nseg; g += W) {
+					const size_t a = seg[g], b = seg[g + 1];
+					if (!(T[a].flags & ACM_TILE_FRESH)) {
+						size_t from = a;
+						for (size_t n = 0; n < lead && from > 0; n++) {
+							from--;
+							if (T[from].flags & ACM_TILE_FRESH)
+								break;
+						}
+						for (size_t k = from; k < a; k++) {
+							AcmTile2 r = T[k];
+							r.flags |= ACM_TILE_DISCARD;
+							N.push_back(r);
+						}
+					}
+					N.insert(N.end(), T.begin() + (long)a, T.begin() + (long)b);
+				}
+			T.swap(N);
+		}
+	}
+#endif
+
 	/* H1 patches -> plane coordinates */
 	std::vector<AcmDevPatch> dp;
 	std::vector<std::vector<size_t>> win_of(windows.empty() ? 0 : n);

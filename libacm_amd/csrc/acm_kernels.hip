@@ -3135,6 +3135,15 @@ extern "C" int acmk_tile2m_lead_in(uint32_t level)
 	}
 }
 
+/* wavefronts that share a launch of the chunk kernel's table among them (each takes one contiguous run of it); 0: not the chunk kernel */
+extern "C" int acmk_tile2m_run_waves(uint32_t level, int cus)
+{
+	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL || tile2m_entry(level).g0 != 6)
+		return 0;
+	const Tile2Entry &e = tile2m_entry(level).e;
+	return (cus > 0 ? cus : 256) * e.wg_per_cu * (e.threads / 64);
+}
+
 extern "C" int acmk_tile2m_stages(uint32_t level)
 {
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL)

@@ -88,6 +88,24 @@ extern "C" int acm_one_way_gbs(size_t bytes, double *out) {
 }
 /* bench.py poisons the whole PCM buffer before it times another staged form: a launch that skipped tiles must not find the
  * previous form's (correct) samples there */
+/* the best of those kernels between two buffers of the caller's (profiles/placement_k3_realloc.py: is a slow allocation slow for a copy too?) */
+extern "C" double acm_copy_between_gbs(void *dst, const void *src, size_t bytes) {
+  const size_t n = bytes / 16;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  double best = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    hipLaunchKernelGGL((copy_runs<1, 1>), dim3(2048), dim3(256), 0, 0, (const uint4 *)src, (uint4 *)dst, n);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL((copy_runs<1, 1>), dim3(2048), dim3(256), 0, 0, (const uint4 *)src, (uint4 *)dst, n);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double gbs = 5 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    if (gbs > best) best = gbs;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return best;
+}
 extern "C" int acm_poison(void *p, size_t bytes, int value) {
   if (hipMemset(p, value, bytes) != hipSuccess) return -1;
   return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
