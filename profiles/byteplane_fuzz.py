@@ -1,8 +1,8 @@
 """Soak of the byte-plane staged form: random batches (levels 6-14 around the levels that have the form, block heights 1-70,
 pwr ranges from "every index a nibble" (pwr 3) to full 16 bits, mono / stereo, ragged ends, truncated files, H1 streams, junk) through
 (a) the plan API with the byte-plane arena bound (capi.synth(mform=True): host stager + the matrix-core build of acm_tile2, ACM_K2=1 so that small plans take
-the lean kernels too) and (b) acm_batch_decode with ACM_BATCH_STAGE_BYTEPLANE (host parsing, optionally prestaged, pinned or pageable
-output) - every stream's PCM against the CPU oracle.
+the lean kernels too) and (b) acm_batch_decode with byte-plane staging (the default; host parsing, prestaged, or device parsing in 1 ... 16 block ranges; pinned or
+pageable output) - every stream's PCM against the CPU oracle.
 usage: python3 profiles/byteplane_fuzz.py [batches [seed]]   (GPU box)"""
 import os
 import sys
@@ -59,8 +59,10 @@ with capi.Device(0) as dev:
                     bad += 1
                     print("batch %d (plan API, fmt %d): stream differs" % (b, fmt), flush=True)
         # (b) batch front end
-        res, tm = capi.batch_decode(dev, files, threads=int(rng.integers(1, 9)), pinned=bool(rng.integers(0, 2)), prestage=bool(rng.integers(0, 2)),
-                                    byteplane=True)
+        mode = int(rng.integers(0, 3))             # host parsing, host parsing ahead of the call, device parsing in 1 ... 16 block ranges
+        os.environ["ACM_BATCH_RANGES"] = str(int(rng.choice([1, 2, 3, 5, 8, 16])))
+        res, tm = capi.batch_decode(dev, files, threads=int(rng.integers(1, 9)), pinned=bool(rng.integers(0, 2)), prestage=mode == 1,
+                                    parse=capi.PARSE_DEVICE if mode == 2 else capi.PARSE_HOST, byteplane=True if mode == 1 else None)
         packed_streams += tm.packed_streams
         for k, f in enumerate(files):
             streams += 1
