@@ -1298,6 +1298,30 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		return ACMHIP_OK;
 	};
 
+	/* uploads of many small pieces of one arena (a stream's byte-plane block, its int16 tail): a transfer call costs what ~256 KB cost
+	 * on the wire, so pieces closer together than that travel as one, the bytes between them with them (unread on the device); a
+	 * batch of 65 536 small streams is a few transfers per chunk instead of two per stream */
+	struct Span { uint64_t at, len; };
+	auto upload_spans = [&](uint8_t *d_base, const uint8_t *h_base, std::vector<Span> &spans) -> hipError_t {
+		constexpr uint64_t JOIN = 256u << 10;
+		for (size_t k = 0; k < spans.size();) {
+			uint64_t at = spans[k].at, end = spans[k].at + spans[k].len;
+			size_t j = k + 1;
+			while (j < spans.size() && spans[j].at >= at && spans[j].at <= end + JOIN) {
+				end = std::max(end, spans[j].at + spans[j].len);
+				j++;
+			}
+			const hipError_t e = hipMemcpyAsync(d_base + at, h_base + at, end - at, hipMemcpyHostToDevice, st_main);
+			if (e != hipSuccess)
+				return e;
+			tm.h2d_bytes += end - at;
+			k = j;
+		}
+		spans.clear();
+		return hipSuccess;
+	};
+	std::vector<Span> spans;
+
 	/* 3. this thread feeds the device, chunk by chunk (with block ranges the loop above has queued everything already) */
 	for (size_t c = 0; c < chunks.size() && R == 1; c++) {
 		Chunk &ch = chunks[c];
@@ -1334,9 +1358,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
 						if (!rows2)
 							continue;               /* the plan reads this stream's int16 rows (see below): its byte-plane block stays here */
-						HTRY(hipMemcpyAsync(d_pkblob + s.mf_off, h_pkblob + s.mf_off, s.mf_used, hipMemcpyHostToDevice, st_main));
-						tm.h2d_bytes += s.mf_used;
+						spans.push_back(Span{ s.mf_off, s.mf_used });
 					}
+					HTRY(upload_spans(d_pkblob, h_pkblob, spans));
 					/* the chunk's pair-table entries in one piece (a few bytes per thousand samples; entries of streams without the form
 					 * travel with them unread) instead of a transfer per stream */
 					if (ch.mf_pair_end > ch.mf_pair_begin) {
@@ -1384,10 +1408,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 							continue;               /* nothing behind the whole tiles is emitted */
 						from_row = rows2 >= 2 ? rows2 - 2 : 0;
 					}
-					HTRY(hipMemcpyAsync(d_idx + s.idx_off + from_row * cols, h_idx + s.idx_off + from_row * cols,
-							    (nrows - from_row) * cols * sizeof(int16_t), hipMemcpyHostToDevice, st_main));
-					tm.h2d_bytes += (nrows - from_row) * cols * sizeof(int16_t);
+					spans.push_back(Span{ (s.idx_off + from_row * cols) * sizeof(int16_t), (nrows - from_row) * cols * sizeof(int16_t) });
 				}
+				HTRY(upload_spans(reinterpret_cast<uint8_t *>(d_idx), reinterpret_cast<const uint8_t *>(h_idx), spans));
 				HTRY(hipMemcpyAsync(d_hdr + ch.hdr_begin, h_hdr + ch.hdr_begin, (ch.hdr_end - ch.hdr_begin) * sizeof(acmhip_blkhdr),
 						    hipMemcpyHostToDevice, st_main));
 			} else if (!dev_parse) {

@@ -406,9 +406,11 @@ int to_device(acmhip_plan *pl, const std::vector<T> &v, T **out)
 	std::lock_guard<std::mutex> g(dev->upload_mutex);
 	if (!dev->upload)
 		HIPTRY(hipStreamCreateWithFlags(&dev->upload, hipStreamNonBlocking));
-	if (!dev->up_ring && bytes <= acmhip_device::UP_RING_BYTES)
+	/* (the ring is pinned when the first table of 256 KB or more comes by: a handle that only ever decodes a file or two - acmtool -d -
+	 * does not pay for 32 MB of pinned memory, its few small tables go up straight from where they are) */
+	if (!dev->up_ring && bytes >= ((size_t)256 << 10) && bytes <= acmhip_device::UP_RING_BYTES)
 		HIPTRY(hipHostMalloc((void **)&dev->up_ring, acmhip_device::UP_RING_BYTES, hipHostMallocDefault));
-	if (bytes > acmhip_device::UP_RING_BYTES) {
+	if (!dev->up_ring || bytes > acmhip_device::UP_RING_BYTES) {
 		HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
 		HIPTRY(hipStreamSynchronize(dev->upload));
 		return ACMHIP_OK;
@@ -576,25 +578,53 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		};
 		/* where sample (row r, column 0) goes: rows count from the window's first row (a lead-in stores into the sink) */
 		auto pcm_of = [&](uint64_t r) -> uint64_t { return s.pcm_off + ((r >= row0 ? r - row0 : 0) << s.level); };
-		for (uint64_t r = row0 ? row0 - T2 : 0; r < row0 + rows2; r += T2) {
+		/* (a batch of small streams cuts millions of records, on the thread that feeds the device: block and row of a record by
+		 * 32-bit division - rows < 2^32 - and room in the vectors made per stream, not per record) */
+		const uint64_t first = row0 ? row0 - T2 : 0, ntile = (row0 + rows2 - first) / T2;
+		const uint64_t lead_rows = mf ? (uint64_t)T2M * (uint64_t)acmk_tile2m_lead_in(s.level) : 0;      /* (<= T2: two rows more at most) */
+		const uint32_t pk_slots = pk ? (uint32_t)acmk_tile2p_slots(s.level) : 0;
+		const bool twin = !(mf && (flags & ACMHIP_PLAN_FORM_ONLY));
+		/* (room for this stream's records in one step - doubling, or every stream would move the whole table) */
+		auto room = [](std::vector<AcmTile2> &v, uint64_t more) {
+			if (v.capacity() < v.size() + more)
+				v.reserve(std::max<size_t>(2 * v.capacity(), v.size() + more));
+		};
+		if (twin)
+			room(plain, ntile);
+		if (pk)
+			room(tiles2p[s.level], ntile);
+		std::vector<AcmTile2> &mtab = tiles2m[s.level];
+		if (mf)
+			room(mtab, ntile * (T2 / T2M));
+		const uint32_t srows = s.rows;
+		for (uint64_t r = first; r < row0 + rows2; r += T2) {
 			const bool lead_in = r < row0;
-			const uint64_t rh = r >= 2 ? r - 2 : 0;         /* the row the row-value fetch counts from */
-			if (!(mf && (flags & ACMHIP_PLAN_FORM_ONLY)))
+			const uint32_t rh = (uint32_t)(r >= 2 ? r - 2 : 0);         /* the row the row-value fetch counts from */
+			if (twin)
 				plain.push_back(AcmTile2{ s.idx_off + (r << s.level), pcm_of(r),
-							  (uint32_t)(s.hdr_off + rh / s.rows), (uint32_t)(rh % s.rows), magic, flags_of(r, lead_in) });
+							  (uint32_t)(s.hdr_off + rh / srows), rh % srows, magic, flags_of(r, lead_in) });
 			if (pk)
-				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)acmk_tile2p_slots(s.level), s.pcm_off + (r << s.level),
-								     (uint32_t)(s.hdr_off + r / s.rows), (uint32_t)(r % s.rows), magic,
+				tiles2p[s.level].push_back(AcmTile2{ packed[i].chunk_off + r / T2 * (uint64_t)pk_slots, s.pcm_off + (r << s.level),
+								     (uint32_t)(s.hdr_off + (uint32_t)r / srows), (uint32_t)r % srows, magic,
 								     r == 0 ? ACM_TILE_FRESH : 0u });
 			/* a byte-plane tile is named by the pair-table entry of the row pair in front of it (entry 0 of a stream: the pair of zeros).
 			 * (chunks of one row - T2M == 1, the chunk kernel at levels 11 and 12 - also say whether they start a pair and whether they
 			 * are row 1; of a lead-in tile only the last chunks are needed, acmk_tile2m_lead_in of them) */
-			const uint64_t lead_rows = (uint64_t)T2M * (uint64_t)acmk_tile2m_lead_in(s.level);      /* (<= T2: two rows more at most) */
-			for (uint64_t rm = lead_in ? r + T2 - std::min<uint64_t>(T2, lead_rows) : r; mf && rm < r + T2; rm += T2M) {
-				const uint64_t rhm = rm >= 2 ? rm - 2 : 0;
-				tiles2m[s.level].push_back(AcmTile2{ packed[i].chunk_off + rm / 2, pcm_of(rm),
-								     (uint32_t)(s.hdr_off + rhm / s.rows), (uint32_t)(rhm % s.rows), magic,
-								     flags_of(rm, lead_in) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
+			if (!mf)
+				continue;
+			uint64_t rm = lead_in ? r + T2 - std::min<uint64_t>(T2, lead_rows) : r;
+			const uint32_t rhm0 = (uint32_t)(rm >= 2 ? rm - 2 : 0);
+			uint32_t blk = rhm0 / srows, pos = rhm0 % srows;        /* of row rm - 2, carried along from chunk to chunk */
+			for (; rm < r + T2; rm += T2M) {
+				mtab.push_back(AcmTile2{ packed[i].chunk_off + rm / 2, pcm_of(rm), (uint32_t)s.hdr_off + blk, pos, magic,
+							 flags_of(rm, lead_in) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
+				/* the next chunk's row rm + T2M - 2 (rows 0 and 1 of a stream both count from row 0) */
+				const uint32_t step = rm >= 2 ? T2M : rm + T2M >= 2 ? (uint32_t)(rm + T2M - 2) : 0u;
+				pos += step;
+				while (pos >= srows) {
+					pos -= srows;
+					blk++;
+				}
 			}
 		}
 		return ACMHIP_OK;

@@ -125,7 +125,9 @@ def test_batch_decode_stages_packed(dev, prestage):
     plain, tm0 = capi.batch_decode(dev, files, threads=4, prestage=prestage, byteplane=False)
     res, tm = capi.batch_decode(dev, files, threads=4, prestage=prestage, packed=True)
     assert tm0.packed_streams == 0 and tm.packed_streams >= 25, (tm0.packed_streams, tm.packed_streams)
-    assert tm.h2d_bytes < 0.8 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
+    # (pieces of one arena closer together than a transfer call is worth travel as one, the bytes between them included: with streams this
+    # small a good part of the int16 rows the packed form replaces travels anyway)
+    assert tm.h2d_bytes < 0.9 * tm0.h2d_bytes, (tm.h2d_bytes, tm0.h2d_bytes)
     for k, f in enumerate(files):
         o = O.Oracle(f)
         if o.err < 0:
