@@ -23,6 +23,15 @@ def test_host_parser_under_asan_ubsan(tmp_path):
         pytest.skip("sanitizer runtimes not installed")
     assert r.returncode == 0, r.stdout
     files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "acm", "f[1257]_*.acm")))[:40]
+    # ... and blocks tall and wide enough for the parser's padded scratch (rows x row bytes > 24 KB: acm_fill.cpp parse_block)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_stream
+    for k, (lv, rows, nb) in enumerate(((11, 16, 3), (12, 64, 2), (9, 70, 3), (13, 5, 2))):
+        path = str(tmp_path / ("tall_%d.acm" % k))
+        with open(path, "wb") as f:
+            f.write(make_stream(4100 + k, lv, rows, nb, channels=1 + k % 2, cut=k, pwr_max=12))
+        files.append(path)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, files[0], "60"] + files[1:], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        env=env, timeout=600)
