@@ -14,6 +14,7 @@ from . import _build
 
 FMT_S16LE, FMT_S16BE, FMT_U16LE, FMT_U16BE = 0, 1, 2, 3
 PLAN_AUTO, PLAN_STAGEWISE = 0, 1
+PLAN_FORM_ONLY, PLAN_UPLOAD_ASYNC = 0x100, 0x200          # modifiers, or-ed in (acm_hip.h)
 ERR_NO_DEVICE = -101
 ERR_RANGE = -105
 

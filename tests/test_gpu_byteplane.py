@@ -205,6 +205,44 @@ def test_byteplane_and_int16_launches_of_one_plan_agree(dev, force_k2):
         dev.free(p)
 
 
+def test_plan_modifiers_form_only_and_async_upload(dev, force_k2):
+    """ACMHIP_PLAN_FORM_ONLY: the int16 twin of the byte-plane records is not cut - a launch without the form bound fails loudly instead
+    of reading rows that may never have been staged; ACMHIP_PLAN_UPLOAD_ASYNC: the tables are only queued when the plan comes back,
+    its launches wait for them on the device.  Same PCM as the oracle either way (what acm_batch_decode's plans are made with)"""
+    files = [make_stream(26300 + i, 8 + i % 5, 16, 64 + 11 * i, cut=i, pwr_max=12) for i in range(8)]
+    staged = [capi.stage_file(f) for f in files]
+    ar = capi.Arena(staged)
+    mf = capi.mform_streams(ar.idx, ar.descs)
+    # only the rows the plan does not read from the form exist as int16 on the device: everything else is poison
+    probe = capi.Plan(dev, ar.descs, packed=mf.streams)
+    idx = np.full(ar.idx.size, 0x5A5A, dtype=np.int16)
+    for i, d in enumerate(ar.descs):
+        r2 = probe.form_rows(i)
+        keep = max(0, r2 - 2) << d.level
+        idx[d.idx_off + keep:d.idx_off + (d.nrows << d.level)] = ar.idx[d.idx_off + keep:d.idx_off + (d.nrows << d.level)]
+    probe.destroy()
+    d_idx, d_hdr, d_pcm = dev.malloc(ar.idx.nbytes), dev.malloc(ar.hdr.nbytes), dev.malloc(ar.pcm_words * 2)
+    d_mf = mf.upload(dev)
+    dev.upload(d_idx, idx)
+    dev.upload(d_hdr, ar.hdr)
+    for flags in (capi.PLAN_FORM_ONLY, capi.PLAN_UPLOAD_ASYNC, capi.PLAN_FORM_ONLY | capi.PLAN_UPLOAD_ASYNC):
+        plan = capi.Plan(dev, ar.descs, flags=flags, packed=mf.streams)
+        assert plan.stats().mform_tiles > 0
+        if flags & capi.PLAN_FORM_ONLY:
+            with pytest.raises(capi.AcmHipError):
+                plan.launch(d_idx, d_hdr, d_pcm)            # no form bound, no twin to fall back to
+        plan.bind_mform(*d_mf)
+        dev.upload(d_pcm, np.full(ar.pcm_words, 0xA5A5, dtype=np.uint16))
+        plan.launch(d_idx, d_hdr, d_pcm)
+        out = np.zeros(ar.pcm_words, dtype=np.uint16)
+        dev.download(out, d_pcm)
+        for f, (_, _, po, _, ne) in zip(files, ar.layout):
+            assert np.array_equal(out[po:po + ne], oracle_pcm(f)[0]), flags
+        plan.destroy()
+    for p in (d_idx, d_hdr, d_pcm) + d_mf:
+        dev.free(p)
+
+
 def test_plan_rejects_a_byteplane_form_that_is_too_short(dev, force_k2):
     """a stream that comes with fewer byte-plane tiles than the plan would decode from them, or with an unknown form, is an argument
     error at plan creation - not a launch that reads past its pair table"""
