@@ -854,6 +854,10 @@ def main():
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
                      "kernel": (("acm_chunk<%s>: six stages on v_mfma_i32_16x16x64_i8, one wavefront per 2048-sample chunk, one LDS pass group behind "
                                  "(+ acm_fused_tile on ragged tails)" % lv_txt)
+                                if mf and args.workload == "uniform" and capi.lib().acmhip_mform_group(args.level) == 64 and args.level <= 12 else
+                                ("acm_tile2<TileCfg<%s,%d,%d>, first six stages on v_mfma_i32_16x16x64_i8 (a row pair per tile, sixteen residue classes per "
+                                 "wavefront), LDS passes with barriers behind> (+ the prefix + plane pair on ragged tails)" % (
+                                     (lv_txt,) + {13: (512, 16384), 14: (1024, 32768)}[args.level]))
                                 if mf and args.workload == "uniform" and capi.lib().acmhip_mform_group(args.level) == 64 else
                                 "acm_tile2%s<TileCfg<%s,%d,%d>%s> (+ acm_fused_tile on ragged tails)" % (
                                     ("p" if pk else "", lv_txt) + K2_GEOMETRY.get(args.level, (256, 8192)) +

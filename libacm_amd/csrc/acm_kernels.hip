@@ -1301,6 +1301,7 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	{
 		load(raw, sgpr_u64(reinterpret_cast<uint64_t>(idx) + 2 * (r.idx_off - 2 * (uint64_t)COLS)), voff, voff_warm);
 	}
+	static constexpr bool KEEPS_HISTORY = false;
 	static constexpr bool SIGNED_ROWVAL = true;              /* odd tile rows carry -val when stage 0 is an N stage; rows in front of a stream weigh 0 */
 	static __device__ __forceinline__ bool fresh_lane(const int tid) { return tid < FP::TPS; }      /* lanes whose two rows in front are missing in a stream's first tile */
 	static __device__ __forceinline__ void fill_tables(Tables &, const int) { }
@@ -1368,6 +1369,7 @@ struct FirstPassM {
 	static constexpr int ROWB_W = COLS * 2;                 /* staged bytes per row at 16 bits per index (class 3); class c: >> (3 - c) */
 	static constexpr int RESB_W = 2 * QN;                   /* ... per row and residue */
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
+	static constexpr bool KEEPS_HISTORY = false;
 	static constexpr bool SIGNED_ROWVAL = false;            /* rowval = val << SHIFT for every row; rows in front of a stream repeat row 0's */
 	using T = MfmaTables<G>;
 	typedef std::conditional_t<G == 3, uint64_t, v4i_t> Operand;
@@ -1745,6 +1747,221 @@ struct FirstPassM {
 	}
 };
 
+#include "acm_toeplitz_tables.inc"
+
+/*
+ * The same six-stage first pass for rows that no longer fit a wavefront (levels 13 and 14: 128 / 256 residue classes per row), as a first
+ * pass of acm_tile2: the tile is ONE ROW PAIR in the workgroup's LDS (level 13: 512 threads, two workgroups per CU; level 14: 1024), each
+ * wavefront takes sixteen classes - one matrix "set" per row - of both rows, and keeps the two rows in front of them in its registers
+ * from the tile before (the same wavefront had the same classes there).  Behind it acm_tile2's LDS passes with their barriers, two
+ * (level 13) or three (level 14) of them instead of the three / four behind the four-stage FirstPassM.
+ */
+template <class C_>
+struct FirstPassZW {
+	using C = C_;
+	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS, TR = C::TR, PS = C::PS;
+	static constexpr int G = 6, QN = 1 << G, SIGMA = COLS / QN, NWAVE = NT / 64;
+	static constexpr int NGW = SIGMA / 16 / NWAVE;          /* groups of sixteen classes per wavefront */
+	static constexpr int NSW = TR, NX = TR + 2, NM = QN / 16, NE = NX / 2;
+	static_assert(TR == 2 && NGW >= 1 && NGW * 16 * NWAVE == SIGMA && SIGMA >= 32, "a row pair per tile, whole groups per wavefront");
+	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;
+	static constexpr bool SIGNED_ROWVAL = false, KEEPS_HISTORY = true;
+	static constexpr uint32_t CB = 16;
+	static __device__ __forceinline__ uint32_t group_at(const uint32_t g) { return 8u * (g & 1u) + 32u * (g >> 1); }
+	static __device__ __forceinline__ uint32_t class_of(const uint32_t i) { return (i & 3u) + CB * ((i >> 2) & 1u) + 4u * (i >> 3); }
+
+	struct Raw { v4u_t lo[NGW][NX], hi[NGW][NX]; };
+	struct Desc { uint32_t e[NE]; };
+	struct Tables {
+		v4i_t coef[3][NM][64];
+		int32_t bias[3][QN];            /* [rows in front that exist: 0, 1, 2 and more][q], scaled; for the lane that owns residue 0 */
+	};
+	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid)
+	{
+		constexpr int32_t ONE = 1 << OutScale<L>::SHIFT;
+		for (int k = tid; k < 3 * NM * 64; k += NT) {
+			const int j = k / (NM * 64), mt = (k / 64) % NM, lane = k % 64;
+			t.coef[j][mt][lane] = *reinterpret_cast<const v4i_t *>(&ACM_TZ6[VARIANT][j][16 * mt + (lane & 15)][16 * (lane >> 4)]);
+		}
+		for (int k = tid; k < 3 * QN; k += NT)
+			t.bias[k / QN][k % QN] = ACM_TZ6_BIAS[VARIANT][k / QN][k % QN] * ONE;
+	}
+	static __device__ __forceinline__ uint32_t lane_offset(const int) { return 0u; }
+	static __device__ __forceinline__ bool fresh_lane(const int) { return false; }
+	static __device__ __forceinline__ Desc fetch_desc(const uint32_t *__restrict__ pairs, const AcmTile2 &r, const int)
+	{
+		Desc d;
+		const uint32_t at = __builtin_amdgcn_readfirstlane((uint32_t)r.idx_off);
+#pragma unroll
+		for (int j = 0; j < NE; j++)
+			d.e[j] = pairs[at + j];
+		return d;
+	}
+	static __device__ __forceinline__ int32_t opaque_s(int32_t v)
+	{
+		asm("" : "+s"(v));
+		return v;
+	}
+	static __device__ __forceinline__ int32_t opaque_v(int32_t v)
+	{
+		asm("" : "+v"(v));
+		return v;
+	}
+	/* rows k = 0, 1: the pair in front (d.e[0]); 2, 3: the tile's own (d.e[1]) */
+	template <bool KEEP>
+	static __device__ __forceinline__ void issue_rows(Raw &raw, const uint8_t *arena, const Desc &d, const int tid)
+	{
+		const uint32_t lane = (uint32_t)tid & 63u, i = lane & 15u, ks = lane >> 4;
+		const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (uint32_t)NGW;
+		const uint32_t c = class_of(i);
+		const uint32_t e0 = d.e[0];
+		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
+#pragma unroll
+		for (int k = KEEP ? 2 : 0; k < NX; k++) {
+			const uint32_t e = (uint32_t)opaque_s((int32_t)d.e[k >> 1]);
+			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
+			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((k & 1) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
+#pragma unroll
+			for (int g = 0; g < NGW; g++) {
+				const uint32_t v = row_at + (((group_at(g0 + (uint32_t)g) + c) * (uint32_t)QN) << sh);
+				asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[g][k]) : "v"(v), "s"(base) : "memory");
+				asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(raw.hi[g][k]) : "v"(v), "s"(base) : "memory");
+			}
+		}
+	}
+	/* the first tile of a run: every row, the two in front included (a stream's first tile finds the stager's pair of zeros there) */
+	static __device__ __forceinline__ void issue_all(Raw &raw, const int16_t *idx, const Desc &d, const int tid)
+	{
+		issue_rows<false>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid);
+	}
+	/* every other tile (called behind run() of the tile before): that tile's own rows are this one's rows in front - unless this one
+	 * starts a stream (zeros).  (A window's lead-in record - not the successor of the tile before - finds another stream's rows there:
+	 * its output is dropped, and the planner puts a second lead-in tile behind it: acmk_tile2m_lead_in) */
+	static __device__ __forceinline__ void issue(Raw &raw, const int16_t *idx, const AcmTile2 &r, const Desc &d, const int tid, const uint32_t, const uint32_t)
+	{
+		const v4u_t z = { 0, 0, 0, 0 };
+		const bool fresh = (r.flags & ACM_TILE_FRESH) != 0;
+#pragma unroll
+		for (int g = 0; g < NGW; g++)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				raw.lo[g][k] = fresh ? z : raw.lo[g][k + NSW];
+				raw.hi[g][k] = fresh ? z : raw.hi[g][k + NSW];
+			}
+		issue_rows<true>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid);
+	}
+	static __device__ __forceinline__ v4i_t mfma(const v4u_t data, const v4i_t coef, const v4i_t acc)
+	{
+		return __builtin_amdgcn_mfma_i32_16x16x64_i8((v4i_t)data, coef, acc, 0, 0, 0);
+	}
+
+	/* rowval[k] = val << SHIFT of tile row k - 2 (FirstPassZ::run_t, further down, has the algebra: one accumulator chain per output row, the block
+	 * boundaries as multiply-adds of its partial sums) */
+	template <bool WORDS>
+	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const int32_t *rowval, const bool fresh, const int tid, const Tables &t)
+	{
+		const v4i_t zero = { 0, 0, 0, 0 };
+		const uint32_t lane = (uint32_t)tid & 63u, h = lane >> 4, qd = lane & 15u;
+		const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (uint32_t)NGW;
+		int32_t rv[NX];
+#pragma unroll
+		for (int k = 0; k < NX; k++)
+			rv[k] = __builtin_amdgcn_readfirstlane(rowval[k]);
+		int32_t val[NSW], dv2[NSW], dv1[NSW];
+		bool step2[NSW], step1[NSW];
+#pragma unroll
+		for (int s = 0; s < NSW; s++) {
+			val[s] = rv[s + 2];
+			dv2[s] = rv[s + 1] - rv[s + 2];
+			dv1[s] = rv[s] - rv[s + 1];
+			step2[s] = dv2[s] != 0;
+			step1[s] = dv1[s] != 0;
+		}
+		const v4i_t *cf = &t.coef[0][0][lane];
+#pragma unroll 1
+		for (int mt = 0; mt < NM; mt++) {
+			const v4i_t cf0 = cf[0], cf1 = cf[NM * 64], cf2 = cf[2 * NM * 64];
+#pragma unroll
+			for (int g = 0; g < NGW; g++) {
+				const uint32_t c0 = group_at(g0 + (uint32_t)g) + class_of(4u * h);     /* the lane's four outputs: classes c0 .. c0 + 3 */
+#pragma unroll
+				for (int s = 0; s < NSW; s++) {
+					const uint32_t var = fresh ? (uint32_t)s : 2u;          /* rows of the stream in front of this one: 0, 1, two or more */
+					const int32_t b = c0 == 0 ? (&t.bias[0][0])[var * QN + qd + 16u * (uint32_t)mt] : 0;
+					const v4i_t l1 = mfma(raw.lo[g][s], cf2, zero);
+					const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
+					const v4i_t la = mfma(raw.lo[g][s + 2], cf0, l2);
+					v4i_t y;
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						y[v] = __mul24(la[v], val[s]) + (v == 0 ? b : 0);
+					if (step2[s]) {
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] += __mul24(l2[v], dv2[s]);
+					}
+					if (step1[s]) {
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] += __mul24(l1[v], dv1[s]);
+					}
+					if constexpr (WORDS) {
+						const v4i_t h1 = mfma(raw.hi[g][s], cf2, zero);
+						const v4i_t h2 = mfma(raw.hi[g][s + 1], cf1, h1);
+						const v4i_t ha = mfma(raw.hi[g][s + 2], cf0, h2);
+						/* (opaque copies: FirstPassZ::run_t says why) */
+						const int32_t wv = opaque_v(val[s]), w2 = opaque_v(dv2[s]), w1 = opaque_v(dv1[s]);
+						v4i_t yh;
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							yh[v] = __mul24(ha[v], wv);
+						if (step2[s]) {
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								yh[v] += __mul24(h2[v], w2);
+						}
+						if (step1[s]) {
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								yh[v] += __mul24(h1[v], w1);
+						}
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << 8) + (uint32_t)y[v]);
+					}
+					const uint32_t m = (uint32_t)(s * COLS) + c0 + (uint32_t)SIGMA * (qd + 16u * (uint32_t)mt);
+					uint32_t *const o = tile + (m + (m >> PS));
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						o[v] = (uint32_t)y[v];
+				}
+			}
+			cf += 64;
+		}
+	}
+	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const int32_t *rowval, const bool fresh, const int tid, const Tables &t, const Desc &d)
+	{
+		uint32_t any_word = 0;
+#pragma unroll
+		for (int j = 0; j < NE; j++)
+			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
+		if (any_word) {
+			/* a pair at 8 bits has no high bytes: what was loaded in their place is its neighbour's low ones (in place: the rows that stay in
+			 * their registers for the next tile stay what they are) */
+#pragma unroll
+			for (int k = 0; k < NX; k++) {
+				const uint32_t mask = ((uint32_t)opaque_s((int32_t)d.e[k >> 1]) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+				for (int g = 0; g < NGW; g++)
+					raw.hi[g][k] &= mask;
+			}
+			run_t<true>(raw, tile, rowval, fresh, tid, t);
+		} else {
+			run_t<false>(raw, tile, rowval, fresh, tid, t);
+		}
+	}
+};
+
 /*
  * Vector memory in acm_tile2 is issued and waited for by hand.  Left to the compiler, the first use of a prefetched
  * index waits with vmcnt(0) - for the PCM stores of the previous tile as well (it cannot prove how many stores are
@@ -1777,8 +1994,8 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	  const acmhip_blkhdr *__restrict__ hdr, int16_t *__restrict__ pcm, int16_t *__restrict__ sink, const unsigned fmt)
 {
 	constexpr int L = C::L, NT = C::NT, COLS = C::COLS, NELEM = C::NELEM, TR = C::TR, NJ_LAST = C::NJ_LAST;
-	using FP = std::conditional_t<MFORM, FirstPassM<C, (MFORM ? G0 : 3)>, FirstPass2<C, G0, 2, ABL>>;
-	static_assert(!MFORM || G0 == 3 || G0 == 4, "coefficient tables exist for a first pass of three or four stages");
+	using FP = std::conditional_t<MFORM, std::conditional_t<G0 == 6, FirstPassZW<C>, FirstPassM<C, (G0 == 4 ? 4 : 3)>>, FirstPass2<C, G0, 2, ABL>>;
+	static_assert(!MFORM || G0 == 3 || G0 == 4 || G0 == 6, "coefficient tables exist for a first pass of three, four or six stages");
 	constexpr bool NEG_ODD_ROWS = FP::SIGNED_ROWVAL && StageKind<L, 0>::N;
 	static_assert(TR + 2 <= NT, "one row value per thread");
 	constexpr bool PRIO = WPS * 256 / NT > 1;               /* several workgroups per CU: see phase_prio */
@@ -1850,7 +2067,10 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	typename FP::Desc dcur = FP::fetch_desc(pairs, cur, tid);        /* byte-plane form: where the tile's row pairs are and how wide */
 	typename FP::Raw raw;
 	uint32_t hv = fetch_val(cur);
-	load_tile(raw, cur, dcur);
+	if constexpr (FP::KEEPS_HISTORY)
+		FP::issue_all(raw, idx, dcur, tid);     /* (the rows in front of a tile are the registers of the tile before: not at a run's start) */
+	else
+		load_tile(raw, cur, dcur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
 	int buf = 0;
 	bool fresh = true;              /* the first tile of a run starts from zero carries (stream start or lead-in) */
@@ -1957,7 +2177,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
  * its walk, like FirstPassM); the last pass takes its 16-element history from the previous chunk through a carry buffer of the
  * wavefront's own, as every LDS pass of acm_tile2 does.
  */
-#include "acm_toeplitz_tables.inc"
+/* (acm_toeplitz_tables.inc - ACM_TZ6, ACM_TZ6_BIAS - is included in front of acm_tile2, whose level-13 / 14 first pass reads it too) */
 
 template <int L_>
 struct FirstPassZ {
@@ -2574,6 +2794,13 @@ const Tile2MEntry g_tile2m[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1][2] = {
 constexpr int g_tile2m_default[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = { 3, 3, 3, 4, 4, 4, 4, 4 };
 /* levels whose byte-plane tiles go to the chunk kernel (acm_chunk: six stages on the matrix cores, a wavefront per chunk of 2048 samples)
  * unless ACM_K3=0 asks for acm_tile2's matrix build; the staged form follows the choice (64 columns of a residue class side by side) */
+/* ... and the six-stage first pass inside acm_tile2 (FirstPassZW): a row pair per tile, LDS passes with barriers behind it */
+#ifndef ACM_K3_L13
+#define ACM_K3_L13 entry_k2mw<TileCfg<13, 512, 16384>, 2, 6, 4, 3>(), 6
+#endif
+#ifndef ACM_K3_L14
+#define ACM_K3_L14 entry_k2mw<TileCfg<14, 1024, 32768>, 1, 6, 3, 3, 2>(), 6
+#endif
 template <int L, int... Gs>
 constexpr Tile2MEntry entry_k3()
 {
@@ -2589,11 +2816,12 @@ const Tile2MEntry g_chunk[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
 	entry_k3<10, 2, 2>(),
 	entry_k3<11, 3, 2>(),
 	entry_k3<12, 3, 3>(),
-	/* (level 13: a row of 8192 per wavefront is four wavefronts of 350 registers - the staged rows of a chunk alone are 192 - and past 256
-	 * the compiler parks what the hand-issued loads have just asked for in accumulation registers BEFORE the wait, i.e. copies what
-	 * is not there yet: tests/test_isa_invariants.py refuses the build.  Level 13 stays with acm_tile2's matrix build.) */
-	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
-	{ Tile2Entry{ nullptr, 0, 0, 0 }, 0 },
+	/* (level 13 as a chunk kernel: a row of 8192 per wavefront is four wavefronts of 350 registers - the staged rows of a chunk alone are
+	 * 192 - and past 256 the compiler parks what the hand-issued loads have just asked for in accumulation registers BEFORE the wait,
+	 * i.e. copies what is not there yet: tests/test_isa_invariants.py refuses the build.)  Levels 13 and 14: the same first pass shared
+	 * by the wavefronts of a workgroup, in acm_tile2 */
+	{ ACM_K3_L13 },
+	{ ACM_K3_L14 },
 };
 inline const Tile2MEntry &tile2m_entry(uint32_t level)
 {
@@ -3131,6 +3359,7 @@ extern "C" int acmk_tile2m_lead_in(uint32_t level)
 	case 10: return FirstPassZ<10>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<10>::NSW - 1) / FirstPassZ<10>::NSW : 1;
 	case 11: return FirstPassZ<11>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<11>::NSW - 1) / FirstPassZ<11>::NSW : 1;
 	case 12: return FirstPassZ<12>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<12>::NSW - 1) / FirstPassZ<12>::NSW : 1;
+	case 13: case 14: return 2;             /* FirstPassZW: a row pair per tile, the pair in front of it in registers */
 	default: return 1;
 	}
 }
@@ -3138,7 +3367,7 @@ extern "C" int acmk_tile2m_lead_in(uint32_t level)
 /* wavefronts that share a launch of the chunk kernel's table among them (each takes one contiguous run of it); 0: not the chunk kernel */
 extern "C" int acmk_tile2m_run_waves(uint32_t level, int cus)
 {
-	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL || tile2m_entry(level).g0 != 6)
+	if (level < ACM_K2M_MIN_LEVEL || level > 12 || tile2m_entry(level).g0 != 6)
 		return 0;
 	const Tile2Entry &e = tile2m_entry(level).e;
 	return (cus > 0 ? cus : 256) * e.wg_per_cu * (e.threads / 64);

@@ -30,7 +30,7 @@ int acmhip_plan_launch(acmhip_plan *, const int16_t *, const acmhip_blkhdr *, in
 /* tile geometries the stagers ask the kernels' translation unit for (acm_kernels.hip is not in this build): the shipped ones */
 int acmk_tile2_rows(uint32_t level) { return level >= 6 && level <= 11 ? 8192 >> level : level == 12 || level == 13 ? 4 : level == 14 ? 2 : 0; }
 int acmk_tile2m_rows(uint32_t level) { return level == 7 ? 64 : level >= 8 && level <= 11 ? 2048 >> level : level == 12 ? 1 : level == 13 || level == 14 ? 2 : 0; }
-int acmk_tile2m_stages(uint32_t level) { return level == 7 ? 3 : level >= 8 && level <= 12 ? 6 : level == 13 || level == 14 ? 4 : 0; }
+int acmk_tile2m_stages(uint32_t level) { return level == 7 ? 3 : level >= 8 && level <= 14 ? 6 : 0; }
 int acmk_tile2m_lead_in(uint32_t) { return 1; }
 int acmk_tile2p_rows(uint32_t level) { return level >= 6 && level <= 9 ? 8192 >> level : 0; }
 int acmk_tile2p_group_rows(uint32_t level) { return level == 6 ? 32 : 16; }

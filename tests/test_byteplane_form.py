@@ -24,8 +24,9 @@ def test_levels_with_a_byteplane_form():
         if level in LEVELS:
             qn = L.acmhip_mform_group(level)
             assert qn in (8, 16, 64)
-            # a level of the chunk kernel (64 columns of a residue class side by side) is cut into chunks of 2048 samples
-            assert tr == (max(1, 2048 >> level) if qn == 64 else {12: 4, 13: 2, 14: 2}.get(level, 8192 >> level))
+            # a level of the chunk kernel (64 columns of a residue class side by side) is cut into chunks of 2048 samples; levels 13 and 14
+            # (the same first pass inside acm_tile2) into row pairs
+            assert tr == ((2 if level >= 13 else max(1, 2048 >> level)) if qn == 64 else {12: 4, 13: 2, 14: 2}.get(level, 8192 >> level))
             assert L.acmhip_mform_bytes(level, 10) == 10 * (2 << level) + (2 << level) + 64
         else:
             assert tr == 0 and L.acmhip_mform_group(level) == 0
@@ -118,8 +119,8 @@ def test_split_form_range():
 def test_width_classes_follow_the_blocks():
     """quiet blocks (pwr <= 3: indices in [-8, 7]) travel at 4 bits, pwr <= 7 at 8 bits: the stager's classes are what the block
     headers promise or narrower"""
-    level, rows = 13, 16            # (a level of acm_tile2's matrix build: the chunk kernel's form has no 4-bit class)
-    s = capi.stage_file(make_stream(44000, level, rows, 6, pwr_min=0, pwr_max=12))
+    level, rows = 7, 16             # (the level of acm_tile2's three-stage matrix build: the six-stage form has no 4-bit class)
+    s = capi.stage_file(make_stream(44000, level, rows, 16, pwr_min=0, pwr_max=12))
     cols = 1 << level
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
                         nrows=s.info.blocks * rows, row_begin=0)
@@ -310,7 +311,7 @@ def test_stager_rejects_what_the_kernel_could_not_read():
     """odd row counts (a unit is a row pair), a block that would not start on 16 bytes, offsets beyond the pair table's 30 bits, levels
     without the form; the inverse refuses a table with an unknown width class or a non-zero pair in front"""
     L = capi.lib()
-    level, cols = 13, 8192
+    level, cols = 7, 128             # (the form with a 4-bit class)
     idx = np.zeros(4 * cols, dtype=np.int16)
     out = np.zeros(L.acmhip_mform_bytes(level, 4), dtype=np.uint8)
     pairs = np.zeros(8, dtype=np.uint32)

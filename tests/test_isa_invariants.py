@@ -130,7 +130,8 @@ def test_no_read_of_a_loading_register_before_the_wait(kernel_asm):
                     work.append(t)
         # prologue + in-loop sets of staged-index loads (the matrix-core builds: 8 + the row values; the chunk kernel asks for as few as four
         # in its loop where the rows in front of a walk stay in registers)
-        assert n_loads >= (12 if "acm_chunk" in name else 2 * 9), (name, n_loads)
+        # (and the six-stage first pass inside acm_tile2 - levels 13, 14 -: eight loads for the four rows of a run's first tile, four per tile after it)
+        assert n_loads >= (12 if "acm_chunk" in name or "Lb1ELi6E" in name else 2 * 9), (name, n_loads)
     assert n_kernels >= 26                                 # nine levels of acm_tile2, its matrix build at eight (one depth each), five levels of the chunk kernel, four of acm_tile2p
 
 
