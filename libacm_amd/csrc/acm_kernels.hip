@@ -2267,10 +2267,45 @@ struct FirstPassZ {
 	/* KEEP (one walker only: the rows in front of a lane's walk are rows the SAME lane loaded for the chunk in front): only the walk's own
 	 * rows are asked for, the two rows in front stay in their registers (shift_history) - a third (level 11) or half of the requests */
 	static constexpr bool HISTORY_IN_REGISTERS = RR == 1;
+	/* two walkers of two rows each (level 9): the rows in front of walker 1 are walker 0's own rows of the same chunk, the rows in front of
+	 * walker 0 are walker 1's own rows of the chunk before - both sit eight lanes away in the same row of sixteen, one v_mov_b32_dpp per
+	 * register instead of a second request for bytes the partner lane has just loaded (half the load instructions of a chunk) */
+#ifndef ACM_K3_DPP_HISTORY
+#define ACM_K3_DPP_HISTORY 1
+#endif
+	static constexpr bool HISTORY_BY_DPP = ACM_K3_DPP_HISTORY && RR == 2 && NSW == 2 && SIGMA == 8;
+	static constexpr bool KEEPS_ROWS = HISTORY_IN_REGISTERS || HISTORY_BY_DPP;
+	template <int CTRL, int BANKS>
+	static __device__ __forceinline__ v4u_t dpp4(const v4u_t old, const v4u_t src)
+	{
+		v4u_t r;
+#pragma unroll
+		for (int v = 0; v < 4; v++)
+			r[v] = (uint32_t)__builtin_amdgcn_update_dpp((int)old[v], (int)src[v], CTRL, 0xF, BANKS, false);
+		return r;
+	}
+	/* behind run(): the lanes of walker 0 (instances 0-7) take walker 1's own rows - the chunk's last two - as the rows in front of the next chunk */
+	static __device__ __forceinline__ void hand_history_on(Raw &raw)
+	{
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			raw.lo[0][k] = dpp4<0x108, 0x3>(raw.lo[0][k], raw.lo[0][k + NSW]);      /* row_shl:8 into lanes 0-7 of every row of sixteen */
+			raw.hi[0][k] = dpp4<0x108, 0x3>(raw.hi[0][k], raw.hi[0][k + NSW]);
+		}
+	}
+	/* in front of run(): the lanes of walker 1 take walker 0's own rows of this chunk */
+	static __device__ __forceinline__ void take_history_from_partner(Raw &raw)
+	{
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			raw.lo[0][k] = dpp4<0x118, 0xC>(raw.lo[0][k], raw.lo[0][k + NSW]);      /* row_shr:8 into lanes 8-15 */
+			raw.hi[0][k] = dpp4<0x118, 0xC>(raw.hi[0][k], raw.hi[0][k + NSW]);
+		}
+	}
 	template <bool KEEP>
 	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd)
 	{
-		static_assert(!KEEP || HISTORY_IN_REGISTERS, "the rows in front belong to another lane");
+		static_assert(!KEEP || KEEPS_ROWS, "the rows in front belong to another lane");
 		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4;
 		const uint32_t c = class_of(i), rr = RR == 1 ? 0u : i / SIGMA;
 		const uint32_t e0 = d.e[0];
@@ -2517,6 +2552,8 @@ struct FirstPassZ {
 #else
 		const int lane = lane_;
 #endif
+		if constexpr (HISTORY_BY_DPP)
+			take_history_from_partner(raw);         /* (a run's first chunk has loaded these rows itself: the same bytes again) */
 		uint32_t any_word = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++)
@@ -2646,6 +2683,13 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 			 * its own stream's rows in front of it, acmk_tile2m_lead_in.  A second load sequence for that case, in a branch, makes the
 			 * compiler join the two with copies of registers whose loads are still in flight: tests/test_isa_invariants.py) */
 			FP::shift_history(raw);
+			if (nxt.flags & ACM_TILE_FRESH)
+				FP::zero_history(raw);
+			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+		} else if constexpr (FP::HISTORY_BY_DPP) {
+			/* (the same with two walkers: walker 0's rows in front come from walker 1's lanes now, walker 1's from walker 0's in front of
+			 * the next first pass - FirstPassZ::run.  A window's first lead-in chunk: as above) */
+			FP::hand_history_on(raw);
 			if (nxt.flags & ACM_TILE_FRESH)
 				FP::zero_history(raw);
 			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
@@ -3356,6 +3400,7 @@ extern "C" int acmk_tile2m_lead_in(uint32_t level)
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL || tile2m_entry(level).g0 != 6)
 		return 1;
 	switch (level) {
+	case 9: return FirstPassZ<9>::KEEPS_ROWS ? 1 + (2 + FirstPassZ<9>::NSW - 1) / FirstPassZ<9>::NSW : 1;
 	case 10: return FirstPassZ<10>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<10>::NSW - 1) / FirstPassZ<10>::NSW : 1;
 	case 11: return FirstPassZ<11>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<11>::NSW - 1) / FirstPassZ<11>::NSW : 1;
 	case 12: return FirstPassZ<12>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<12>::NSW - 1) / FirstPassZ<12>::NSW : 1;
