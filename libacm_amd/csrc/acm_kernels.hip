@@ -2497,6 +2497,23 @@ struct FirstPassZ {
 					const v4i_t h1 = mfma(hi[g][s], cf2, zero);
 					const v4i_t h2 = mfma(hi[g][s + 1], cf1, h1);
 					const v4i_t ha = mfma(hi[g][s + 2], cf0, h2);
+					/* With val itself below 2^16 (levels 8 and 9: no scaling) and no change of val in reach, the high plane joins in ONE
+					 * instruction per output: y += ha * (val << 8) as v_mad_u32_u24.  Its operands are the low 24 bits of each register
+					 * taken as unsigned: val << 8 is below 2^24, and a negative ha reads as ha + 2^24, which adds 2^24 * 256 * val = 0
+					 * (mod 2^32).  (val << 8 through an opaque copy: or the optimiser folds both planes into one 32-bit multiply) */
+					if constexpr (OutScale<L>::SHIFT == 0) {
+						if (!step2[s] && !step1[s]) {
+							uint32_t v8[NH];
+#pragma unroll
+							for (int hf = 0; hf < NH; hf++)
+								v8[hf] = (uint32_t)opaque_v((int32_t)((uint32_t)val[s][hf] << 8));
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								y[v] = (int32_t)(__umul24((uint32_t)ha[v], v8[v / NVH]) + (uint32_t)y[v]);
+							goto joined;
+						}
+					}
+					{
 					/* (opaque copies of the multipliers: or the optimiser adds the planes first and multiplies a sum beyond 24 bits at
 					 * a quarter of the rate; an opaque sum: or it moves the shift into the multipliers) */
 					v4i_t yh;
@@ -2523,6 +2540,8 @@ struct FirstPassZ {
 #pragma unroll
 					for (int v = 0; v < 4; v++)
 						y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << 8) + (uint32_t)y[v]);
+					}
+				joined:;
 				}
 				/* the constant parts of the address: multiples of 32, or (16 g) small enough to stay inside the lane's group of 32 - the pad rule splits */
 				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0 &&
