@@ -4,7 +4,7 @@
 # Tags without a suffix are bench.py's default staged form for their level (the byte-plane form: acm_chunk at levels 9-12).
 set -e
 cd "$(dirname "$0")/.."
-for t in r5_level9 r5_level9_int16 r5_level7 r5_level10 r5_level11 r5_level12 r5_config5; do
+for t in r5_level9 r5_level9_int16 r5_level7 r5_level10 r5_level11 r5_level12 r5_level13 r5_level14 r5_config5; do
   src=gpurun_out/prof_$t
   [ -d $src ] || continue
   python3 profiles/summarize.py $src > profiles/${t}_summary.txt
@@ -15,4 +15,5 @@ done
 python3 profiles/traffic_json.py level9_1024x250blocks_rows16_byteplane=profiles/r5_level9_summary.txt level9_1024x250blocks_rows16=profiles/r5_level9_int16_summary.txt \
   level7_1024x1000blocks_rows16_byteplane=profiles/r5_level7_summary.txt level10_1024x125blocks_rows16_byteplane=profiles/r5_level10_summary.txt \
   level11_1024x16blocks_rows64_byteplane=profiles/r5_level11_summary.txt level12_1024x8blocks_rows64_byteplane=profiles/r5_level12_summary.txt \
+  level13_1024x4blocks_rows64_byteplane=profiles/r5_level13_summary.txt level14_1024x16blocks_rows8_byteplane=profiles/r5_level14_summary.txt \
   level11_65536x2blocks_rows64_ch2_byteplane=profiles/r5_config5_summary.txt
