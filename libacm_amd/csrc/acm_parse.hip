@@ -424,6 +424,7 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 		bit = prev.end_bit;
 		mf_at = prev.mf_at;
 	}
+	const uint32_t mf_at_lo = mf_at;                /* where this range's first block would be staged */
 	ww.load(bit >> 5);
 	uint32_t done = b_lo, status = 1;
 	uint32_t *cp = colpos + job.col_off + (uint64_t)b_lo * cols;
@@ -475,7 +476,11 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	}
 	status = 0;
 out:
-	if (status != 0 || range == 0)
+	/* (a walk that stops inside its range: the column kernel skips the stream altogether - status != 0 -, the blocks of this range the walk
+	 * did get through included; none of the range's entries is written by anybody else) */
+	if (status != 0)
+		park_entries(b_lo, mf_at_lo);
+	else if (range == 0)
 		park_entries(done, mf_at);
 	if (lane == 0)
 		res[jobno] = AcmParseResult{ done, status, bit, mf_at };

@@ -19,6 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
 bad = streams = flagged = 0
 with capi.Device(0) as dev:
     for b in range(batches):
+        if os.environ.get("ACM_FUZZ_TRACE"):
+            print("batch", b, flush=True)
         files = []
         for _ in range(int(rng.integers(1, 40))):
             kind = rng.random()

@@ -22,6 +22,8 @@ bad = streams = packed_tiles = packed_streams = 0
 os.environ["ACM_K2"] = "1"
 with capi.Device(0) as dev:
     for b in range(batches):
+        if os.environ.get("ACM_FUZZ_TRACE"):
+            print("batch", b, flush=True)
         files = []
         for _ in range(int(rng.integers(1, 30))):
             kind = rng.random()
@@ -39,17 +41,32 @@ with capi.Device(0) as dev:
                 kw.update(mix=2, single_code=int(rng.choice([0, 3, 8, 16, 17, 19, 22, 26, 29])))
                 if 3 <= kw["single_code"] <= 16:
                     kw.update(pwr_min=15, pwr_max=15)
-            f = make_stream(int(rng.integers(1, 1 << 30)), lv, rows, nb, **kw)
+            fseed = int(rng.integers(1, 1 << 30))
+            f = make_stream(fseed, lv, rows, nb, **kw)
+            if os.environ.get("ACM_FUZZ_ONLY") == str(b):
+                print("  gen %d: make_stream(%d, %d, %d, %d, **%r) kind %.3f" % (len(files), fseed, lv, rows, nb, kw, kind), flush=True)
             if 0.12 <= kind < 0.2:
                 f = f[:int(rng.integers(15, len(f) + 1))]
             elif 0.2 <= kind < 0.22:
                 f = bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8))
             files.append(f)
         good = [f for f in files if O.Oracle(f).err >= 0]
+        # ACM_FUZZ_ONLY=b [ACM_FUZZ_PART=a|b] [ACM_FUZZ_KEEP=i,j,...]: replay one batch (one half of it, some of its files): the generator runs as ever
+        only = os.environ.get("ACM_FUZZ_ONLY")
+        skip = only is not None and int(only) != b
+        part = os.environ.get("ACM_FUZZ_PART", "ab") if not skip else ""
+        if not skip and only is not None:
+            for k, f in enumerate(files):
+                rc, inf = capi.probe(capi._as_u8(f), 0)
+                print("  file %d: %d bytes, probe %d, level %d rows %d channels %d values %d" % (k, len(f), rc, inf.level, inf.rows, inf.channels, inf.total_values), flush=True)
+            if os.environ.get("ACM_FUZZ_KEEP"):
+                files = [files[int(k)] for k in os.environ["ACM_FUZZ_KEEP"].split(",")]
+                good = [f for f in files if O.Oracle(f).err >= 0]
         # (a) plan API
         if good:
-            staged = [capi.stage_file(f) for f in good]
             fmt = int(rng.integers(0, 4))
+        if good and "a" in part:
+            staged = [capi.stage_file(f) for f in good]
             got, st = capi.synth(dev, staged, fmt=fmt, return_stats=True, mform=True)
             packed_tiles += st.mform_tiles
             for f, g in zip(good, got):
@@ -61,7 +78,12 @@ with capi.Device(0) as dev:
         # (b) batch front end
         mode = int(rng.integers(0, 3))             # host parsing, host parsing ahead of the call, device parsing in 1 ... 16 block ranges
         os.environ["ACM_BATCH_RANGES"] = str(int(rng.choice([1, 2, 3, 5, 8, 16])))
-        res, tm = capi.batch_decode(dev, files, threads=int(rng.integers(1, 9)), pinned=bool(rng.integers(0, 2)), prestage=mode == 1,
+        threads, pinned = int(rng.integers(1, 9)), bool(rng.integers(0, 2))
+        if "b" not in part:
+            continue
+        if only is not None:
+            print("  batch half: mode %d ranges %s threads %d pinned %s" % (mode, os.environ["ACM_BATCH_RANGES"], threads, pinned), flush=True)
+        res, tm = capi.batch_decode(dev, files, threads=threads, pinned=pinned, prestage=mode == 1,
                                     parse=capi.PARSE_DEVICE if mode == 2 else capi.PARSE_HOST, byteplane=True if mode == 1 else None)
         packed_streams += tm.packed_streams
         for k, f in enumerate(files):

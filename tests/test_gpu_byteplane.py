@@ -355,6 +355,30 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
         assert res0[k][0] == res[k][0] and np.array_equal(res0[k][1], want), k
 
 
+@pytest.mark.parametrize("ranges", [2, 3, 5])
+def test_device_parser_walk_that_stops_inside_a_range(dev, monkeypatch, ranges):
+    """A truncated stream whose walk gets through SOME blocks of a block range and stops in a later one: the column kernel then skips the
+    stream altogether, so none of that range's pair-table entries is written by it - and the synthesis of the range is already queued
+    on a plan cut from the headers.  Every entry of the range must name a place the chunk kernel may load from (it used to be only the
+    entries from the block that failed on: a GPU memory fault, profiles/byteplane_fuzz.py seed 2718 batch 133).  The host reader's
+    redo delivers what the reference delivers"""
+    import oracle_api as O
+    monkeypatch.setenv("ACM_BATCH_RANGES", str(ranges))
+    whole = make_stream(500842608, 12, 8, 3, channels=1, cut=5, pwr_min=7, pwr_max=7, val_max=65535)
+    files = [whole[:36185]]
+    for k, (lv, rows, nb) in enumerate(((12, 8, 7), (9, 16, 12), (10, 8, 9), (11, 4, 11), (8, 32, 6))):
+        f = make_stream(33100 + k, lv, rows, nb, pwr_max=12)
+        for frac in (0.55, 0.72, 0.9):
+            files.append(f[:int(len(f) * frac)])
+    files.append(make_stream(33200, 9, 16, 12, pwr_max=12))        # a clean one beside them
+    for _ in range(2):
+        res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE)
+        for k, f in enumerate(files):
+            want, wst = oracle_pcm(f)
+            assert np.array_equal(res[k][1], want), k
+    assert tm.device_parsed >= 1
+
+
 def test_plan_says_which_rows_it_reads_from_the_second_form(dev, monkeypatch):
     """acmhip_plan_form_rows: whole tiles of the lean kernel for a stream that came with the form, 0 for one without, and 0 for a level-14
     stream of a plan too small for the lean kernel (its rows are read from the int16 arena)"""
