@@ -1,6 +1,6 @@
 // Diagnostic: where do the cycles of the chunk kernel (acm_chunk) go?  Builds the real kernel source with ACM_STAMPS (s_memtime stamps per
 // phase, per wavefront) on synthetic byte-plane data and prints the phase shares.  Timing only (the PCM is not looked at).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I libacm_amd/csrc -o phases_k3 profiles/ubench/phases_k3.hip
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I libacm_amd/csrc -o profiles/ubench/phases_k3.bin profiles/ubench/phases_k3.hip
 //   ./phases_k3 <level> [rows per block = 16] [percent of the blocks at 16 bits = 56]
 #define ACM_STAMPS 1
 #include "../../libacm_amd/csrc/acm_kernels.hip"
