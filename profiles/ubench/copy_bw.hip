@@ -106,6 +106,29 @@ extern "C" double acm_copy_between_gbs(void *dst, const void *src, size_t bytes)
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return best;
 }
+/* device memory through the virtual-memory API, in physical chunks of `chunk` bytes (0: one chunk) mapped back to back: does the way the
+ * pages are obtained decide the +-5 % of profiles/r5_placement.txt?  (never freed: a probe) */
+extern "C" void *acm_vmm_alloc(size_t bytes, size_t chunk, size_t *granularity) {
+  int dev = 0; (void)hipGetDevice(&dev);
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) return nullptr;
+  if (granularity) *granularity = gran;
+  if (!chunk) chunk = bytes;
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t total = (bytes + chunk - 1) / chunk * chunk;
+  void *base = nullptr;
+  if (hipMemAddressReserve(&base, total, gran, nullptr, 0) != hipSuccess) return nullptr;
+  for (size_t at = 0; at < total; at += chunk) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) return nullptr;
+    if (hipMemMap((char *)base + at, chunk, 0, h, 0) != hipSuccess) return nullptr;
+  }
+  hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemSetAccess(base, total, &acc, 1) != hipSuccess) return nullptr;
+  return base;
+}
 extern "C" int acm_poison(void *p, size_t bytes, int value) {
   if (hipMemset(p, value, bytes) != hipSuccess) return -1;
   return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
