@@ -1909,6 +1909,14 @@ struct FirstPassZW {
 						const v4i_t h1 = mfma(raw.hi[g][s], cf2, zero);
 						const v4i_t h2 = mfma(raw.hi[g][s + 1], cf1, h1);
 						const v4i_t ha = mfma(raw.hi[g][s + 2], cf0, h2);
+						/* (level 13's sixteen wavefronts per CU have 128 registers each, and the second path costs the one that spills) */
+						if (L != 13 && (uint32_t)val[s] < 65536u && !step2[s] && !step1[s]) {
+							/* (one v_mad_u32_u24 per output: FirstPassZ::run_t says why it is exact) */
+							const uint32_t v8 = (uint32_t)opaque_v((int32_t)((uint32_t)val[s] << 8));
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								y[v] = (int32_t)(__umul24((uint32_t)ha[v], v8) + (uint32_t)y[v]);
+						} else {
 						/* (opaque copies: FirstPassZ::run_t says why) */
 						const int32_t wv = opaque_v(val[s]), w2 = opaque_v(dv2[s]), w1 = opaque_v(dv1[s]);
 						v4i_t yh;
@@ -1928,6 +1936,7 @@ struct FirstPassZW {
 #pragma unroll
 						for (int v = 0; v < 4; v++)
 							y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << 8) + (uint32_t)y[v]);
+						}
 					}
 					const uint32_t m = (uint32_t)(s * COLS) + c0 + (uint32_t)SIGMA * (qd + 16u * (uint32_t)mt);
 					uint32_t *const o = tile + (m + (m >> PS));
@@ -2402,6 +2411,10 @@ struct FirstPassZ {
 		/* per walk row s (and walker of the lane): val of the row, the two differences, and whether any lane of the set has one */
 		int32_t val[NSW][NH], dv2[NSW][NH], dv1[NSW][NH];
 		bool step2[NSW], step1[NSW];
+		bool small[NSW];                /* the row's (scaled) val is below 2^16 in every lane: see the one-instruction join of the high plane */
+#pragma unroll
+		for (int s = 0; s < NSW; s++)
+			small[s] = OutScale<L>::SHIFT == 0;
 		if constexpr (RR <= 2) {
 			int32_t rowval[TR + 2];
 #pragma unroll
@@ -2417,6 +2430,7 @@ struct FirstPassZ {
 					dv1[s][0] = a2 - a1;
 					step2[s] = a1 != a0;
 					step1[s] = a2 != a1;
+					small[s] = (uint32_t)a0 < 65536u;
 				} else {
 					const int32_t b0 = rowval[NSW + s + 2], b1 = rowval[NSW + s + 1], b2 = rowval[NSW + s];
 					val[s][0] = rrd[0] ? b0 : a0;
@@ -2424,6 +2438,7 @@ struct FirstPassZ {
 					dv1[s][0] = rrd[0] ? b2 - b1 : a2 - a1;
 					step2[s] = a1 != a0 || b1 != b0;
 					step1[s] = a2 != a1 || b2 != b1;
+					small[s] = (uint32_t)(a0 | b0) < 65536u;
 				}
 			}
 		} else {
@@ -2497,12 +2512,14 @@ struct FirstPassZ {
 					const v4i_t h1 = mfma(hi[g][s], cf2, zero);
 					const v4i_t h2 = mfma(hi[g][s + 1], cf1, h1);
 					const v4i_t ha = mfma(hi[g][s + 2], cf0, h2);
-					/* With val itself below 2^16 (levels 8 and 9: no scaling) and no change of val in reach, the high plane joins in ONE
-					 * instruction per output: y += ha * (val << 8) as v_mad_u32_u24.  Its operands are the low 24 bits of each register
-					 * taken as unsigned: val << 8 is below 2^24, and a negative ha reads as ha + 2^24, which adds 2^24 * 256 * val = 0
-					 * (mod 2^32).  (val << 8 through an opaque copy: or the optimiser folds both planes into one 32-bit multiply) */
-					if constexpr (OutScale<L>::SHIFT == 0) {
-						if (!step2[s] && !step1[s]) {
+					/* With the row's val (as scaled: val << SHIFT) below 2^16 - always at levels 8 and 9, which do not scale; at the others
+					 * for val below 2^(level - 4 ... level), which is most material - and no change of val in reach, the high plane
+					 * joins in ONE instruction per output: y += ha * (val << 8) as v_mad_u32_u24.  Its operands are the low 24 bits of
+					 * each register taken as unsigned: val << 8 is below 2^24, and a negative ha reads as ha + 2^24, which adds
+					 * 2^24 * 256 * val = 0 (mod 2^32).  (val << 8 through an opaque copy: or the optimiser folds both planes into one
+					 * 32-bit multiply) */
+					{
+						if (small[s] && !step2[s] && !step1[s]) {
 							uint32_t v8[NH];
 #pragma unroll
 							for (int hf = 0; hf < NH; hf++)

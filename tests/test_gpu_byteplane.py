@@ -165,6 +165,19 @@ def test_byteplane_windows(dev, force_k2, level, rows):
             dev.free(p_)
 
 
+@pytest.mark.parametrize("level", [9, 10, 11, 12, 13, 14])
+def test_byteplane_val_around_the_one_instruction_join(dev, force_k2, level):
+    """the high plane of a 16-bit pair joins in one v_mad_u32_u24 per output while the row's scaled val (val << (16 - level) from level 10 on)
+    stays below 2^16, in three instructions above it and wherever val changes in reach: blocks on both sides of that border, next to each other"""
+    border = 65536 >> (16 - level if level >= 10 else 0)
+    rows = 16 if level < 13 else 4
+    for k, vmax in enumerate((border - 1, 2 * border - 1 if 2 * border <= 65536 else 65535, 65535)):
+        f = make_stream(29500 + 10 * level + k, level, rows, max(6, (6 * 8192 >> level) // rows + 2), pwr_min=8, pwr_max=12, val_max=vmax)
+        got, st = capi.synth(dev, [capi.stage_file(f)], return_stats=True, mform=True)
+        assert st.mform_tiles > 0
+        assert np.array_equal(got[0], oracle_pcm(f)[0]), (level, vmax)
+
+
 def test_byteplane_streams_with_h1_patches_keep_the_int16_form(dev, force_k2):
     files = [make_stream(25000, 9, 16, 12, pwr_max=12),
              make_stream(25001, 9, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6),
