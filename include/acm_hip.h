@@ -114,6 +114,8 @@ int  acmhip_host_alloc(size_t bytes, void **hptr);            /* pinned */
 int  acmhip_host_free(void *hptr);
 int  acmhip_upload(acmhip_device *dev, void *dptr, const void *hptr, size_t bytes);    /* async on the device stream */
 int  acmhip_download(acmhip_device *dev, void *hptr, const void *dptr, size_t bytes);  /* async on the device stream */
+int  acmhip_memset(acmhip_device *dev, void *dptr, int byte, size_t bytes);            /* async on the device stream: a caller that wants to
+                                                                                         * see every sample written (tests, bench) poisons the PCM arena first */
 
 /*
  * Build the launch tables for `n` streams (+ optional H1 patches).  Streams may
@@ -229,6 +231,7 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  * ---------------------------------------------------------------------- */
 typedef uint32_t acmhip_mform_pair;
 #define ACMHIP_BP_NIBBLE 1u
+#define ACMHIP_BP_NIB12  1u     /* the same code in the six-stage form of levels 8-12 (which has no 4-bit class): 12 bits, see above */
 #define ACMHIP_BP_BYTE   2u
 #define ACMHIP_BP_WORD   3u
 int  acmhip_mform_tile_rows(uint32_t level);     /* rows per tile of the matrix-core build, 0 if the level has none */

@@ -1,6 +1,25 @@
 /*
  * libacm.h - public C API of the MI355X-native ACM decoder.
  *
+ * The declarations below (function prototypes, struct layouts, constants) reproduce the public interface of
+ * libacm 1.3 - they ARE the ABI this library is a drop-in for - and that interface is
+ *
+ *   Copyright (c) 2004-2010, Marko Kreen
+ *
+ *   Permission to use, copy, modify, and/or distribute this software for any
+ *   purpose with or without fee is hereby granted, provided that the above
+ *   copyright notice and this permission notice appear in all copies.
+ *
+ *   THE SOFTWARE IS PROVIDED "AS IS" AND THE AUTHOR DISCLAIMS ALL WARRANTIES
+ *   WITH REGARD TO THIS SOFTWARE INCLUDING ALL IMPLIED WARRANTIES OF
+ *   MERCHANTABILITY AND FITNESS. IN NO EVENT SHALL THE AUTHOR BE LIABLE FOR
+ *   ANY SPECIAL, DIRECT, INDIRECT, OR CONSEQUENTIAL DAMAGES OR ANY DAMAGES
+ *   WHATSOEVER RESULTING FROM LOSS OF USE, DATA OR PROFITS, WHETHER IN AN
+ *   ACTION OF CONTRACT, NEGLIGENCE OR OTHER TORTIOUS ACTION, ARISING OUT OF
+ *   OR IN CONNECTION WITH THE USE OR PERFORMANCE OF THIS SOFTWARE.
+ *
+ * (ISC licence, kept here as it asks; the implementation behind the interface is this repository's own.)
+ *
  * Source- and ABI-compatible with markokr/libacm v1.3 (reference:
  * /root/reference/src/libacm.h): same 19 entry points, same error codes, same
  * public struct layouts (x86-64: sizeof(ACMStream) == 176, offsets listed in

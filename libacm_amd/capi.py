@@ -83,7 +83,7 @@ class BatchTiming(C.Structure):
 ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
-    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_plan_create", "acmhip_plan_destroy",
+    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_memset", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file", "acm_stage_file_mform",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
@@ -132,6 +132,7 @@ def lib():
     L.acmhip_host_free.argtypes = [vp]
     L.acmhip_upload.argtypes = [vp, vp, vp, sz]
     L.acmhip_download.argtypes = [vp, vp, vp, sz]
+    L.acmhip_memset.argtypes = [vp, vp, C.c_int, sz]
     L.acmhip_plan_create.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_destroy.argtypes = [vp]
     L.acmhip_plan_destroy.restype = None
@@ -322,11 +323,11 @@ class MformArena:
         return np.bincount(self.pairs & 3, minlength=4)
 
 
-def mform_streams(idx, descs, threads=1):
+def mform_streams(idx, descs, threads=1, L=None):
     """The byte-plane form of every stream of a staged arena that can have one (whole tiles from row 0 of the levels
-    acmhip_mform_tile_rows() covers)."""
+    acmhip_mform_tile_rows() covers).  L: another build of the library to stage with (profiles/ab_kernels.py --own-form)."""
     from concurrent.futures import ThreadPoolExecutor
-    L = lib()
+    L = L or lib()
     n = len(descs)
     ntiles, rows, cap, p_at = [0] * n, [0] * n, [0] * n, [0] * n
     np_tot = 0
@@ -484,6 +485,10 @@ class Device:
     def download(self, arr, dptr):
         _check(lib().acmhip_download(self.h, arr.ctypes.data, dptr, arr.nbytes), "acmhip_download")
         self.sync()
+
+    def memset(self, dptr, byte, nbytes):
+        """fill device memory (queued on the device stream); the parity tests poison a whole PCM arena with it before a launch"""
+        _check(lib().acmhip_memset(self.h, dptr, byte, nbytes), "acmhip_memset")
 
 
 class Plan:

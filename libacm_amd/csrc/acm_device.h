@@ -38,6 +38,9 @@ struct AcmTile {
 /* records of the chunk kernel whose chunks are ONE row (acm_chunk, level 11) */
 #define ACM_TILE_ROW1    4u    /* the chunk is row 1 of its stream: one row in front of it */
 #define ACM_TILE_ODD     8u    /* the chunk starts on the second row of a pair (idx_off still names the entry of the pair in front of that pair) */
+#define ACM_TILE_ONEBLOCK 16u  /* chunk records: every row in reach of the chunk - the two in front of it through its last - lies in ONE block
+                                * (hdr_blk), so one val scales them all (decode.c:586-600: val is per block).  Geometry only: the planner
+                                * knows it without looking at a header; acm_chunk takes its fast path on it */
 
 /* one tile of the lean kernels (acm_tile2, acm_chunk): tile_rows consecutive rows of a stream, all of them present and emitted.
  * Tiles of a stream are consecutive table entries; the first one carries ACM_TILE_FRESH when it is the stream's row 0 - or, for a

@@ -352,6 +352,15 @@ extern "C" int acmhip_download(acmhip_device *dev, void *hptr, const void *dptr,
 	return ACMHIP_OK;
 }
 
+extern "C" int acmhip_memset(acmhip_device *dev, void *dptr, int byte, size_t bytes)
+{
+	if (!dev)
+		return ACMHIP_ERR_ARG;
+	if (bytes)
+		HIPTRY(hipMemsetAsync(dptr, byte, bytes, dev->stream));
+	return ACMHIP_OK;
+}
+
 /* ------------------------------------------------------------------------ */
 
 namespace {
@@ -616,8 +625,11 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			const uint32_t rhm0 = (uint32_t)(rm >= 2 ? rm - 2 : 0);
 			uint32_t blk = rhm0 / srows, pos = rhm0 % srows;        /* of row rm - 2, carried along from chunk to chunk */
 			for (; rm < r + T2; rm += T2M) {
+				/* rows in reach: max(rm - 2, 0) - the row (blk, pos) names - through rm + T2M - 1 */
+				const uint64_t span = rm + T2M - 1 - (rm >= 2 ? rm - 2 : 0);
 				mtab.push_back(AcmTile2{ packed[i].chunk_off + rm / 2, pcm_of(rm), (uint32_t)s.hdr_off + blk, pos, magic,
-							 flags_of(rm, lead_in) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) });
+							 flags_of(rm, lead_in) | (rm == 1 ? ACM_TILE_ROW1 : 0u) | ((rm & 1) ? ACM_TILE_ODD : 0u) |
+							 (pos + span < srows ? ACM_TILE_ONEBLOCK : 0u) });
 				/* the next chunk's row rm + T2M - 2 (rows 0 and 1 of a stream both count from row 0) */
 				const uint32_t step = rm >= 2 ? T2M : rm + T2M >= 2 ? (uint32_t)(rm + T2M - 2) : 0u;
 				pos += step;

@@ -2311,27 +2311,132 @@ struct FirstPassZ {
 			raw.hi[0][k] = dpp4<0x118, 0xC>(raw.hi[0][k], raw.hi[0][k + NSW]);
 		}
 	}
+	/*
+	 * The fast path (round 6).  profiles/ubench/issue_model.hip: a SIMD of this chip issues ONE instruction at a time whatever its kind, and
+	 * the chunk loop is bound by that (r6 notes in DESIGN.md: ~860 instructions per chunk, 190 of them scalar) - so what a chunk can know
+	 * as a SCALAR it should not work out per lane.  Two facts make most chunks simple:
+	 *   - every row in reach lies in one block (ACM_TILE_ONEBLOCK, set by the planner from the geometry alone), so one val - a scalar
+	 *     load of the block header, asked for two chunks ahead with the chunk's pair-table entries - scales everything: no per-row
+	 *     values, no differences, no per-set branches;
+	 *   - the row pairs in reach are stored at ONE width and back to back (what every stager writes inside a block; checked here on the
+	 *     entries themselves, which are scalars already), so a row's place is a scalar base plus ONE lane offset that does not change
+	 *     from chunk to chunk, nothing is masked, and a chunk of 8-bit pairs does not ask for high bytes at all.
+	 * mode: 0 = the general path, 1 = fast, pairs at 8 bits, 2 = fast, pairs at 16 bits.
+	 */
+	static constexpr int JM = (TR & 1) ? 1 : TR / 2;         /* pair-table entries 0 .. JM hold the rows in reach of a chunk */
+	static_assert(JM + 1 <= NE, "entries in reach are entries fetched");
+	/* HALF-bytes per index of a width class: ACMHIP_BP_NIB12 (1) 3, _BYTE (2) 2, _WORD (3) 4; a row of a pair takes COLS / 2 times that many
+	 * bytes, the QN indices of a residue class QN / 2 times (their low bytes first, the high bytes - or nibbles - 64 bytes on) */
+	static __device__ __forceinline__ uint32_t half_bytes(const uint32_t cls) { return (0x4230u >> (4u * cls)) & 15u; }
+	/* J0: the first entry whose rows the chunk's loads ask for (1 where the rows in front stay in registers).
+	 * Returns the mode: 0 general; else fast with every pair in reach at 8 (1), 16 (2) or 12 bits (3) */
+	template <int J0>
+	static __device__ __forceinline__ uint32_t mode_of(const uint32_t flags, const Desc &d, const uint32_t sval)
+	{
+		const uint32_t cls = d.e[0] & 3u;
+		const uint32_t pair_units = (uint32_t)(COLS / 64) * half_bytes(cls);   /* 64-byte units a pair of this width takes */
+		bool ok = (flags & ACM_TILE_ONEBLOCK) != 0 && cls != 0u;
+		if constexpr (OutScale<L>::SHIFT != 0)
+			ok = ok && sval < 65536u;               /* (the one-instruction join of the high plane, see run_t) */
+#pragma unroll
+		for (int j = 1; j <= JM; j++)
+			ok = ok && (d.e[j] & 3u) == cls;
+#pragma unroll
+		for (int j = J0; j < JM; j++)
+			ok = ok && (d.e[j + 1] >> 2) - (d.e[j] >> 2) == pair_units;
+		return ok ? (cls == ACMHIP_BP_NIB12 ? 3u : cls - (ACMHIP_BP_BYTE - 1u)) : 0u;
+	}
+
+#ifndef ACM_K3_LD_MOD
+#define ACM_K3_LD_MOD " nt"     /* the staged bytes are read once: non-temporal.  A/B in one process, every build on its own staging (profiles/ab_kernels.py
+				 * --own-form): +1.8 % on a box whose allocation runs the launch in its slow mode (1.5221 -> 1.4957 ms), +0.3 % on a fast one;
+				 * sc1 / sc0 sc1: -0.7 ... -0.8 %, sc0: 0, sc1 nt / sc0 sc1 nt: as nt (profiles/r6_level9_notes.txt) */
+#endif
 	template <bool KEEP>
-	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd)
+	static __device__ __forceinline__ void issue(Raw &raw, const uint8_t *arena, const Desc &d, const int lane, const uint32_t odd, const uint32_t mode)
 	{
 		static_assert(!KEEP || KEEPS_ROWS, "the rows in front belong to another lane");
+		constexpr int K0 = KEEP ? 2 : 0, J0 = KEEP ? 1 : 0;
 		const uint32_t i = (uint32_t)lane & 15u, ks = (uint32_t)lane >> 4;
 		const uint32_t c = class_of(i), rr = RR == 1 ? 0u : i / SIGMA;
-		const uint32_t e0 = d.e[0];
-		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
+		const uint32_t smode = __builtin_amdgcn_readfirstlane(mode);   /* (wave-uniform by construction; says so to the compiler) */
+		/* where a lane's sixteen bytes of (row k, group g) are: a lane offset - one for the low bytes, one for what is 64 bytes behind them:
+		 * sixteen high bytes, or eight bytes of high nibbles, which sit 8 ks and not 16 ks into their part (and are asked for as sixteen
+		 * bytes like everything else: what comes with them is dropped, see expand_nib) - from a base the wavefront shares */
+		uint32_t va[NX][NG], vh[NX][NG];
+		const uint8_t *sb[NX][NG];
+		if (mode) {
+			/* one width, back to back: row u (counted from the first row of entry J0's pair) starts u rows of this width on */
+			const uint32_t hb = smode == 1u ? 2u : smode == 2u ? 4u : 3u;
+			const uint64_t base = reinterpret_cast<uint64_t>(arena) + ((uint64_t)(d.e[J0] >> 2) << 6);
+			const uint32_t vl = (rr * (uint32_t)(NSW * COLS / 2) + c * (uint32_t)(QN / 2)) * hb + 16u * ks;
+			const uint32_t vlh = vl - (smode == 3u ? 8u * ks : 0u);
 #pragma unroll
-		for (int k = KEEP ? 2 : 0; k < NX; k++) {
-			const uint32_t u = (TR & 1 ? odd : 0u) + rr * NSW + k;          /* row 0 = the first row of the pair in front */
-			const uint32_t e = entry_of(d, u);
-			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
-			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((u & 1u) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
+			for (int k = K0; k < NX; k++)
 #pragma unroll
-			for (int g = 0; g < NG; g++) {
-				const uint32_t v = row_at + (((group_at(g) + c) * (uint32_t)QN) << sh);
-				asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[g][k]) : "v"(v), "s"(base) : "memory");
-				asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(raw.hi[g][k]) : "v"(v), "s"(base) : "memory");
+				for (int g = 0; g < NG; g++) {
+					va[k][g] = vl;
+					vh[k][g] = vlh;
+					sb[k][g] = sgpr_u64(base + (uint64_t)((((TR & 1 ? odd : 0u) + (uint32_t)(k - K0)) * (uint32_t)(COLS / 2) + group_at(g) * (uint32_t)(QN / 2)) * hb));
+				}
+		} else {
+			const uint32_t e0 = d.e[0];
+			const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
+#pragma unroll
+			for (int k = K0; k < NX; k++) {
+				const uint32_t u = (TR & 1 ? odd : 0u) + rr * NSW + k;          /* row 0 = the first row of the pair in front */
+				const uint32_t e = entry_of(d, u);
+				const uint32_t hb = half_bytes(e & 3u);
+				const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((u & 1u) ? (uint32_t)(COLS / 2) * hb : 0u) + 16u * ks;
+#pragma unroll
+				for (int g = 0; g < NG; g++) {
+					va[k][g] = row_at + (group_at(g) + c) * (uint32_t)(QN / 2) * hb;
+					vh[k][g] = va[k][g] - ((e & 3u) == ACMHIP_BP_NIB12 ? 8u * ks : 0u);
+					sb[k][g] = base;
+				}
 			}
 		}
+		/* ONE place that asks for a register, whatever the path: two load sequences joined by the compiler would be joined with copies of
+		 * registers whose loads are still in flight (tests/test_isa_invariants.py).  The high bytes of a chunk of 8-bit pairs (mode 1)
+		 * are not asked for: the skip is a scalar branch inside the statement, the register keeps what it had (never looked at: the
+		 * fast path at 8 bits runs no high plane, the general path masks the rows that have none) */
+#pragma unroll
+		for (int k = K0; k < NX; k++)
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				asm volatile("global_load_dwordx4 %0, %1, %2" ACM_K3_LD_MOD : "=v"(raw.lo[g][k]) : "v"(va[k][g]), "s"(sb[k][g]) : "memory");
+				asm volatile("s_cmp_eq_u32 %3, 1\n\ts_cbranch_scc1 .Lacm_z8_%=\n\t"
+					     "global_load_dwordx4 %0, %1, %2 offset:64" ACM_K3_LD_MOD "\n"
+					     ".Lacm_z8_%=:"
+					     : "+v"(raw.hi[g][k]) : "v"(vh[k][g]), "s"(sb[k][g]), "s"(smode) : "memory", "scc");
+			}
+	}
+	/*
+	 * The 12-bit class in registers.  What the load of a row's "high bytes" brings for a 12-bit pair is eight bytes of high NIBBLES (dwords
+	 * 0 and 1; dwords 2 and 3 are the next lane's): element 8 d + b of the lane's sixteen in the high nibble of byte b of dword d, element
+	 * 8 d + 4 + b in the low one (acm_pack.cpp put_row_nib12).  expand: the sixteen operand bytes hi << 4 - signed bytes as they stand,
+	 * the matrix pass of such rows is scaled by val << 4 instead of val << 8.  This "N form" is what a 12-bit row's registers hold from
+	 * then on (history handed from chunk to chunk included); the general path, which runs ONE high plane over rows of any width, takes
+	 * such rows to true bytes first (sra4) and the rows that stay for the next chunk back afterwards (shl4).
+	 */
+	static __device__ __forceinline__ v4u_t expand_nib(const v4u_t x)
+	{
+		const uint32_t M = 0xF0F0F0F0u;
+		return v4u_t{ x[0] & M, (x[0] << 4) & M, x[1] & M, (x[1] << 4) & M };
+	}
+	static __device__ __forceinline__ v4u_t sra4(const v4u_t x)    /* every byte arithmetically shifted right by four */
+	{
+		v4u_t r;
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const uint32_t m = x[v] & 0x80808080u;          /* sign bits: 0xF0 per negative byte = (m << 1) - (m >> 3), whole-word arithmetic */
+			r[v] = ((x[v] >> 4) & 0x0F0F0F0Fu) | ((m << 1) - (m >> 3));
+		}
+		return r;
+	}
+	static __device__ __forceinline__ v4u_t shl4(const v4u_t x)
+	{
+		return v4u_t{ (x[0] << 4) & 0xF0F0F0F0u, (x[1] << 4) & 0xF0F0F0F0u, (x[2] << 4) & 0xF0F0F0F0u, (x[3] << 4) & 0xF0F0F0F0u };
 	}
 	/* what the chunk behind this one finds in front of its walk: the last two rows of this one's (the registers of rows 2 .. are about to
 	 * be asked for again).  A stream's first chunk has nothing in front of it: zeros, as the stager's pair of zeros would have been */
@@ -2386,11 +2491,15 @@ struct FirstPassZ {
 	 * differences that is not zero in SOME lane of the set (step2 / step1, decided per set from the scalar row values) - no matrix
 	 * instruction more, and nothing for the chunks in the middle of a block.
 	 */
-	/* hvs: lane k holds val << SHIFT of chunk row k - 2 (k < TR + 2) */
-	template <bool WORDS>
+	/* hvs: lane k holds val << SHIFT of chunk row k - 2 (k < TR + 2).
+	 * FAST (mode_of): one val, below 2^16 as scaled, over every row in reach - the scalar sval; hvs is not looked at.  No differences,
+	 * no branches per set, the multipliers are scalar operands: per output ONE instruction per plane. */
+	/* NIB (FAST only): the high plane's rows are 12-bit rows in N form (expand_nib): scaled by val << 4, a signed multiply */
+	template <bool WORDS, bool FAST, bool NIB = false>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const uint32_t hvs,
-						     const uint32_t in_front)
+						     const uint32_t in_front, const uint32_t sval)
 	{
+		static_assert(!NIB || (WORDS && FAST), "rows in N form are a fast-path matter; the general path takes them to bytes first");
 		const v4i_t zero = { 0, 0, 0, 0 };
 		/* output side of the lane: instances 4 (lane / 16) .. + 3 = four adjacent classes of one walker (two classes each of two walkers
 		 * where a row has only two), output q = 16 mt + lane % 16 */
@@ -2415,7 +2524,16 @@ struct FirstPassZ {
 #pragma unroll
 		for (int s = 0; s < NSW; s++)
 			small[s] = OutScale<L>::SHIFT == 0;
-		if constexpr (RR <= 2) {
+		if constexpr (FAST) {
+#pragma unroll
+			for (int s = 0; s < NSW; s++) {
+				step2[s] = step1[s] = false;
+				small[s] = true;
+#pragma unroll
+				for (int hf = 0; hf < NH; hf++)
+					val[s][hf] = dv2[s][hf] = dv1[s][hf] = 0;
+			}
+		} else if constexpr (RR <= 2) {
 			int32_t rowval[TR + 2];
 #pragma unroll
 			for (int k = 0; k < TR + 2; k++)
@@ -2495,6 +2613,29 @@ struct FirstPassZ {
 				const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
 				const v4i_t la = mfma(raw.lo[g][s + 2], cf0, l2);
 				v4i_t y;
+				if constexpr (FAST) {
+					/* (opaque copies of the scalar multipliers: or the optimiser folds the two planes into one 32-bit multiply, see below) */
+					const int32_t sv = opaque_s((int32_t)__builtin_amdgcn_readfirstlane(sval));
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						y[v] = __mul24(la[v], sv) + (v % NVH == 0 ? b[v / NVH] : 0);
+					if constexpr (WORDS) {
+						const v4i_t h1 = mfma(hi[g][s], cf2, zero);
+						const v4i_t h2 = mfma(hi[g][s + 1], cf1, h1);
+						const v4i_t ha = mfma(hi[g][s + 2], cf0, h2);
+						if constexpr (NIB) {
+							const int32_t sv4 = opaque_s((int32_t)__builtin_amdgcn_readfirstlane(sval << 4));      /* below 2^20: a signed 24-bit operand */
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								y[v] = __mul24(ha[v], sv4) + y[v];
+						} else {
+							const uint32_t sv8 = (uint32_t)opaque_s((int32_t)__builtin_amdgcn_readfirstlane(sval << 8));
+#pragma unroll
+							for (int v = 0; v < 4; v++)
+								y[v] = (int32_t)(__umul24((uint32_t)ha[v], sv8) + (uint32_t)y[v]);
+						}
+					}
+				} else {
 #pragma unroll
 				for (int v = 0; v < 4; v++)
 					y[v] = __mul24(la[v], val[s][v / NVH]) + (v % NVH == 0 ? b[v / NVH] : 0);
@@ -2560,6 +2701,7 @@ struct FirstPassZ {
 					}
 				joined:;
 				}
+				}       /* !FAST */
 				/* the constant parts of the address: multiples of 32, or (16 g) small enough to stay inside the lane's group of 32 - the pad rule splits */
 				static_assert(COLS % (1 << PS) == 0 && (SIGMA * 16) % (1 << PS) == 0 &&
 					      (NG == 1 || (group_at(NG - 1) % (1 << PS) + CB + 7 < (1 << PS) && SIGMA % (1 << PS) == 0)), "address split");
@@ -2578,8 +2720,11 @@ struct FirstPassZ {
 		}
 	}
 
+	/* first: the chunk's loads asked for every row, the two in front included (a run's first chunk; every chunk where the rows in front are
+	 * not kept in registers) - else rows 0 and 1 are history in the form the chunk before left them in */
 	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const Tables &t, const int lane_, const uint32_t hvs,
-						   const Desc &d, const uint32_t in_front, const uint32_t odd)
+						   const Desc &d, const uint32_t in_front, const uint32_t odd, const uint32_t mode, const uint32_t sval,
+						   const bool first)
 	{
 		/* what a lane derives from its number (LDS places, table offsets) is worked out again per chunk - a handful of instructions - instead
 		 * of living in registers through the LDS passes, which are what the kernel is short of */
@@ -2588,25 +2733,80 @@ struct FirstPassZ {
 #else
 		const int lane = lane_;
 #endif
-		if constexpr (HISTORY_BY_DPP)
-			take_history_from_partner(raw);         /* (a run's first chunk has loaded these rows itself: the same bytes again) */
-		uint32_t any_word = 0;
+		const bool all_new = !KEEPS_ROWS || first;
+		if (mode == 3u) {
+			/* twelve bits throughout: the rows just loaded go to N form, that is all */
 #pragma unroll
-		for (int j = 0; j < NE; j++)
+			for (int k = 0; k < NX; k++)
+				if (k >= 2 || all_new) {
+#pragma unroll
+					for (int g = 0; g < NG; g++)
+						raw.hi[g][k] = expand_nib(raw.hi[g][k]);
+				}
+			if constexpr (HISTORY_BY_DPP)
+				take_history_from_partner(raw);
+			run_t<true, true, true>(raw, tile, t, lane, 0u, in_front, sval);
+			return;
+		}
+		if (mode) {
+			if constexpr (HISTORY_BY_DPP)
+				take_history_from_partner(raw);         /* (a run's first chunk has loaded these rows itself: the same bytes again) */
+			if (mode == 2u)
+				run_t<true, true>(raw, tile, t, lane, 0u, in_front, sval);
+			else
+				run_t<false, true>(raw, tile, t, lane, 0u, in_front, sval);
+			return;
+		}
+		uint32_t any_word = 0, any_nib = 0;
+#pragma unroll
+		for (int j = 0; j < NE; j++) {
 			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
-		if (any_word) {
-			/* in place: the rows that stay in their registers for the next chunk (HISTORY_IN_REGISTERS) stay what they are */
-			const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
+			any_nib |= (d.e[j] & 3u) == ACMHIP_BP_NIB12 ? 1u : 0u;
+		}
+		const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
+		if (any_nib) {
+			/* the rows just loaded that are 12-bit rows: to N form (before a partner lane takes them as its history) */
+#pragma unroll
+			for (int k = 0; k < NX; k++)
+				if (k >= 2 || all_new) {
+					if ((entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_NIB12) {
+#pragma unroll
+						for (int g = 0; g < NG; g++)
+							raw.hi[g][k] = expand_nib(raw.hi[g][k]);
+					}
+				}
+		}
+		if constexpr (HISTORY_BY_DPP)
+			take_history_from_partner(raw);                 /* (a run's first chunk has loaded these rows itself: the same bytes again) */
+		if (any_word | any_nib) {
+			/* in place: the rows that stay in their registers for the next chunk (HISTORY_IN_REGISTERS) stay what they are - 8-bit rows have
+			 * no high bytes (zeros); 12-bit rows go from N form to bytes for ONE high plane over rows of any width, and the rows the next
+			 * chunk inherits go back behind it */
 #pragma unroll
 			for (int k = 0; k < NX; k++) {
-				const uint32_t mask = (entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+				const uint32_t cls = entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u;
+				const uint32_t mask = cls == ACMHIP_BP_BYTE ? 0u : 0xFFFFFFFFu;
 #pragma unroll
 				for (int g = 0; g < NG; g++)
 					raw.hi[g][k] &= mask;
+				if (any_nib && cls == ACMHIP_BP_NIB12) {
+#pragma unroll
+					for (int g = 0; g < NG; g++)
+						raw.hi[g][k] = sra4(raw.hi[g][k]);
+				}
 			}
-			run_t<true>(raw, tile, t, lane, hvs, in_front);
+			run_t<true, false>(raw, tile, t, lane, hvs, in_front, 0u);
+			if (any_nib && KEEPS_ROWS) {
+#pragma unroll
+				for (int k = NSW; k < NX; k++)
+					if ((entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_NIB12) {
+#pragma unroll
+						for (int g = 0; g < NG; g++)
+							raw.hi[g][k] = shl4(raw.hi[g][k]);
+					}
+			}
 		} else {
-			run_t<false>(raw, tile, t, lane, hvs, in_front);
+			run_t<false, false>(raw, tile, t, lane, hvs, in_front, 0u);
 		}
 	}
 };
@@ -2657,16 +2857,33 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	/* rows of the stream in front of a chunk: 0, 1 (chunks of one row only), or 2 for "two or more" */
 	auto rows_in_front = [](const AcmTile2 &r) -> uint32_t { return (r.flags & ACM_TILE_FRESH) ? 0u : (r.flags & ACM_TILE_ROW1) ? 1u : 2u; };
 	/* row values: lane lr < TR + 2 fetches the val of chunk row lr - 2 (decode.c:589; the record counts from that row, or from row 0 of the
-	 * stream where it does not exist); every lane issues the load */
-	auto fetch_val = [&](const AcmTile2 &r, const int lane) -> uint32_t {
-		const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
-		const uint32_t missing = 2u - rows_in_front(r);
-		const uint32_t q = r.rowpos + (lr_fetch < missing ? 0u : lr_fetch - missing);
-		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;
-		const uint32_t *p = &hdr[r.hdr_blk + b].val;
-		uint32_t v;
-		asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+	 * stream where it does not exist); every lane issues the load.  A chunk on the fast path (mode != 0) has ONE val, a scalar (val_of):
+	 * it asks for nothing here - the skip is a scalar branch inside the load statement, so that whichever way it goes there is ONE
+	 * statement that writes the register (see FirstPassZ::issue) */
+	auto fetch_val = [&](const AcmTile2 &r, const int lane, uint32_t v, const uint32_t mode) -> uint32_t {
+		const uint32_t *p = &hdr[0].val;
+		if (!mode) {
+			const uint32_t lr_fetch = (uint32_t)(lane < TR + 2 ? lane : TR + 1);
+			const uint32_t missing = 2u - rows_in_front(r);
+			const uint32_t q = r.rowpos + (lr_fetch < missing ? 0u : lr_fetch - missing);
+			const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;
+			p = &hdr[r.hdr_blk + b].val;
+		}
+		asm volatile("s_cmp_lg_u32 %2, 0\n\ts_cbranch_scc1 .Lacm_zv_%=\n\t"
+			     "global_load_dword %0, %1, off\n"
+			     ".Lacm_zv_%=:"
+			     : "+v"(v) : "v"(p), "s"(__builtin_amdgcn_readfirstlane(mode)) : "memory", "scc");
 		return v;
+	};
+	/* the val of the block that holds the first row in reach, scaled like every row value: THE val of an ACM_TILE_ONEBLOCK chunk.  Through the
+	 * scalar cache, asked for two chunks ahead with the chunk's pair-table entries */
+	/* (read through the CONSTANT address space - the block headers are never written while the kernel runs: hdr itself is an operand of
+	 * the hand-issued row-value loads, and what a "memory"-clobbering statement has seen the compiler reloads with a VECTOR load,
+	 * whose wait it would count without knowing of the hand-issued ones) */
+	typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+	auto val_of = [&](const AcmTile2 &r) -> uint32_t {
+		const uint64_t a = reinterpret_cast<uint64_t>(&hdr[__builtin_amdgcn_readfirstlane(r.hdr_blk)].val);
+		return *(const_u32_ptr)a << OutScale<L>::SHIFT;
 	};
 
 	constexpr int NVEC = TR * COLS / 8, PER_OWNER = NJ_LAST / 8, NSTORE = NVEC / 64;
@@ -2678,15 +2895,37 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	 * wavefront's time).  Asked for a whole iteration before they are looked at, they cost nothing.  The last chunks of a run name
 	 * themselves as their successors */
 	auto record_at = [&](const uint32_t k) -> AcmTile2 { return tiles[__builtin_amdgcn_readfirstlane(k < t_end ? k : t_end - 1)]; };
+	/* the path a chunk takes (FirstPassZ::mode_of).  Where the rows in front of a walk stay in registers a chunk's loads start at its own
+	 * first pair; elsewhere (level 8: four walkers) at the pair in front */
+	constexpr int MODE_J0 = FP::KEEPS_ROWS ? 1 : 0;
+#ifdef ACM_K3_NO_FAST
+	auto mode_of = [&](const AcmTile2 &, const typename FP::Desc &, const uint32_t) -> uint32_t { return 0u; };      /* (A/B builds: the round-5 path throughout) */
+#else
+	auto mode_of = [&](const AcmTile2 &r, const typename FP::Desc &d, const uint32_t sval) -> uint32_t {
+		return FP::template mode_of<MODE_J0>(r.flags, d, sval);
+	};
+#endif
 	AcmTile2 cur = record_at(t);
 	typename FP::Desc dcur = FP::fetch_desc(pairs, cur);
 	typename FP::Raw raw;
-	uint32_t hv = fetch_val(cur, lane0);
-	FP::template issue<false>(raw, arena, dcur, lane0, (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
+	{
+		const v4u_t z = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int g = 0; g < FP::NG; g++)
+#pragma unroll
+			for (int k = 0; k < FP::NX; k++)
+				raw.hi[g][k] = z;               /* (the load statement of the high bytes reads the register it may leave alone) */
+	}
+	/* a run's first chunk asks for all its rows, the ones in front included, and for its row values: the general path */
+	uint32_t mode_cur = 0u, sv_cur = val_of(cur);
+	uint32_t hv = fetch_val(cur, lane0, 0u, 0u);
+	FP::template issue<false>(raw, arena, dcur, lane0, (cur.flags & ACM_TILE_ODD) ? 1u : 0u, 0u);
 	k2_wait<0>();
-	bool fresh = true;
+	bool fresh = true, first_of_run = true;
 	AcmTile2 nxt = record_at(t + 1), nx2 = record_at(t + 2);
 	typename FP::Desc dnxt = FP::fetch_desc(pairs, nxt);
+	uint32_t sv_nxt = val_of(nxt);
+	uint32_t mode_nxt = mode_of(nxt, dnxt, sv_nxt);
 #ifdef ACM_STAMPS
 	unsigned long long acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long last_ = stamp_now();
@@ -2706,11 +2945,12 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		const uint32_t hvs = hv << OutScale<L>::SHIFT;
 		ACM_STAMP(0);
 		phase_prio<true, PRIO_FIRST_PASS>();
-		FP::run(raw, tile, tables, lane, hvs, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u);
+		FP::run(raw, tile, tables, lane, hvs, dcur, rows_in_front(cur), (cur.flags & ACM_TILE_ODD) ? 1u : 0u, mode_cur, sv_cur, first_of_run);
+		first_of_run = false;
 		phase_prio<true, PRIO_IDLE>();
 		ACM_STAMP(1);
 
-		hv = fetch_val(nxt, lane);                            /* the last chunk of a run fetches its own again: no branch around the loads */
+		hv = fetch_val(nxt, lane, hv, mode_nxt);              /* the last chunk of a run fetches its own again: no branch around the loads */
 		if constexpr (FP::HISTORY_IN_REGISTERS) {
 			/* the rows in front of the next chunk's walk are in this lane's registers already - unless that chunk starts a stream
 			 * (nothing in front of it: zeros).  (The last chunk of a run, which names itself, is never looked at again.) */
@@ -2721,20 +2961,21 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 			FP::shift_history(raw);
 			if (nxt.flags & ACM_TILE_FRESH)
 				FP::zero_history(raw);
-			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u, mode_nxt);
 		} else if constexpr (FP::HISTORY_BY_DPP) {
 			/* (the same with two walkers: walker 0's rows in front come from walker 1's lanes now, walker 1's from walker 0's in front of
 			 * the next first pass - FirstPassZ::run.  A window's first lead-in chunk: as above) */
 			FP::hand_history_on(raw);
 			if (nxt.flags & ACM_TILE_FRESH)
 				FP::zero_history(raw);
-			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+			FP::template issue<true>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u, mode_nxt);
 		} else {
-			FP::template issue<false>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u);
+			FP::template issue<false>(raw, arena, dnxt, lane, (nxt.flags & ACM_TILE_ODD) ? 1u : 0u, mode_nxt);
 		}
 		/* (asked for here, looked at from the end of this iteration on: behind the LDS passes' own waits) */
 		const AcmTile2 nx3 = record_at(t + 3);
 		const typename FP::Desc dnx2 = FP::fetch_desc(pairs, nx2);
+		const uint32_t sv_nx2 = val_of(nx2);
 		ACM_STAMP(2);
 		phase_prio<true, PRIO_LDS_PASSES>();
 		run_lds_passes<C, PASS_ABL, true, FP::G, Gs...>(tile, lane, fmt, carry_mem);
@@ -2762,9 +3003,13 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		discard = (nxt.flags & ACM_TILE_DISCARD) != 0;
 		cur = nxt;
 		dcur = dnxt;
+		sv_cur = sv_nxt;
+		mode_cur = mode_nxt;
 		t = tn;
 		nxt = nx2;
 		dnxt = dnx2;
+		sv_nxt = sv_nx2;
+		mode_nxt = mode_of(nxt, dnxt, sv_nxt);
 		nx2 = nx3;
 	}
 #ifdef ACM_STAMPS

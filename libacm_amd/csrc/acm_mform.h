@@ -14,7 +14,8 @@
 struct AcmMformWriter {
 	uint32_t level;
 	size_t qn, sigma, cols;
-	bool split;                     /* the chunk kernel's form: 8 / 16 bits only, a 16-bit index as two signed bytes */
+	bool split;                     /* the six-stage form (64 columns of a class side by side): a 16-bit index as two signed bytes, no 4-bit class */
+	bool nib12;                     /* ... of a level of the chunk kernel: + the 12-bit class (a signed low byte and a signed high NIBBLE) */
 	uint8_t *out;
 	uint64_t blob_base, at;
 	acmhip_mform_pair *pairs;

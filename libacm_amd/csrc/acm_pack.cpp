@@ -264,8 +264,14 @@ extern "C" uint64_t acmhip_mform_pairs(uint64_t nrows)
 }
 
 namespace {
+/* the chunk kernel's form (64 columns of a residue class side by side): classes 8 and 16 bits - the 16-bit one as two SIGNED bytes - and,
+ * at the levels of acm_chunk itself (8-12; levels 13 / 14 read the same form inside acm_tile2, which knows no third class), 12 bits */
+inline bool split_form(size_t qn) { return qn == 64; }
+inline bool nib12_level(uint32_t level) { return acmhip_mform_group(level) == 64 && level <= 12; }
 inline uint32_t pair_bytes(uint32_t level, uint32_t cls)
 {
+	if (cls == ACMHIP_BP_NIB12 && split_form((size_t)acmhip_mform_group(level)))
+		return 3u << level;                     /* two rows of 1.5 bytes per index */
 	return (4u << level) >> (3 - cls);             /* two rows of 2 / 1 / 0.5 bytes per index */
 }
 #if defined(__SSE2__)
@@ -291,7 +297,8 @@ inline void transpose8x8(__m128i (&v)[8])
  * signed (the chunk kernel's form, qn = 64); else the low byte minus 128 and the arithmetic high byte */
 bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, uint8_t *dst)
 {
-	if ((qn != 8 && qn != 16 && qn != 64) || (sigma & 7) || (cls != ACMHIP_BP_WORD && cls != ACMHIP_BP_BYTE))
+	const bool nib12 = split && qn == 64 && cls == ACMHIP_BP_NIB12;
+	if ((qn != 8 && qn != 16 && qn != 64) || (sigma & 7) || (cls != ACMHIP_BP_WORD && cls != ACMHIP_BP_BYTE && !nib12))
 		return false;
 	const __m128i flip = _mm_set1_epi16(0x0080), low = _mm_set1_epi16(0x00ff);
 	for (size_t c0 = 0; c0 < sigma; c0 += 8) {
@@ -302,10 +309,22 @@ bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool
 			transpose8x8(t[h]);
 		}
 		for (size_t c = 0; c < 8; c++) {
-			uint8_t *d = dst + (c0 + c) * (cls == ACMHIP_BP_WORD ? 2 * qn : qn);
+			uint8_t *d = dst + (c0 + c) * (cls == ACMHIP_BP_WORD ? 2 * qn : nib12 ? 96 : qn);
 			for (size_t h = 0; h < qn / 8; h += 2) {
 				const __m128i xa = t[h][c], xb = h + 1 < qn / 8 ? t[h + 1][c] : _mm_setzero_si128();
 				__m128i lo, hi;
+				if (nib12) {
+					/* (put_row_nib12 is what this computes) the sixteen elements q = 8 h .. 8 h + 15 are one lane's: 16 low bytes, 8 bytes of nibbles */
+					const __m128i la = _mm_srai_epi16(_mm_slli_epi16(xa, 8), 8), lb = _mm_srai_epi16(_mm_slli_epi16(xb, 8), 8);
+					lo = _mm_packs_epi16(la, lb);
+					hi = _mm_packs_epi16(_mm_srai_epi16(_mm_sub_epi16(xa, la), 8), _mm_srai_epi16(_mm_sub_epi16(xb, lb), 8));       /* [-8, 7] each */
+					const __m128i up = _mm_and_si128(_mm_slli_epi32(hi, 4), _mm_set1_epi8((char)0xF0));      /* elements 0-3 | 4-7 | 8-11 | 12-15 in the high nibbles */
+					const __m128i dn = _mm_and_si128(hi, _mm_set1_epi8(0x0F));
+					const __m128i r = _mm_or_si128(up, _mm_srli_epi64(dn, 32));             /* dword 0: elements 0-3 over 4-7, dword 2: 8-11 over 12-15 */
+					_mm_storeu_si128(reinterpret_cast<__m128i *>(d + 8 * h), lo);
+					_mm_storel_epi64(reinterpret_cast<__m128i *>(d + 64 + 4 * h), _mm_shuffle_epi32(r, _MM_SHUFFLE(3, 1, 2, 0)));
+					continue;
+				}
 				if (cls == ACMHIP_BP_BYTE) {
 					lo = _mm_packs_epi16(xa, xb);                   /* every index in [-128, 127]: no saturation */
 					hi = lo;
@@ -334,6 +353,46 @@ bool put_row_sse(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool
 }
 #endif
 
+/* the 12-bit class of the chunk kernel's form: idx = 256 hi + lo, lo a signed byte, hi a signed NIBBLE (idx in [-2176, 1919]).  Per residue
+ * c: 64 low bytes, then 32 bytes of high nibbles in the order the kernel's lanes take them - the lane that feeds columns q = 16 ks ..
+ * 16 ks + 15 of the class to the matrix instruction reads 8 bytes at 8 ks: dword d < 2 holds its elements 8 d .. 8 d + 7, element 8 d + b
+ * (b < 4) in the HIGH nibble of byte b and element 8 d + 4 + b in the low one, so that x & 0xf0f0f0f0 and (x << 4) & 0xf0f0f0f0 are the
+ * operand bytes (hi << 4: signed bytes as they stand) of elements 8 d .. + 3 and 8 d + 4 .. + 7 */
+void put_row_nib12(const int16_t *src, size_t sigma, uint8_t *dst)
+{
+	for (size_t c = 0; c < sigma; c++) {
+		uint8_t *d = dst + c * 96;
+		int hi[64];
+		for (size_t q = 0; q < 64; q++) {
+			const int x = src[c + q * sigma];
+			const int lo = (int8_t)(uint8_t)x;
+			d[q] = (uint8_t)lo;
+			hi[q] = (x - lo) >> 8;                  /* [-8, 7] */
+		}
+		for (size_t ks = 0; ks < 4; ks++)
+			for (size_t dw = 0; dw < 2; dw++)
+				for (size_t b = 0; b < 4; b++) {
+					const size_t q0 = 16 * ks + 8 * dw;
+					d[64 + 8 * ks + 4 * dw + b] = (uint8_t)(((hi[q0 + b] & 15) << 4) | (hi[q0 + 4 + b] & 15));
+				}
+	}
+}
+void get_row_nib12(const uint8_t *src, size_t sigma, int16_t *dst)
+{
+	for (size_t c = 0; c < sigma; c++) {
+		const uint8_t *d = src + c * 96;
+		for (size_t ks = 0; ks < 4; ks++)
+			for (size_t dw = 0; dw < 2; dw++)
+				for (size_t b = 0; b < 4; b++) {
+					const size_t q0 = 16 * ks + 8 * dw;
+					const uint8_t n = d[64 + 8 * ks + 4 * dw + b];
+					const int h0 = (int)(int8_t)(n & 0xF0) >> 4, h1 = (int)(int8_t)(uint8_t)(n << 4) >> 4;
+					dst[c + (q0 + b) * sigma] = (int16_t)(256 * h0 + (int)(int8_t)d[q0 + b]);
+					dst[c + (q0 + 4 + b) * sigma] = (int16_t)(256 * h1 + (int)(int8_t)d[q0 + 4 + b]);
+				}
+	}
+}
+
 /* one row at width class cls: per residue c < sigma the qn indices of columns c + q * sigma */
 void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, uint8_t *dst)
 {
@@ -341,6 +400,10 @@ void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool spl
 	if (put_row_sse(src, sigma, qn, cls, split, dst))
 		return;
 #endif
+	if (split && cls == ACMHIP_BP_NIB12) {
+		put_row_nib12(src, sigma, dst);
+		return;
+	}
 	for (size_t c = 0; c < sigma; c++) {
 		if (cls == ACMHIP_BP_WORD) {
 			uint8_t *d = dst + c * 2 * qn;
@@ -376,6 +439,10 @@ void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool spl
 }
 void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, int16_t *dst)
 {
+	if (split && cls == ACMHIP_BP_NIB12) {
+		get_row_nib12(src, sigma, dst);
+		return;
+	}
 	for (size_t c = 0; c < sigma; c++) {
 		if (cls == ACMHIP_BP_WORD) {
 			const uint8_t *d = src + c * 2 * qn;
@@ -397,8 +464,6 @@ void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, bool spl
 		}
 	}
 }
-/* the chunk kernel's form (64 columns of a residue class side by side): classes 8 and 16 bits only, the 16-bit one as two SIGNED bytes */
-inline bool split_form(size_t qn) { return qn == 64; }
 } // namespace
 
 int acm_mform_begin(AcmMformWriter *w, uint32_t level, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs)
@@ -411,6 +476,7 @@ int acm_mform_begin(AcmMformWriter *w, uint32_t level, uint8_t *out, uint64_t bl
 	w->cols = (size_t)1 << level;
 	w->sigma = w->cols / qn;
 	w->split = split_form(qn);
+	w->nib12 = nib12_level(level);
 	w->out = out;
 	w->blob_base = blob_base;
 	w->pairs = pairs;
@@ -453,7 +519,8 @@ int acm_mform_put_pair(AcmMformWriter *w, const int16_t *src)
 #endif
 	if (w->split && hi >= 32640)
 		return ACMHIP_ERR_RANGE;          /* 256 hi + lo with two signed bytes ends at 32639: such a stream stays in the int16 form */
-	const uint32_t cls = (!w->split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE : ACMHIP_BP_WORD;
+	const uint32_t cls = (!w->split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE :
+			     (w->nib12 && lo >= -2176 && hi <= 1919) ? ACMHIP_BP_NIB12 : ACMHIP_BP_WORD;
 	if (((w->blob_base + w->at) >> 6) >= (1ull << 30))
 		return ACMHIP_ERR_ARG;
 	w->pairs[w->npairs++] = (acmhip_mform_pair)(((w->blob_base + w->at) >> 6) << 2 | cls);
@@ -477,7 +544,7 @@ int acm_mform_get_pair(uint32_t level, const uint8_t *blob, acmhip_mform_pair en
 		return ACMHIP_ERR_ARG;
 	const size_t cols = (size_t)1 << level, sigma = cols / qn;
 	const uint32_t cls = entry & 3;
-	if (cls < (split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
+	if (cls < ((split_form(qn) && !nib12_level(level)) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
 		return ACMHIP_ERR_ARG;
 	const uint8_t *src = blob + ((uint64_t)(entry >> 2) << 6);
 	const size_t rowb = pair_bytes(level, cls) / 2;

@@ -36,16 +36,30 @@ def bind(path):
     L.acmhip_plan_time.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_int, C.POINTER(C.c_float)]
     L.acmhip_plan_create_packed.argtypes = [vp, C.POINTER(capi.StreamDesc), sz, C.POINTER(capi.PackedStream), C.POINTER(capi.Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_bind_mform.argtypes = [vp, vp, vp]
+    L.acmhip_mform_tile_rows.argtypes = [C.c_uint]
+    L.acmhip_mform_bytes.argtypes = [C.c_uint, C.c_uint64]
+    L.acmhip_mform_bytes.restype = C.c_uint64
+    L.acmhip_mform_pairs.argtypes = [C.c_uint64]
+    L.acmhip_mform_pairs.restype = C.c_uint64
+    L.acmhip_mform_rows.argtypes = [C.c_uint, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
     return L
 
 
 class Variant:
-    def __init__(self, path, descs, mform=None, d_mform=None):
+    def __init__(self, path, descs, mform=None, d_mform=None, own_form=None):
         from libacm_amd import capi
         path, _, env = path.partition("@")            # lib.so@ACM_K2_ABL=17: environment set around this library's launches
         self.env = dict(kv.split("=", 1) for kv in env.split(",") if kv)
         self.name = os.path.basename(path).replace(".so", "") + ("@" + env if env else "")
         self.L = bind(path)
+        if own_form is not None:
+            # --own-form: this library's OWN stager writes the byte-plane arena it reads (builds whose forms differ)
+            idx, dev0, threads = own_form
+            mfa = capi.mform_streams(idx, descs, threads=threads, L=self.L)
+            d_mform = mfa.upload(dev0)
+            mform = mfa.streams
+            self.form_bytes = mfa.nbytes
+            print("# %s: its own byte-plane form, %.1f MB, pairs by class code 1 / 2 / 3: %s" % (self.name, mfa.nbytes / 1e6, list(mfa.class_counts()[1:4])), flush=True)
         self.dev = C.c_void_p()
         rc = self.L.acmhip_device_open(0, None, C.byref(self.dev))
         if rc:
@@ -98,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--allow-wrong", default="")
     ap.add_argument("--form", choices=["int16", "byteplane"], default="int16")
+    ap.add_argument("--own-form", action="store_true", help="byte-plane form staged by every library's own stager (builds whose forms differ)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     from libacm_amd import capi, workload
@@ -106,15 +121,18 @@ def main():
     bufs = b.upload(dev)
     allow = set(x for x in a.allow_wrong.split(",") if x)
     mf = d_mf = None
-    if a.form == "byteplane":
+    if a.form == "byteplane" and not a.own_form:
         mfa = capi.mform_streams(b.idx, b.descs, threads=max(4, min(64, workload.usable_cpus())))
         d_mf = mfa.upload(dev)
         mf = mfa.streams
-    vs = [Variant(p, b.descs, mf, d_mf) for p in a.libs]
+    own = (b.idx, dev, max(4, min(64, workload.usable_cpus()))) if a.own_form else None
+    vs = [Variant(p, b.descs, mf, d_mf, own) for p in a.libs]
     host = np.empty(b.pcm_words, dtype=np.uint16)
     ref = None
     for v in vs:
         print("# first launch of", v.name, flush=True)
+        dev.memset(bufs[2], 0xA5, 2 * b.pcm_words)     # nothing of another library's PCM survives a launch that skips a tile
+        dev.sync()
         v.setenv(True)
         v.launch(bufs)
         v.sync()

@@ -7,7 +7,13 @@ set -u
 # PROFILE_LIGHT=1: kernel trace + the two traffic passes + the clock pass only (big workloads whose staging takes minutes)
 TAG=${1:-r3}; shift || true
 OUT=gpurun_out/prof_$TAG
+# one summary = one build: refuse a directory that already holds a collection (round 5 merged four builds into one summary that way)
+if [ -d "$OUT" ] && [ -n "$(ls -A "$OUT" 2>/dev/null)" ]; then
+  echo "run_profile.sh: $OUT is not empty - pick another tag or remove it (a summary must come from ONE build)" >&2; exit 2
+fi
 mkdir -p $OUT
+# what was profiled: hash of the kernel source and of the library on this box
+{ echo "tag $TAG"; echo "args $*"; date -u +"utc %Y-%m-%dT%H:%M:%SZ"; sha256sum libacm_amd/csrc/acm_kernels.hip libacm_amd/csrc/acm_hip_api.cpp libacm_amd/lib/libacm_hip.so bench.py; } > $OUT/BUILD_STAMP.txt 2>&1
 export TMPDIR=/tmp
 ARGS="--steps 100 --warmup 20 --no-cpu --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err

@@ -8,6 +8,11 @@ from collections import defaultdict
 
 root = sys.argv[1]
 print("# profile summary for", root)
+stamp = os.path.join(root, "BUILD_STAMP.txt")
+if os.path.exists(stamp):
+    print("## build stamp (one collection = one build; run_profile.sh refuses a directory that already holds one)")
+    for line in open(stamp):
+        print("  " + line.rstrip())
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("## kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
     with open(f) as fh:

@@ -25,7 +25,8 @@ int main(int argc, char **argv) {
     for (uint32_t r = 0; r + TR <= nrows; r += TR) {
       const uint64_t rh = r >= 2 ? r - 2 : 0;
       tiles.push_back(AcmTile2{ p0 + r / 2, i * per + r * cols, (uint32_t)(i * nblocks + rh / rows), (uint32_t)(rh % rows),
-                                (uint32_t)(((1ull << 32) + rows - 1) / rows), (r == 0 ? ACM_TILE_FRESH : 0u) | (r == 1 ? ACM_TILE_ROW1 : 0u) | ((r & 1) ? ACM_TILE_ODD : 0u) });
+                                (uint32_t)(((1ull << 32) + rows - 1) / rows), (r == 0 ? ACM_TILE_FRESH : 0u) | (r == 1 ? ACM_TILE_ROW1 : 0u) | ((r & 1) ? ACM_TILE_ODD : 0u) |
+                                ((rh % rows) + (r + TR - 1 - rh) < rows ? ACM_TILE_ONEBLOCK : 0u) });
     }
   }
   for (int k = 0; k < 64; k++) pairs.push_back(0);

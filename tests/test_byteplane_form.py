@@ -63,9 +63,11 @@ def test_round_trip(level, rows, pwr_max):
     # every pair at the narrowest class that holds it, one behind the other
     rowsv = s.idx[:nrows * cols].reshape(nrows // 2, 2 * cols).astype(np.int64)
     lo, hi = rowsv.min(axis=1), rowsv.max(axis=1)
-    want_cls = np.where((lo >= -8) & (hi <= 7) & (not split), 1, np.where((lo >= -128) & (hi <= 127), 2, 3))
+    nib12 = split and level <= 12                        # the chunk kernel's own levels: a 12-bit class (signed low byte + signed high nibble)
+    want_cls = np.where((lo >= -8) & (hi <= 7) & (not split), 1, np.where((lo >= -128) & (hi <= 127), 2,
+                        np.where((lo >= -2176) & (hi <= 1919) & nib12, 1, 3)))
     assert np.array_equal(cls[1:], want_cls)
-    size = np.array([0, cols, 2 * cols, 4 * cols])[cls]
+    size = np.array([0, 3 * cols if nib12 else cols, 2 * cols, 4 * cols])[cls]
     assert np.array_equal(off[1:], off[:-1] + size[:-1])
     assert off[-1] + size[-1] + 64 <= mf.data.size <= capi.lib().acmhip_mform_bytes(level, nrows) + 256
     back = capi.mform_unrows(level, mf.data, pairs, nrows)
@@ -86,11 +88,57 @@ def test_round_trip(level, rows, pwr_max):
             assert mf.data[at + 2 * qn * c + q] == (x & 0xFF) ^ 0x80 and mf.data[at + 2 * qn * c + qn + q] == (x >> 8) & 0xFF
         elif k == 2:
             assert mf.data[at + qn * c + q] == x & 0xFF
+        elif split:
+            # 12 bits: per residue 64 signed low bytes, then 32 bytes of signed high nibbles in lane order - lane ks (columns 16 ks .. + 15
+            # of the class) reads 8 bytes at 8 ks: dword d holds its elements 8 d .. 8 d + 7, element 8 d + b in the HIGH nibble of byte b,
+            # element 8 d + 4 + b in the low one
+            lo_s = ((x & 0xFF) ^ 0x80) - 0x80
+            h = (x - lo_s) >> 8
+            assert -8 <= h <= 7 and mf.data[at + 96 * c + q] == lo_s & 0xFF
+            ks, e = divmod(q, 16)
+            dw, e8 = divmod(e, 8)
+            byte = int(mf.data[at + 96 * c + 64 + 8 * ks + 4 * dw + (e8 % 4)])
+            assert ((byte >> 4) if e8 < 4 else (byte & 15)) == h & 15
         else:
             j, i = divmod(q, 8)
             nib = 2 * (i % 4) + (i // 4)
             byte = mf.data[at + (qn // 2) * c + 4 * j + nib // 2]
             assert (byte >> (4 * (nib % 2))) & 15 == x + 8
+
+
+def test_twelve_bit_class():
+    """levels 8-12 (acm_chunk): a row pair whose indices fit a signed low byte + a signed high nibble, [-2176, 1919], takes 1.5 bytes per
+    index; one index beyond either end and the pair is written at 16 bits.  Levels 13 / 14 (the same form read by acm_tile2) never get it."""
+    L = capi.lib()
+    for level in (8, 9, 10, 11, 12, 13):
+        cols, tr = 1 << level, L.acmhip_mform_tile_rows(level)
+        nrows = 2 * max(tr, 2) + 2
+        rng = np.random.default_rng(1200 + level)
+        for lo_v, hi_v, want in ((-2176, 1919, 1), (-2177, 0, 3), (0, 1920, 3), (-128, 127, 2), (-129, 0, 1), (0, 128, 1)):
+            idx = rng.integers(max(lo_v, -2176), min(hi_v, 1919) + 1, size=nrows * cols).astype(np.int16)
+            idx[2 * cols + 7], idx[3 * cols + cols - 3] = lo_v, hi_v         # the extremes sit in the second pair
+            if want == 2:
+                idx[:] = np.clip(idx, -128, 127)
+            buf = np.zeros(L.acmhip_mform_bytes(level, nrows) + 256, dtype=np.uint8)
+            pairs = np.zeros(nrows // 2 + 33, dtype=np.uint32)
+            used = C.c_uint64()
+            assert L.acmhip_mform_rows(level, idx.ctypes.data, nrows, buf.ctypes.data, 0, pairs.ctypes.data, C.byref(used)) == 0
+            cls = pairs[1:nrows // 2 + 1] & 3
+            if level >= 13:
+                assert (cls >= 2).all()
+            else:
+                assert cls[1] == want, (level, lo_v, hi_v, cls)
+                if want == 1:
+                    nxt = (int(pairs[3]) >> 2) - (int(pairs[2]) >> 2)
+                    assert nxt * 64 == 3 * cols
+            assert np.array_equal(capi.mform_unrows(level, buf, pairs, nrows), idx)
+    # a stream of pwr 8 ... 10 blocks: every pair at 12 bits, 1.5 bytes per index
+    level, rows = 9, 16
+    s = capi.stage_file(make_stream(47000, level, rows, 12, pwr_min=8, pwr_max=10))
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows << level, level=level, rows=rows, nrows=s.info.blocks * rows, row_begin=0)
+    mf = capi.mform_streams(s.idx, [d])
+    assert ((mf.pairs[1:1 + s.info.blocks * rows // 2] & 3) == 1).all()
+    assert mf.data.size <= 1.5 * (s.info.blocks * rows << level) + (2 << level) + 64 + 256
 
 
 def test_split_form_range():

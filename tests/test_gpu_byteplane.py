@@ -81,6 +81,28 @@ def test_byteplane_width_classes(dev, force_k2, level, rows, pwr_min, pwr_max):
     assert st.mform_tiles >= 9
 
 
+@pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("rows,pwr_min,pwr_max,val_max", [(16, 8, 10, 255), (2, 8, 10, 255), (64, 9, 9, 65535), (16, 6, 12, 255), (1, 6, 12, 255),
+                                                           (6, 7, 11, 65535), (4, 8, 10, 65535), (250, 10, 10, 255)])
+def test_byteplane_twelve_bit_class(dev, force_k2, level, rows, pwr_min, pwr_max, val_max):
+    """levels 8-12: pairs whose indices fit a signed low byte and a signed high nibble travel at 12 bits (pwr 8-10).  Streams that are 12
+    bits throughout (the chunk kernel's fast path on nibble planes: one val per chunk in the middle of a block, the general path with
+    its conversions at every block boundary), every neighbourhood of 8 / 12 / 16-bit pairs a block boundary can produce (pwr 6-12, block
+    heights 1 ... 16), and row values beyond 16 bits as scaled (val_max 65535: the general path at levels 10-12) - against the CPU oracle"""
+    tr = plan_rows(level)
+    nblocks = max(3, (11 * tr + rows - 1) // rows + 1)
+    f = make_stream(31000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=3, pwr_min=pwr_min, pwr_max=pwr_max, val_max=val_max)
+    s = capi.stage_file(f)
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows << level, level=level, rows=rows, nrows=s.info.blocks * rows, row_begin=0)
+    cc = capi.mform_streams(s.idx, [d]).class_counts()
+    if pwr_min >= 8 and pwr_max <= 10:
+        assert cc[1] > 0 and cc[3] == 0, cc             # (a pair may happen to fit 8 bits)
+    elif pwr_min == 6 and pwr_max == 12 and rows <= 16:
+        assert cc[1] > 0, cc
+    st = check(dev, [f])
+    assert st.mform_tiles >= 9
+
+
 @pytest.mark.parametrize("fmt", [capi.FMT_S16LE, capi.FMT_S16BE, capi.FMT_U16LE, capi.FMT_U16BE])
 def test_byteplane_batch(dev, force_k2, fmt):
     """many streams in one plan, levels with and without the form side by side: workgroup runs start inside streams (lead-in tiles)

@@ -31,8 +31,8 @@ def test_full_size_config_2(dev):
     assert len(b.descs) == 4000 and {d.level for d in b.descs} == {7, 8, 9} and b.samples > 1_800_000_000
     with ThreadPoolExecutor(max_workers=threads) as ex:
         want = list(ex.map(lambda k: oracle_crc(b.files[k], b.descs[k].n_emit), range(4000)))
-    # (a) one plan over the staged arena: on the int16 form, then with the byte-plane form of the whole tiles bound (first pass on the
-    # matrix cores; the ragged tails stay int16)
+    # (a) one plan over the staged arena: with the byte-plane form of the whole tiles bound (first pass on the matrix cores; the
+    # ragged tails stay int16), then on the int16 form
     bufs = b.upload(dev)
     mf = capi.mform_streams(b.idx, b.descs, threads=threads)
     mf_ptrs = mf.upload(dev)
@@ -40,9 +40,11 @@ def test_full_size_config_2(dev):
         plan = capi.Plan(dev, b.descs, packed=mf.streams)
         st = plan.stats()
         assert st.fused_streams == 4000 and st.stagewise_streams == 0 and st.samples == b.samples and st.mform_tiles > 100000
-        for bind in ((None, None), mf_ptrs):
+        # the byte-plane form (the headline kernel family) FIRST, and the WHOLE PCM arena poisoned in front of every form's launch:
+        # a kernel that skipped a tile would leave 0xA5A5 there, not the previous form's correct PCM (Weak 1a)
+        for bind in (mf_ptrs, (None, None)):
             plan.bind_mform(*bind)
-            dev.upload(bufs[2], np.zeros(1 << 20, dtype=np.uint16))
+            dev.memset(bufs[2], 0xA5, 2 * b.pcm_words)
             plan.launch(*bufs)
             dev.sync()
             host = np.empty(b.pcm_words, dtype=np.uint16)
@@ -95,8 +97,9 @@ def test_full_size_config_4(dev):
         plan = capi.Plan(dev, descs, packed=[mf.streams[k % distinct] for k in range(len(descs))])
         st = plan.stats()
         assert st.samples == 65536 * per and st.fused_streams == 65536 and st.mform_tiles == 65536 * 128 // capi.lib().acmhip_mform_tile_rows(11)
-        for bind in ((None, None), mf_ptrs):                  # the int16 form (vector-ALU first pass), then the byte-plane form
+        for bind in (mf_ptrs, (None, None)):                  # the byte-plane form first, then the int16 form (vector-ALU first pass)
             plan.bind_mform(*bind)
+            dev.memset(d_pcm, 0xA5, len(descs) * pad * 2)     # all 34 GB: nothing of another launch's PCM survives (Weak 1a)
             plan.launch(d_idx, d_hdr, d_pcm)
             dev.sync()
             # read back replica by replica (1024 streams = 537 MB each)
@@ -108,8 +111,6 @@ def test_full_size_config_4(dev):
                     got = list(ex.map(lambda k: zlib.crc32(raw[2 * k * pad: 2 * (k * pad + per)]), range(distinct)))
                 bad = [k for k in range(distinct) if got[k] != want[k]]
                 assert not bad, (bind[0] is not None, r, bad[:10])
-                if r == 0:
-                    dev.upload(d_pcm, np.zeros(1 << 20, dtype=np.uint16))       # the next form must write this again
         plan.destroy()
     finally:
         for p in (d_idx, d_hdr, d_pcm) + mf_ptrs:
