@@ -493,7 +493,8 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
         _, ms = time_plan(dev, pl, bufs, steps, 5, lambda: None)
         rate = b.samples * steps / (ms * 1e-3)
         return {"msamples_s": round(rate / 1e6, 1), "algo_gbs": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9, 1),
-                "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4), "verified_streams": check()}
+                "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(ms / steps, 4),
+                "verified_streams": check()}
     out = {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "channels": channels, "steps": steps, "tiles": int(tiles)}
     int16 = timed(plan)
     if mf is not None:
@@ -681,7 +682,7 @@ def main():
             d2 = mf2.upload(dev)
             p2 = capi.Plan(dev, batch.descs, packed=mf2.streams)
             p2.bind_mform(*d2)
-            time_form("byteplane (row pairs at 4 / 8 / 16 bits per index, in matrix-core operand order)", p2,
+            time_form("byteplane (row pairs at 8 / 12 / 16 bits per index - 4 / 8 / 16 at level 7 - in matrix-core operand order)", p2,
                       {"host_reorder_seconds": round(tm_, 2), "staged_bytes_per_sample": round(mf2.nbytes / batch.samples, 3)})
             p2.destroy()
             for p_ in d2:
@@ -790,7 +791,7 @@ def main():
     # collect counters on itself.  The file records the kernel source it was measured on; another source -> null.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r5_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r6_traffic.json")) as f:
             tj = json.load(f)
         key = "level%d_%dx%dblocks_rows%d" % (args.level, args.streams, args.blocks, args.rows)
         if args.channels != 1:
@@ -799,7 +800,7 @@ def main():
             key += "_" + args.form
         if args.workload == "uniform" and tj.get("kernel_source_sha16") == kernel_source_sha() and key in tj:
             traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r5_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
+            traffic_src = "profiles/r6_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, same kernel source %s)" % tj["kernel_source_sha16"]
     except Exception:
         traffic = None
 
@@ -839,9 +840,9 @@ def main():
                    "staged_form": ("packed: width class per column pair and 16-row group + residuals at 0/4/8/16 bits (%.3f B/sample), "
                                    "{val, pwr} per block; written by the host stager (acmhip_pack_tiles)" % (pk.nbytes / batch.samples))
                                   if pk else
-                                  ("byteplane: every row pair's indices at the narrowest of 4 / 8 / 16 bits that holds them (8 / 16 at a level of the chunk "
-                                   "kernel, where a 16-bit index is two signed bytes; %.3f B/sample here; "
-                                   "pairs at 4 / 8 / 16 bits: %d / %d / %d), per row in groups of %s columns a residue class apart (the order the "
+                                  ("byteplane: every row pair's indices at the narrowest width class that holds them - 8 / 12 / 16 bits at a level of the chunk "
+                                   "kernel (12: a signed low byte + a signed high nibble; 16: two signed bytes), 4 / 8 / 16 at level 7; %.3f B/sample here; "
+                                   "pairs by class code 1 (12 bits; 4 at level 7) / 2 (8 bits) / 3 (16 bits): %d / %d / %d), per row in groups of %s columns a residue class apart (the order the "
                                    "matrix cores read operands in) + a 4-byte entry per pair + {val, pwr} per block; written by the host stager "
                                    "(acm_stage_file + acmhip_mform_rows, %.2f s for this batch)" % (
                                        (mf.nbytes / batch.samples,) + tuple(int(x) for x in mf.class_counts()[1:4]) +
@@ -852,8 +853,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_committed_profile": traffic_committed, "frac_of_peak_on_measured_traffic": frac_measured,
                      "algorithmic_bytes_per_launch": int(batch.samples) * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": (("acm_chunk<%s>: six stages on v_mfma_i32_16x16x64_i8, one wavefront per 2048-sample chunk, one LDS pass group behind "
-                                 "(+ acm_fused_tile on ragged tails)" % lv_txt)
+                     "kernel": (("acm_chunk<%s>: six stages on v_mfma_i32_16x16x64_i8, one wavefront per 2048-sample chunk, one LDS pass group behind; "
+                                 "chunks inside one block on the scalar fast path (+ acm_fused_tile on ragged tails)" % lv_txt)
                                 if mf and args.workload == "uniform" and capi.lib().acmhip_mform_group(args.level) == 64 and args.level <= 12 else
                                 ("acm_tile2<TileCfg<%s,%d,%d>, first six stages on v_mfma_i32_16x16x64_i8 (a row pair per tile, sixteen residue classes per "
                                  "wavefront), LDS passes with barriers behind> (+ the prefix + plane pair on ragged tails)" % (
@@ -951,6 +952,19 @@ def main():
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
+            # ... and their key figures inside `roofline`, which the driver's record keeps whole (task 4): fraction of the 8 TB/s
+            # roofline at 4 B/sample, the launch's duration from HIP events, and how many streams' PCM was CRC-compared with the oracle's
+            oc = {}
+            for e in extra:
+                if "frac_hbm" not in e:
+                    continue
+                name = ("configs4_65536_stereo_streams_level11_rows64" if e.get("config") else
+                        "configs1_1024_streams_level7_rows16" if (e["level"], e["rows"], e["blocks"]) == (7, 16, 1000) else
+                        "level%d_rows%d_%dstreams" % (e["level"], e["rows"], e["streams"]))
+                oc[name] = {"frac": e["frac_hbm"], "launch_ms": e.get("launch_ms"), "verified_streams": e.get("verified_streams"),
+                            "staged_form": e.get("staged_form"), "staged_bytes_per_sample": e.get("staged_bytes_per_sample"),
+                            "frac_int16_form": (e.get("int16_form") or {}).get("frac_hbm")}
+            out["roofline"]["other_configs"] = oc
         if not args.no_extra and not args.no_cpu and len(batch.files) > 4:
             # informational: file bytes -> PCM in host memory through acm_batch_decode (bit parsing on the host pool
             # or on device lanes, PCIe both ways, pipelined); by contract this is NOT `value`

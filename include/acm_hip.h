@@ -118,6 +118,18 @@ int  acmhip_memset(acmhip_device *dev, void *dptr, int byte, size_t bytes);     
                                                                                          * see every sample written (tests, bench) poisons the PCM arena first */
 
 /*
+ * Host synthesis (csrc/acm_host_synth.cpp): the SAME contract as a plan over one stream descriptor, on host pointers, without a device -
+ * value = idx * val, the cascade of decode.c:508-577, the four writers of :617-655, bit-exact.  It is what acm_read() (include/libacm.h)
+ * runs on a box without a usable HIP device, and for streams shorter than acmhip_host_synth_limit() samples while no device handle is
+ * open in the process (bringing the HIP runtime up costs more than such a stream's whole decode).  The plan and batch calls never use it.
+ * limit: default 8 Msamples; 0 = the host path only where no device exists; UINT64_MAX = never the device from acm_read().
+ */
+int  acmhip_host_synth(const acmhip_stream_desc *stream, const int16_t *idx, const acmhip_blkhdr *hdr,
+		       const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm);
+void acmhip_set_host_synth_limit(uint64_t samples);
+uint64_t acmhip_host_synth_limit(void);
+
+/*
  * Build the launch tables for `n` streams (+ optional H1 patches).  Streams may
  * mix levels/rows/lengths freely.  Replaces nothing in the reference (it has
  * no batching); it is what lets one launch cover thousands of decode_block()s.

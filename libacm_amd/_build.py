@@ -50,7 +50,9 @@ def build_synth(force=False):
     return out
 
 
-HIP_SOURCES = ["acm_kernels.hip", "acm_parse.hip", "acm_hip_api.cpp", "acm_fill.cpp", "acm_pack.cpp", "acm_stream.cpp", "acm_batch.cpp"]
+HIP_SOURCES = ["acm_kernels.hip", "acm_parse.hip", "acm_hip_api.cpp", "acm_fill.cpp", "acm_pack.cpp", "acm_stream.cpp", "acm_batch.cpp",
+               "acm_host_synth.cpp"]
+HOST_ONLY = {"acm_host_synth.cpp"}      # plain C++ (CPU-dispatched AVX2 inside): no device pass
 
 
 def build_hip(force=False):
@@ -70,7 +72,9 @@ def build_hip(force=False):
                     cmd.insert(1, "-DACM_TUNING=1")
                 extra = os.environ.get("ACM_HIPCC_EXTRA", "").split()           # compiler-flag experiments
                 cmd[1:1] = extra
-                if s.endswith(".cpp"):
+                if os.path.basename(s) in HOST_ONLY:
+                    cmd = [c for c in cmd if not c.startswith("--offload-arch")]
+                elif s.endswith(".cpp"):
                     cmd.insert(1, "-x")
                     cmd.insert(2, "hip")
                 _run(cmd)

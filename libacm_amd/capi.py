@@ -16,6 +16,7 @@ FMT_S16LE, FMT_S16BE, FMT_U16LE, FMT_U16BE = 0, 1, 2, 3
 PLAN_AUTO, PLAN_STAGEWISE = 0, 1
 PLAN_FORM_ONLY, PLAN_UPLOAD_ASYNC = 0x100, 0x200          # modifiers, or-ed in (acm_hip.h)
 ERR_NO_DEVICE = -101
+ERR_ARG = -103
 ERR_RANGE = -105
 
 
@@ -83,7 +84,7 @@ class BatchTiming(C.Structure):
 ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
-    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_memset", "acmhip_plan_create", "acmhip_plan_destroy",
+    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_memset", "acmhip_host_synth", "acmhip_set_host_synth_limit", "acmhip_host_synth_limit", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file", "acm_stage_file_mform",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
@@ -133,6 +134,10 @@ def lib():
     L.acmhip_upload.argtypes = [vp, vp, vp, sz]
     L.acmhip_download.argtypes = [vp, vp, vp, sz]
     L.acmhip_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.acmhip_host_synth.argtypes = [C.POINTER(StreamDesc), vp, vp, vp, sz, C.c_uint, vp]
+    L.acmhip_set_host_synth_limit.argtypes = [C.c_uint64]
+    L.acmhip_set_host_synth_limit.restype = None
+    L.acmhip_host_synth_limit.restype = C.c_uint64
     L.acmhip_plan_create.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_destroy.argtypes = [vp]
     L.acmhip_plan_destroy.restype = None

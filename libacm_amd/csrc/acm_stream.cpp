@@ -107,7 +107,7 @@ bool default_device_pending()
 	return g_dev_state == 1;
 }
 
-acmhip_device *default_device()
+acmhip_device *default_device(bool quiet = false)
 {
 	std::unique_lock<std::mutex> lock(g_dev_mutex);
 	if (g_dev_state == 0) {
@@ -117,7 +117,7 @@ acmhip_device *default_device()
 		lock.lock();
 	}
 	g_dev_cv.wait(lock, []() { return g_dev_state == 2; });
-	if (!g_dev && !g_dev_reported) {
+	if (!g_dev && !g_dev_reported && !quiet) {
 		g_dev_reported = true;
 		fprintf(stderr, "libacm_hip: cannot decode: %s\n", g_dev_error);
 	}
@@ -163,6 +163,7 @@ struct HipStream {
 	acmhip_plan *plan = nullptr;
 	acmhip_stream_desc plan_desc{};
 	bool plan_valid = false;
+	bool on_host = false;                   /* this stream's windows are synthesised by acm_host_synth.cpp */
 	bool pcm_valid = false;
 	unsigned pcm_fmt = 0;
 };
@@ -271,15 +272,48 @@ int fill_window(HipStream *hs)
 	return 1;
 }
 
-/* synthesise the current window on the GPU in sample layout `fmt`; 0 or ACM_ERR_OTHER */
+/* is a device handle open in this process already (without bringing the runtime up to find out)? */
+bool default_device_open()
+{
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	return g_dev_state == 2 && g_dev != nullptr;
+}
+
+/* the current window on the host (acm_host_synth.cpp): same staged arrays, same descriptor, same bytes out */
+int synth_window_host(HipStream *hs, unsigned fmt)
+{
+	ACMStream *a = &hs->pub;
+	acmhip_stream_desc d{};
+	d.level = a->info.acm_level;
+	d.rows = a->info.acm_rows;
+	d.nrows = (hs->carry + hs->win_blocks) * a->info.acm_rows;
+	d.row_begin = hs->carry * a->info.acm_rows;
+	d.n_emit = (uint64_t)hs->win_blocks * a->block_len;
+	if (acmhip_host_synth(&d, hs->h_idx, hs->h_hdr, hs->patches.data(), hs->patches.size(), fmt, hs->h_pcm) != ACMHIP_OK)
+		return ACM_ERR_OTHER;
+	hs->pcm_valid = true;
+	hs->pcm_fmt = fmt;
+	return 0;
+}
+
+/* synthesise the current window in sample layout `fmt`; 0 or ACM_ERR_OTHER.  On the GPU - unless there is none, or the stream is short and
+ * no device handle is open yet (include/acm_hip.h, acmhip_host_synth_limit): a stream stays on the side its first window took */
 int synth_window(HipStream *hs, unsigned fmt)
 {
 	ACMStream *a = &hs->pub;
 	const size_t bl = a->block_len;
+	if (hs->on_host)
+		return synth_window_host(hs, fmt);
 	if (!hs->dev) {
-		hs->dev = default_device();
-		if (!hs->dev)
-			return ACM_ERR_OTHER;
+		if ((uint64_t)a->total_values < acmhip_host_synth_limit() && !default_device_open() && !default_device_pending()) {
+			hs->on_host = true;
+			return synth_window_host(hs, fmt);
+		}
+		hs->dev = default_device(/*quiet=*/true);
+		if (!hs->dev) {
+			hs->on_host = true;             /* no usable device on this box: the reference decodes anywhere, so does this */
+			return synth_window_host(hs, fmt);
+		}
 	}
 	if (!hs->d_idx) {
 		const size_t blocks = (size_t)hs->win_cap + hs->carry_max;

@@ -229,6 +229,10 @@ static void decode_one(const char *src, const char *dst)
 		fprintf(stderr, "%s: %s\n", src, acm_strerror(err));
 		return;
 	}
+	/* a long stream goes to the GPU: let it come up on a thread of the library's own while this one parses.  A short one is synthesised
+	 * on the host by acm_read() itself (acmhip_host_synth_limit) and never pays for the runtime */
+	if ((unsigned long long)acm_pcm_total(acm) * acm_channels(acm) >= acmhip_host_synth_limit())
+		acmhip_prewarm();
 	if (!cfg.no_output) {
 		if (strcmp(dst, "-") == 0) {
 			out = stdout;
@@ -844,8 +848,6 @@ int main(int argc, char *argv[])
 	detach_teardown();              /* from here on this is the child: nothing has touched the GPU yet */
 	if (batch)
 		return decode_batch(argc - optind, argv + optind);
-	/* decoding for sure: the GPU comes up on a thread of the library's own while this one opens and parses */
-	acmhip_prewarm();
 	if (outname) {
 		if (optind + 1 != argc)
 			usage(1);

@@ -10,6 +10,6 @@ python3 -c "from libacm_amd import _build; _build.build_hip()"
 mkdir -p libacm_amd/lib/exp
 hipcc -O3 -g1 -std=c++17 -fPIC -Wall -Wextra --offload-arch=gfx950 -I include -I libacm_amd/csrc "$@" -c $SRC -o libacm_amd/lib/exp/$NAME.kernels.o
 hipcc -shared -fPIC --offload-arch=gfx950 -o libacm_amd/lib/exp/$NAME.so libacm_amd/lib/exp/$NAME.kernels.o \
-  libacm_amd/lib/acm_parse.hip.o libacm_amd/lib/acm_hip_api.cpp.o libacm_amd/lib/acm_fill.cpp.o libacm_amd/lib/acm_pack.cpp.o libacm_amd/lib/acm_stream.cpp.o libacm_amd/lib/acm_batch.cpp.o -lpthread
+  libacm_amd/lib/acm_parse.hip.o libacm_amd/lib/acm_hip_api.cpp.o libacm_amd/lib/acm_fill.cpp.o libacm_amd/lib/acm_pack.cpp.o libacm_amd/lib/acm_stream.cpp.o libacm_amd/lib/acm_batch.cpp.o libacm_amd/lib/acm_host_synth.cpp.o -lpthread
 rm -f libacm_amd/lib/exp/$NAME.kernels.o
 ls -la libacm_amd/lib/exp/$NAME.so

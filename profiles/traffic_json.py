@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_summary.txt files -> profiles/r5_traffic.json: HBM bytes per launch of the tile kernel from the PMC passes
+"""profiles/<tag>_summary.txt files -> profiles/r6_traffic.json: HBM bytes per launch of the tile kernel from the PMC passes
 (FETCH_SIZE x 2 + WRITE_SIZE, KiB units -> bytes; MI355X_MICROARCH.md "HBM"), stamped with the sha256 of the kernel source
 the profile was taken on.  bench.py reports `traffic` only while the source still has that hash.
 usage: python3 profiles/traffic_json.py key=summary.txt [key=summary.txt ...]"""
@@ -28,5 +28,5 @@ for arg in sys.argv[1:]:
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         out[key] = {"fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                     "hbm_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "summary": os.path.basename(path)}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r5_traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r6_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))

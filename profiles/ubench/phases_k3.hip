@@ -1,14 +1,16 @@
 // Diagnostic: where do the cycles of the chunk kernel (acm_chunk) go?  Builds the real kernel source with ACM_STAMPS (s_memtime stamps per
 // phase, per wavefront) on synthetic byte-plane data and prints the phase shares.  Timing only (the PCM is not looked at).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I libacm_amd/csrc -o profiles/ubench/phases_k3.bin profiles/ubench/phases_k3.hip
-//   ./phases_k3 <level> [rows per block = 16] [percent of the blocks at 16 bits = 56]
-#define ACM_STAMPS 1
+//   ./phases_k3 <level> [rows per block = 16] [percent of the blocks at 16 bits = 56] [percent at 12 bits = 0]
+#ifndef NO_STAMPS
+#define ACM_STAMPS 1              /* (-DNO_STAMPS: the plain kernel, for counter collections and timing) */
+#endif
 #include "../../libacm_amd/csrc/acm_kernels.hip"
 #include <cstdio>
 #include <vector>
 int main(int argc, char **argv) {
   const int level = argc > 1 ? atoi(argv[1]) : 9;
-  const uint32_t rows = argc > 2 ? atoi(argv[2]) : 16, pct16 = argc > 3 ? atoi(argv[3]) : 56;
+  const uint32_t rows = argc > 2 ? atoi(argv[2]) : 16, pct16 = argc > 3 ? atoi(argv[3]) : 56, pct12 = argc > 4 ? atoi(argv[4]) : 0;
   const uint32_t nstreams = 1024, nrows = (uint32_t)((1u << 21) >> level), nblocks = (nrows + rows - 1) / rows;
   const uint64_t cols = 1ull << level, per = (uint64_t)nrows * cols;
   const uint32_t TR = (uint32_t)acmk_tile2m_rows(level);
@@ -19,8 +21,8 @@ int main(int argc, char **argv) {
     pairs.push_back((uint32_t)((at >> 6) << 2 | ACMHIP_BP_BYTE)); at += 2 * cols;            /* the pair of zeros in front */
     uint32_t cls = ACMHIP_BP_WORD;
     for (uint32_t p = 0; p < nrows / 2; p++) {
-      if ((2 * p) % rows < 2) { seed = seed * 1664525u + 1013904223u; cls = (seed >> 16) % 100 < pct16 ? ACMHIP_BP_WORD : ACMHIP_BP_BYTE; }
-      pairs.push_back((uint32_t)((at >> 6) << 2 | cls)); at += (cls == ACMHIP_BP_WORD ? 4 : 2) * cols;
+      if ((2 * p) % rows < 2) { seed = seed * 1664525u + 1013904223u; const uint32_t d100 = (seed >> 16) % 100; cls = d100 < pct16 ? ACMHIP_BP_WORD : d100 < pct16 + pct12 ? ACMHIP_BP_NIB12 : ACMHIP_BP_BYTE; }
+      pairs.push_back((uint32_t)((at >> 6) << 2 | cls)); at += (cls == ACMHIP_BP_WORD ? 4 : cls == ACMHIP_BP_NIB12 ? 3 : 2) * cols;
     }
     for (uint32_t r = 0; r + TR <= nrows; r += TR) {
       const uint64_t rh = r >= 2 ? r - 2 : 0;
@@ -47,6 +49,11 @@ int main(int argc, char **argv) {
     if (rc) { printf("launch failed %d\n", rc); return 1; }
     (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
+#ifdef NO_STAMPS
+  printf("acm_chunk level %d, %u rows per block, %u %% / %u %% of the blocks at 16 / 12 bits (staged %.2f B/sample), %zu chunks, no stamps: %.3f ms per launch (best of 8; %.3f of the 8 TB/s roofline at 4 B/sample)\n",
+         level, rows, pct16, pct12, (double)at / (per * nstreams), tiles.size(), best, per * nstreams * 4.0 / best / 8e9);
+  return 0;
+#else
   static unsigned long long h[2048][8];
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_acm_stamps), sizeof(h));
   double sum[8] = {0}; int n = 0;
@@ -60,4 +67,5 @@ int main(int argc, char **argv) {
          tot / n / chunks_per_wave, (double)at / (per * nstreams));
   for (int k = 0; k < 7; k++) if (k != 4) printf("  %-62s %5.1f %%  %8.0f ticks per chunk\n", names[k], 100.0 * sum[k] / tot, sum[k] / n / chunks_per_wave);
   return 0;
+#endif
 }

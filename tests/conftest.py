@@ -18,5 +18,11 @@ def dev():
     """The HIP device handle of the product library.  GPU tests only: no fallback, fails loudly."""
     from libacm_amd import capi
     d = capi.Device(0)
+    # GPU tests test the GPU: acm_read() of the drop-in API goes to the device whatever the stream's length (by default streams below
+    # 8 Msamples are synthesised on the host while no device is open: include/acm_hip.h, acmhip_set_host_synth_limit)
+    L = capi.lib()
+    prev = L.acmhip_host_synth_limit()
+    L.acmhip_set_host_synth_limit(0)
     yield d
+    L.acmhip_set_host_synth_limit(prev)
     d.close()

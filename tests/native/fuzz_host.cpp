@@ -1,8 +1,8 @@
 // Sanitizer harness for the HOST half of the product (bit reader, filler parsers, stream control): built with
 // g++ -fsanitize=address,undefined (GPU sanitizers are not available on the pool; this is the CPU build).
-// Feeds mutated / truncated ACM images through acm_stage_file and through the libacm.h API in
-// decode-and-discard mode (acm_read(NULL) never needs the device).  The device entry points are stubbed: a
-// call into any of them would mean the host path tried to synthesise, which this harness treats as a failure.
+// Feeds mutated / truncated ACM images through acm_stage_file and through the libacm.h API - decode-and-discard reads and reads into a
+// buffer, which the library's host synthesis serves (acm_host_synth.cpp, acmhip_set_host_synth_limit(UINT64_MAX): never the device).
+// The device entry points are stubbed: a call into any of them would mean the host path reached for the GPU, a failure here.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -98,6 +98,11 @@ static void exercise(const std::vector<uint8_t> &img)
 		switch (rnd() % 5) {
 		case 0: acm_seek_pcm(s, rnd() % (acm_pcm_total(s) + 5)); break;
 		case 1: acm_seek_time(s, rnd() % (acm_time_total(s) + 5)); break;
+		case 2: {       /* PCM for real: parsed windows through the host synthesis, every output format */
+			std::vector<uint8_t> out(2 + rnd() % 20000);
+			acm_read_loop(s, out.data(), (unsigned)out.size(), (int)(rnd() & 1), 2, (int)(rnd() & 1));
+			break;
+		}
 		default: acm_read_loop(s, NULL, 2 + rnd() % 20000, 0, 2, 1); break;
 		}
 		(void)acm_raw_tell(s); (void)acm_pcm_tell(s); (void)acm_time_tell(s); (void)acm_bitrate(s);
@@ -108,6 +113,7 @@ static void exercise(const std::vector<uint8_t> &img)
 int main(int argc, char **argv)
 {
 	int iters = argc > 2 ? atoi(argv[2]) : 300, files = 0;
+	acmhip_set_host_synth_limit(~0ull);
 	for (int a = 1; a < argc; a++) {
 		if (a == 2) continue;
 		FILE *f = fopen(argv[a], "rb");

@@ -67,8 +67,10 @@ def test_error_codes_and_strings():
 
 
 @pytest.mark.skipif(capi.device_count() > 0, reason="a HIP device is present")
-def test_no_device_fails_loudly_never_falls_back():
-    """No GPU: parsing-only calls work, anything that needs synthesis returns an error - there is no CPU path."""
+def test_no_device_decodes_on_the_host_and_device_calls_fail_loudly():
+    """No GPU: everything that asks for the DEVICE (handles, plans, pinned memory, the batch call) fails loudly - those calls have no
+    fallback.  acm_read() - the reference's own API, which decodes anywhere (decode.c:826-876) - synthesises on the host with the
+    library's own host code (libacm_amd/csrc/acm_host_synth.cpp; never the test oracle), bit-exact with the goldens."""
     with pytest.raises(capi.AcmHipError):
         capi.Device(0)
     assert capi.lib().acmhip_last_error()
@@ -77,8 +79,11 @@ def test_no_device_fails_loudly_never_falls_back():
     assert s.err == 0
     rc, _ = s.read(0, discard=True)
     assert s.read(64, discard=True)[0] == 64            # decode-and-discard only parses
-    rc, b = s.read(64)                                  # real PCM needs the device
-    assert rc == -1 and b == b""                        # ACM_ERR_OTHER
+    rc, b = s.read(64)
+    o = O.Oracle(src)
+    o.read(64, discard=True)
+    assert rc == 64 and b == o.read(64)[1]              # the PCM behind what was discarded, from the host synthesis
+    o.close()
     s.close()
     p = C.c_void_p()
     assert capi.lib().acmhip_host_alloc(64, C.byref(p)) == capi.ERR_NO_DEVICE

@@ -2,6 +2,8 @@
 
 CPU part: everything that only needs the host parser (open/close ownership, header errors, getters,
 seeking with decode-and-discard, truncation bookkeeping).  GPU part (-m gpu): the PCM itself."""
+import ctypes as C
+
 import pytest
 
 import oracle_api as O
@@ -192,10 +194,28 @@ def test_corrupt_streams_discard():
     s.close()
 
 
-# ------------------------------------------------------------------ GPU
-@pytest.mark.gpu
+# ------------------------------------------------------------------ PCM: on the device (-m gpu) and on the host
+@pytest.fixture(params=["host", pytest.param("device", marks=pytest.mark.gpu)])
+def side(request):
+    """Where acm_read() synthesises: "device" - the GPU, whatever the stream's length (acmhip_set_host_synth_limit(0); -m gpu) -
+    or "host" - the library's own host synthesis (libacm_amd/csrc/acm_host_synth.cpp; what a box without a GPU gets, and short streams
+    by default).  Same goldens, same oracle, bit for bit."""
+    L = capi.lib()
+    L.acmhip_set_host_synth_limit.argtypes = [C.c_uint64]
+    L.acmhip_set_host_synth_limit.restype = None
+    L.acmhip_host_synth_limit.restype = C.c_uint64
+    prev = L.acmhip_host_synth_limit()
+    if request.param == "device":
+        request.getfixturevalue("dev")
+        L.acmhip_set_host_synth_limit(0)
+    else:
+        L.acmhip_set_host_synth_limit(2 ** 64 - 1)
+    yield request.param
+    L.acmhip_set_host_synth_limit(prev)
+
+
 @pytest.mark.parametrize("family", ["F1_matrix", "F2_codes", "F3_corrupt", "F6_headers"])
-def test_pcm_families(dev, family):
+def test_pcm_families(side, family):
     for case in golden()[family]:
         rec = decode_record(ours, golden_file(case["file"]))
         for k in ("open", "status", "words", "sha256", "info", "raw_tell_end"):
@@ -203,8 +223,7 @@ def test_pcm_families(dev, family):
                 assert rec.get(k) == case[k], (case["file"], k)
 
 
-@pytest.mark.gpu
-def test_pcm_truncation_every_byte(dev):
+def test_pcm_truncation_every_byte(side):
     g = golden()["F4_truncation"]
     base = golden_file(g["file"])
     for cut in g["cuts"]:
@@ -213,16 +232,14 @@ def test_pcm_truncation_every_byte(dev):
             assert rec.get(k) == cut[k], (cut["len"], k)
 
 
-@pytest.mark.gpu
-def test_pcm_wavc_and_quirk(dev):
+def test_pcm_wavc_and_quirk(side):
     g = golden()["F5_wavc"]
     for k, fc in (("plain", 0), ("wavc", 0), ("wavc_quirk", -1), ("plain_quirk", -1)):
         rec = decode_record(ours, golden_file(g[k]["file"]), fc)
         assert (rec["sha256"], rec["words"], rec["info"]) == (g[k]["sha256"], g[k]["words"], g[k]["info"])
 
 
-@pytest.mark.gpu
-def test_pcm_api_traces(dev):
+def test_pcm_api_traces(side):
     g = golden()["F7_api"]
     src = golden_file("f7_src")
     s = ours(src)
@@ -250,8 +267,7 @@ def test_pcm_api_traces(dev):
     s.close()
 
 
-@pytest.mark.gpu
-def test_format_switch_mid_stream(dev):
+def test_format_switch_mid_stream(side):
     """the window is re-synthesised when a caller changes the sample layout between reads"""
     src = golden_file("f7_src")
     want = {}
@@ -269,8 +285,7 @@ def test_format_switch_mid_stream(dev):
     s.close()
 
 
-@pytest.mark.gpu
-def test_long_stream_many_windows(dev):
+def test_long_stream_many_windows(side):
     """windows grow 64K -> 4M samples; the carry (2 staged rows) must make window seams invisible"""
     from helpers import make_stream, oracle_pcm
     for lv, rows, nb in ((7, 16, 4000), (9, 16, 700), (3, 1, 30000), (11, 5, 60), (0, 1, 5000)):
@@ -280,8 +295,7 @@ def test_long_stream_many_windows(dev):
         assert rec["words"] == want.size and rec["sha256"] == sha(want.tobytes()) and rec["status"] == st
 
 
-@pytest.mark.gpu
-def test_concurrent_streams_share_the_device(dev):
+def test_concurrent_streams_share_the_device(side):
     """several threads, each decoding its own stream through acm_read on the shared default device
     (reference contract: one ACMStream = one thread at a time, distinct streams independent)"""
     import threading
@@ -311,8 +325,7 @@ def test_concurrent_streams_share_the_device(dev):
     assert got == want
 
 
-@pytest.mark.gpu
-def test_interleaved_reads_on_two_streams(dev):
+def test_interleaved_reads_on_two_streams(side):
     """alternate small reads on two open streams: windows, carries and plans must not leak between them"""
     from helpers import make_stream, oracle_pcm
     fa, fb = make_stream(2700, 7, 16, 200), make_stream(2701, 9, 3, 150, channels=2)
@@ -331,10 +344,9 @@ def test_interleaved_reads_on_two_streams(dev):
     assert b"".join(ga) == wa and b"".join(gb) == wb
 
 
-@pytest.mark.gpu
 @pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref)")
 @pytest.mark.parametrize("shape", [(7, 16, 120, 1, 0), (5, 1, 300, 2, 1), (9, 16, 12, 2, 0), (6, 3, 80, 1, 0)])
-def test_random_seek_walk_pcm(shape):
+def test_random_seek_walk_pcm(side, shape):
     """seeks forward and backward (block index in use) followed by real reads: the PCM bytes and all positions equal
     the reference's"""
     import numpy as np
@@ -359,10 +371,9 @@ def test_random_seek_walk_pcm(shape):
     r.close()
 
 
-@pytest.mark.gpu
 @pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref)")
 @pytest.mark.parametrize("no_index", [False, True])
-def test_seek_walk_on_a_stale_table_stream(no_index, monkeypatch):
+def test_seek_walk_on_a_stale_table_stream(side, no_index, monkeypatch):
     """hazard H1 plus seeks: out-of-range indices read table entries left by earlier blocks, the reference never clears its
     table (decode.c:809-810) and has only decoded what it served - our parser reads ahead of the caller, so a backward
     seek must continue from the table as the SERVED blocks left it.  prime_table makes block 0 write every

@@ -1,6 +1,6 @@
 """ASan + UBSan over the host half of the product (GPU sanitizers are unavailable on the pool: CPU build only).
-tests/native/fuzz_host.cpp links acm_fill.cpp + acm_stream.cpp + acm_pack.cpp against stubbed device entry points and drives
-mutated/truncated golden files through staging, seeks and decode-and-discard reads."""
+tests/native/fuzz_host.cpp links acm_fill.cpp + acm_stream.cpp + acm_pack.cpp + acm_host_synth.cpp against stubbed device entry points and
+drives mutated/truncated golden files through staging, seeks, decode-and-discard reads and reads into a buffer (host synthesis)."""
 import glob
 import os
 import subprocess
@@ -15,7 +15,8 @@ def test_host_parser_under_asan_ubsan(tmp_path):
     src = [os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"),
            os.path.join(ROOT, "libacm_amd", "csrc", "acm_fill.cpp"),
            os.path.join(ROOT, "libacm_amd", "csrc", "acm_stream.cpp"),
-           os.path.join(ROOT, "libacm_amd", "csrc", "acm_pack.cpp")]          # (the byte-plane / packed stagers: host code like the parser)
+           os.path.join(ROOT, "libacm_amd", "csrc", "acm_pack.cpp"),          # (the byte-plane / packed stagers: host code like the parser)
+           os.path.join(ROOT, "libacm_amd", "csrc", "acm_host_synth.cpp")]    # (the host synthesis behind acm_read() where no device is used)
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "libacm_amd", "csrc"), "-o", exe] + src + ["-lpthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
