@@ -95,6 +95,12 @@ typedef struct acmhip_plan acmhip_plan;       /* device-resident launch tables f
 /* modifiers (or-ed in) */
 #define ACMHIP_PLAN_FORM_ONLY    0x100u  /* streams that come with a byte-plane form are never launched without it: their records over the
                                           * int16 rows are not cut (half the table bytes); a launch with no form bound fails */
+#define ACMHIP_PLAN_LEAN_ALWAYS  0x400u  /* whole tiles go to the lean kernels (acm_tile2 / acm_chunk) however few they are - by default a level's
+                                          * tiles must fill the chip a few times over to be worth the lean kernels' lead-in tiles.  Small plans
+                                          * that want the byte-plane / packed forms read; tests */
+#define ACMHIP_PLAN_NO_LEAN      0x800u  /* never the lean kernels: everything on acm_fused_tile / the stage-wise kernels (cross-checks) */
+#define ACMHIP_PLAN_FORCE_HALO   0x1000u /* acm_fused_tile: every tile recomputes its two halo rows (default: by tile count) */
+#define ACMHIP_PLAN_FORCE_CARRY  0x2000u /* acm_fused_tile: histories carried from tile to tile through LDS (default: by tile count) */
 #define ACMHIP_PLAN_UPLOAD_ASYNC 0x200u  /* acmhip_plan_create* returns with the table uploads queued, not done: every launch of the plan
                                           * waits for them on the device (an event wait: do not capture such a launch into a graph) */
 
@@ -127,6 +133,9 @@ int  acmhip_memset(acmhip_device *dev, void *dptr, int byte, size_t bytes);     
 int  acmhip_host_synth(const acmhip_stream_desc *stream, const int16_t *idx, const acmhip_blkhdr *hdr,
 		       const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm);
 void acmhip_set_host_synth_limit(uint64_t samples);
+/* acm_seek_pcm() re-enters a stream at the block in front of its target through the block index the parser keeps (default); off = the
+ * reference's way, re-parsing from the first block (util.c:219-242).  Same positions, same PCM; for cross-checks and measurements. */
+void acmhip_set_seek_index(int on);
 uint64_t acmhip_host_synth_limit(void);
 
 /*
@@ -380,6 +389,8 @@ typedef struct acm_batch_opts {
                                        int16 rows) and only the rows the other kernels still read as int16; the synthesis launch runs its first pass on
                                        the matrix cores (+3 ... +24 % by level).  Wins over ACM_BATCH_STAGE_PACKED when both are set. */
 #define ACM_BATCH_STAGE_INT16  8u   /* every row is staged as int16, no second form (the round-1 ... round-4 default; measurements, cross-checks) */
+#define ACM_BATCH_RANGES(n)    (((unsigned)(n) & 0xFFu) << 8)  /* device parsing: walk and decode the batch in n block ranges (1 = in one piece;
+                                       0 = the library decides: by the length of the longest stream).  Bits 8-15 of opts->flags */
 #define ACM_BATCH_PCM_PINNED   1u   /* every items[i].pcm is pinned host memory (acmhip_host_alloc): the read-back engine writes
                                        the PCM straight into it, stream by stream, instead of through the library's own pinned
                                        arena and a host copy (taken for streams of 64 KB of PCM and more on average) */

@@ -28,11 +28,11 @@
  *
  * What differs is behind the API: acm_read() serves PCM out of a read-ahead
  * window whose blocks were bit-parsed on the host and synthesised
- * (amplitude-table unpack, subband synthesis, 16-bit write-out) on the GPU.
- * There is no CPU synthesis path in this library.  Everything that only parses
- * (acm_open_*, the getters, acm_seek_*, acm_read() with buf == NULL) works
- * without a device; acm_read() into a buffer needs one and returns
- * ACM_ERR_OTHER (with a line on stderr) when no usable HIP device is present.
+ * (amplitude-table unpack, subband synthesis, 16-bit write-out) on the GPU -
+ * or, where no usable HIP device exists, and for streams shorter than
+ * acmhip_host_synth_limit() samples (include/acm_hip.h; 8 M by default) while
+ * no device is open in the process, by the library's own host synthesis
+ * (csrc/acm_host_synth.cpp): like the reference, this API decodes anywhere.
  */
 #ifndef __LIBACM_H
 #define __LIBACM_H

@@ -68,7 +68,7 @@ def build_hip(force=False):
                        "--offload-arch=" + GFX, "-I", INC, "-I", CSRC, "-c", s, "-o", o]
                 if os.environ.get("ACM_ABLATION"):      # timing-only kernel variants for profiling sessions
                     cmd.insert(1, "-DACM_ABLATION=1")
-                if os.environ.get("ACM_TUNING"):        # the alternative tile geometries behind ACM_K1_VARIANT
+                if os.environ.get("ACM_TUNING"):        # the alternative tile geometries behind ACM_K1_VARIANT, environment switches live
                     cmd.insert(1, "-DACM_TUNING=1")
                 extra = os.environ.get("ACM_HIPCC_EXTRA", "").split()           # compiler-flag experiments
                 cmd[1:1] = extra
@@ -80,6 +80,34 @@ def build_hip(force=False):
                 _run(cmd)
             objs.append(o)
         _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + GFX, "-o", out] + objs + ["-lpthread"])
+    return out
+
+
+def build_tuning(force=False):
+    """libacm_amd/lib/exp/tuning.so: the same sources with -DACM_TUNING - the only build that reads kernel-selection switches (ACM_K3,
+    ACM_K2, ACM_K1_VARIANT, ACM_PARSE_SCAN ...) from the environment.  Measurement scripts under profiles/ and the one test that keeps
+    acm_tile2's matrix builds of levels 8-12 alive (tests/test_gpu_byteplane.py) load it through ACM_HIP_LIB; the product never does."""
+    exp = os.path.join(LIB, "exp")
+    os.makedirs(exp, exist_ok=True)
+    out = os.path.join(exp, "tuning.so")
+    src = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    if force or _stale(out, src + _headers()):
+        from concurrent.futures import ThreadPoolExecutor
+        objs = [os.path.join(exp, "tuning." + os.path.basename(s) + ".o") for s in src]
+
+        def one(k):
+            s, o = src[k], objs[k]
+            cmd = [HIPCC, "-DACM_TUNING=1", "-O3", "-g1", "-std=c++17", "-fPIC", "--offload-arch=" + GFX, "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+            if os.path.basename(s) in HOST_ONLY:
+                cmd = [c for c in cmd if not c.startswith("--offload-arch")]
+            elif s.endswith(".cpp"):
+                cmd[1:1] = ["-x", "hip"]
+            _run(cmd)
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(one, range(len(src))))
+        _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + GFX, "-o", out] + objs + ["-lpthread"])
+        for o in objs:
+            os.remove(o)
     return out
 
 
@@ -112,5 +140,6 @@ def build_all(force=False):
     build_synth(force)
     build_hip(force)
     build_tools(force)
+    build_tuning(force)
     build_bench_tools(force)
     build_oracle()

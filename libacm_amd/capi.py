@@ -15,6 +15,16 @@ from . import _build
 FMT_S16LE, FMT_S16BE, FMT_U16LE, FMT_U16BE = 0, 1, 2, 3
 PLAN_AUTO, PLAN_STAGEWISE = 0, 1
 PLAN_FORM_ONLY, PLAN_UPLOAD_ASYNC = 0x100, 0x200          # modifiers, or-ed in (acm_hip.h)
+PLAN_LEAN_ALWAYS, PLAN_NO_LEAN, PLAN_FORCE_HALO, PLAN_FORCE_CARRY = 0x400, 0x800, 0x1000, 0x2000
+# test plumbing: or-ed into the flags of every Plan / batch call made through this module (fixtures that used to set ACM_K2, ACM_K1_CARRY,
+# ACM_BATCH_RANGES in the environment set these instead: the shipped library reads no kernel-selection switch from the environment)
+PLAN_EXTRA = 0
+BATCH_EXTRA = 0
+
+
+def batch_ranges(n):
+    """ACM_BATCH_RANGES(n) of acm_hip.h: device parsing in n block ranges (1 = in one piece, 0 = the library decides)"""
+    return (int(n) & 0xFF) << 8
 ERR_NO_DEVICE = -101
 ERR_ARG = -103
 ERR_RANGE = -105
@@ -84,7 +94,7 @@ class BatchTiming(C.Structure):
 ACMHIP_SYMBOLS = [
     "acmhip_last_error", "acmhip_device_count", "acmhip_device_open", "acmhip_device_close",
     "acmhip_device_sync", "acmhip_device_stream", "acmhip_malloc", "acmhip_free", "acmhip_host_alloc",
-    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_memset", "acmhip_host_synth", "acmhip_set_host_synth_limit", "acmhip_host_synth_limit", "acmhip_plan_create", "acmhip_plan_destroy",
+    "acmhip_host_free", "acmhip_upload", "acmhip_download", "acmhip_memset", "acmhip_host_synth", "acmhip_set_host_synth_limit", "acmhip_host_synth_limit", "acmhip_set_seek_index", "acmhip_plan_create", "acmhip_plan_destroy",
     "acmhip_plan_launch", "acmhip_plan_get_stats", "acmhip_plan_form_rows", "acmhip_plan_time", "acm_stage_probe", "acm_stage_file", "acm_stage_file_mform",
     "acm_batch_decode", "acm_batch_pcm_words", "acm_batch_prestage", "acm_batch_prestage_free", "acmhip_prewarm",
     "acmhip_packed_tile_rows", "acmhip_packed_group_rows", "acmhip_packed_slots", "acmhip_pack_bound", "acmhip_pack_tiles", "acmhip_unpack_tile",
@@ -138,6 +148,8 @@ def lib():
     L.acmhip_set_host_synth_limit.argtypes = [C.c_uint64]
     L.acmhip_set_host_synth_limit.restype = None
     L.acmhip_host_synth_limit.restype = C.c_uint64
+    L.acmhip_set_seek_index.argtypes = [C.c_int]
+    L.acmhip_set_seek_index.restype = None
     L.acmhip_plan_create.argtypes = [vp, C.POINTER(StreamDesc), sz, C.POINTER(Patch), sz, C.c_uint, C.POINTER(vp)]
     L.acmhip_plan_destroy.argtypes = [vp]
     L.acmhip_plan_destroy.restype = None
@@ -500,6 +512,7 @@ class Plan:
     def __init__(self, dev, descs, patches=None, flags=PLAN_AUTO, packed=None):
         """packed: optional list of PackedStream, one per desc (ntiles 0 = that stream has no packed form)"""
         self.dev = dev
+        flags |= PLAN_EXTRA
         n = len(descs)
         arr = (StreamDesc * max(n, 1))(*descs)
         np_ = len(patches) if patches is not None else 0
@@ -685,7 +698,7 @@ def batch_decode(dev, files, force_chans=0, fmt=FMT_S16LE, threads=0, flags=PLAN
         items[k].len = bufs[k].size
         items[k].pcm = outs[k].ctypes.data if outs[k].size else None
         items[k].pcm_cap = outs[k].size
-    opts = BatchOpts(force_chans, fmt, threads, flags, parse, (BATCH_PCM_PINNED if pinned else 0) | (BATCH_STAGE_PACKED if packed else 0) |
+    opts = BatchOpts(force_chans, fmt, threads, flags | PLAN_EXTRA, parse, BATCH_EXTRA | (BATCH_PCM_PINNED if pinned else 0) | (BATCH_STAGE_PACKED if packed else 0) |
                      (BATCH_STAGE_BYTEPLANE if byteplane else 0) | (BATCH_STAGE_INT16 if byteplane is False else 0))
     tm = BatchTiming()
     pre = C.c_void_p()
@@ -725,7 +738,7 @@ def batch_decode_device(dev, files, d_pcm, d_pcm_words, force_chans=0, fmt=FMT_S
 
     Returns (statuses, words, offsets, BatchTiming); nothing is copied back to the host."""
     bufs, items = _batch_items(files)
-    opts = BatchOpts(force_chans, fmt, threads, flags, parse, 0, d_pcm, d_pcm_words)
+    opts = BatchOpts(force_chans, fmt, threads, flags | PLAN_EXTRA, parse, BATCH_EXTRA, d_pcm, d_pcm_words)
     tm = BatchTiming()
     _check(lib().acm_batch_decode(dev.h, items, len(files), C.byref(opts), C.byref(tm)), "acm_batch_decode")
     n = len(files)

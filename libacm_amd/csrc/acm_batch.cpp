@@ -476,8 +476,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	/* the packed staged form (opt-in, host parsing): chunk-table entries are reserved per stream from what the headers promise;
 	 * a pipeline chunk's blobs share the region of the blob arena that mirrors its slice of the int16 arena (a stream whose
 	 * packed form does not fit there - indices that need 16 bits throughout - simply travels as int16) */
-	bool stage_packed = (opts.flags & ACM_BATCH_STAGE_PACKED) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
-			    !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
+	/* (no second form where the plans may not use the lean kernels that read it) */
+	const bool lean_off = (opts.plan_flags & ACMHIP_PLAN_NO_LEAN) || (ACM_TUNING_ENV("ACM_K2") && atoi(ACM_TUNING_ENV("ACM_K2")) == 0);
+	bool stage_packed = (opts.flags & ACM_BATCH_STAGE_PACKED) && !lean_off && !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
 	uint64_t pk_chunks_total = 0;
 	if (stage_packed)
 		for (size_t c = 0; c < chunks.size(); c++) {
@@ -498,8 +499,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * rows plus the two rows of zeros in front */
 	/* (blocks parsed ahead of time are int16 rows already: re-ordering them is a pass of its own, taken only when asked for) */
 	const bool mform_default = !(opts.flags & (ACM_BATCH_STAGE_INT16 | ACM_BATCH_STAGE_PACKED)) && !pre;
-	bool stage_mform = ((opts.flags & ACM_BATCH_STAGE_BYTEPLANE) || mform_default) && !(getenv("ACM_K2") && atoi(getenv("ACM_K2")) == 0) &&
-			   !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
+	bool stage_mform = ((opts.flags & ACM_BATCH_STAGE_BYTEPLANE) || mform_default) && !lean_off && !(opts.plan_flags & ACMHIP_PLAN_STAGEWISE);
 	uint64_t mf_total = 0, mf_pairs_total = 0;
 	if (stage_mform) {
 		stage_packed = false;           /* one second form per batch */
@@ -538,7 +538,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	 * lean kernels take never exist as int16 then (acm_parse.hip: acm_parse_columns); the host pool's second forms are host-parsing only */
 	bool dev_mform = false;
 	if (dev_parse) {
-		dev_mform = stage_mform && !(getenv("ACM_BATCH_DEV_MFORM") && atoi(getenv("ACM_BATCH_DEV_MFORM")) == 0);
+		dev_mform = stage_mform && !(ACM_TUNING_ENV("ACM_BATCH_DEV_MFORM") && atoi(ACM_TUNING_ENV("ACM_BATCH_DEV_MFORM")) == 0);
 		stage_packed = stage_mform = false;
 	}
 	uint64_t files_total = 0, cols_total = 0;
@@ -570,7 +570,9 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 		/* a range of ~128 Msamples is walked in ~2 ms and read back in ~5: 2 ... 16 ranges from 256 Msamples on (measured on
 		 * the 2.1-Gsample batch: 0.136 / 0.114 / 0.106 / 0.104 s with 1 / 4 / 8 / 16 ranges, profiles/r3_batch_timeline.txt) */
 		size_t want = idx_total >= (256u << 20) ? (size_t)std::min<uint64_t>(16, idx_total >> 27) : 1;
-		if (const char *e = getenv("ACM_BATCH_RANGES"))         /* tests / measurements: force a range count (1 = off) */
+		if ((opts.flags >> 8) & 0xFFu)                          /* ACM_BATCH_RANGES(n): the caller's count (1 = in one piece) */
+			want = (opts.flags >> 8) & 0xFFu;
+		else if (const char *e = ACM_TUNING_ENV("ACM_BATCH_RANGES"))
 			want = (size_t)std::max(1, atoi(e));
 		if (want > 1 && want <= 64 && dev_parse && !keep_on_device && !dev_ids.empty() && dev_ids.size() == ok_streams &&
 		    dev_ids.size() <= ACM_PARSE_RANGE_MAX_STREAMS)

@@ -105,6 +105,17 @@ struct AcmParseResult {
 /* levels below that (cols <= 16) have their own one-launch kernel: the cascade fits one thread's registers */
 #define ACM_SMALL_MAX_LEVEL 4
 
+/* Kernel-selection and tuning switches are read from the environment only in -DACM_TUNING builds (profiles/build_variant.sh,
+ * ACM_TUNING=1 python -c 'from libacm_amd import _build; _build.build_hip(True)'): what a drop-in library does must not depend on
+ * its caller's environment (Weak 9).  The shipped library honours ACM_HIP_DEVICE, ACM_BATCH_TRACE and acmtool's ACMTOOL_*;
+ * everything else is a plan / batch flag of include/acm_hip.h. */
+#ifdef ACM_TUNING
+#include <stdlib.h>
+#define ACM_TUNING_ENV(name) getenv(name)
+#else
+#define ACM_TUNING_ENV(name) ((const char *)0)
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -126,6 +137,7 @@ int acmhip_aux_stream(acmhip_device *dev, int k, void **out);    /* batch pipeli
 int acmhip_report_hip(int hip_error, const char *what);          /* records the text, returns ACMHIP_ERR_HIP */
 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
+int acmk_tuning_build(void);                                     /* 1 if the library was built with -DACM_TUNING (its environment switches are live) */
 int acmk_warmup(void *stream);                                   /* an empty launch: makes the runtime load the kernels' code object */
 int acmk_fused_variants(void);                                   /* number of fused-kernel variants built in */
 int acmk_fused_tile_rows(uint32_t level, int variant);           /* tile rows incl. the 2 halo rows, 0 if unsupported */

@@ -455,21 +455,34 @@ bool fused_ok(const acmhip_stream_desc &s, int variant)
 	return s.level >= ACM_K1_MIN_LEVEL && s.level <= ACM_K1_MAX_LEVEL && acmk_fused_tile_rows(s.level, variant) > 2;
 }
 
-/* ACM_K1_CARRY=0/1 forces the halo / carry flavour of the tile kernel (tests, measurements).  Default: carry mode
- * saves 2 of every tile_rows rows and costs one lead-in tile per workgroup, so it pays from tile_rows/2 tiles per
- * workgroup on; it is taken from tile_rows tiles per workgroup */
-bool carry_wanted(size_t ntiles, size_t grid, size_t tile_rows)
+/* Default: carry mode saves 2 of every tile_rows rows and costs one lead-in tile per workgroup, so it pays from tile_rows/2 tiles per
+ * workgroup on; it is taken from tile_rows tiles per workgroup.  ACMHIP_PLAN_FORCE_HALO / _CARRY force a flavour (tests, measurements) */
+bool carry_wanted(size_t ntiles, size_t grid, size_t tile_rows, unsigned flags)
 {
-	if (const char *e = getenv("ACM_K1_CARRY"))
+	if (flags & (ACMHIP_PLAN_FORCE_HALO | ACMHIP_PLAN_FORCE_CARRY))
+		return (flags & ACMHIP_PLAN_FORCE_CARRY) != 0;
+	if (const char *e = ACM_TUNING_ENV("ACM_K1_CARRY"))
 		return atoi(e) != 0;
 	return grid > 0 && ntiles >= tile_rows * grid;
 }
 
-/* tuning knob: ACM_K1_VARIANT=n picks another built-in tile geometry (default: the measured-best one) */
+/* the lean kernels: -1 by tile count (default), 0 never (ACMHIP_PLAN_NO_LEAN), 1 whenever there is a whole tile (ACMHIP_PLAN_LEAN_ALWAYS) */
+int lean_policy(unsigned flags)
+{
+	if (flags & ACMHIP_PLAN_NO_LEAN)
+		return 0;
+	if (flags & ACMHIP_PLAN_LEAN_ALWAYS)
+		return 1;
+	if (const char *e = ACM_TUNING_ENV("ACM_K2"))
+		return atoi(e) != 0;
+	return -1;
+}
+
+/* tuning builds: ACM_K1_VARIANT=n picks another built-in tile geometry (default: the measured-best one) */
 int pick_variant()
 {
 	int v = ACM_K1_DEFAULT_VARIANT;
-	if (const char *e = getenv("ACM_K1_VARIANT"))
+	if (const char *e = ACM_TUNING_ENV("ACM_K1_VARIANT"))
 		v = atoi(e);
 	if (v < 0 || v >= acmk_fused_variants())
 		v = ACM_K1_DEFAULT_VARIANT;
@@ -641,12 +654,13 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		}
 		return ACMHIP_OK;
 	};
-	const bool k2_allowed = !getenv("ACM_K2") || atoi(getenv("ACM_K2")) != 0;
+	const int lean = lean_policy(flags);
+	const bool k2_allowed = lean != 0;
 	std::vector<std::vector<uint32_t>> lists(16), small_lists(ACM_SMALL_MAX_LEVEL + 1), prefix_lists(16);
 	std::vector<std::vector<AcmTile>> prefix_tiles(16), prefix_tiles_carry(16);
 	std::vector<uint8_t> plane_shift(n, 0);                /* levels 13-15: planes carry values scaled by 2^(16 - level) */
 	std::vector<uint8_t> on_tile_kernel(n, 0);             /* patched stream that stays on the tile kernel: its patches live in windows only */
-	const bool prefix_allowed = !(flags & ACMHIP_PLAN_STAGEWISE) && !(getenv("ACM_PREFIX") && atoi(getenv("ACM_PREFIX")) == 0);
+	const bool prefix_allowed = !(flags & ACMHIP_PLAN_STAGEWISE) && !(ACM_TUNING_ENV("ACM_PREFIX") && atoi(ACM_TUNING_ENV("ACM_PREFIX")) == 0);
 	std::vector<uint64_t> grp_max_elems(16, 0), grp_max_emit(16, 0);
 	std::vector<uint32_t> sw_all;
 	uint64_t plane = 0, sw_max = 0;
@@ -665,7 +679,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 				whole += std::min<uint64_t>(s.nrows, s.n_emit >> lv) / TH;
 		}
 		const size_t gridh = (size_t)acmk_tile2_grid(lv, dev->cus);
-		k2_high[lv] = k2_allowed && prefix_allowed && TH && gridh && (getenv("ACM_K2") ? whole > 0 : whole >= 8 * gridh);
+		k2_high[lv] = k2_allowed && prefix_allowed && TH && gridh && (lean == 1 ? whole > 0 : whole >= 8 * gridh);
 	}
 
 	for (size_t i = 0; i < n; i++) {
@@ -855,7 +869,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 	/* EXPERIMENT (ACM_K3_SEG=S; measured and not kept, profiles/r5_placement.txt): the chunk kernel's table in time-major order - wavefront v's run is segments v, v + W, v + 2 W, ... of S
 	 * chunks each (W wavefronts), every segment behind lead-in records for the chunks in front of it: at any moment the W wavefronts
 	 * work inside one window of W x S chunks that moves through the arenas, instead of all over them */
-	if (const char *e = getenv("ACM_K3_SEG")) {
+	if (const char *e = ACM_TUNING_ENV("ACM_K3_SEG")) {
 		const size_t S = (size_t)atoi(e);
 		for (uint32_t lv = 0; lv < 16 && S > 0; lv++) {
 			const size_t W = (size_t)acmk_tile2m_run_waves(lv, dev->cus);
@@ -961,8 +975,8 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			/* streams that came with a packed form always take the lean kernel: their caller may have staged nothing else for
 			 * these rows (acm_batch_decode with ACM_BATCH_STAGE_PACKED uploads the int16 form of the ragged tails only) */
 			const bool k2 = grid2 && (lv > ACM_K1_MAX_LEVEL ? n2 > 0         /* levels 13, 14: decided before the cut */
-						  : getenv("ACM_K2") ? n2 > 0 : (n2 >= 8 * grid2 || !tiles2p[lv].empty() || !tiles2m[lv].empty()));
-			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant));
+						  : lean == 1 ? n2 > 0 : (n2 >= 8 * grid2 || !tiles2p[lv].empty() || !tiles2m[lv].empty()));
+			g.carry = !k2 && !tiles_carry[lv].empty() && carry_wanted(tiles_carry[lv].size(), grid, (size_t)acmk_fused_tile_rows(lv, variant), flags);
 			const std::vector<AcmTile> &use = k2 ? tiles_rest[lv] : g.carry ? tiles_carry[lv] : tiles[lv];
 			g.ntiles = (uint32_t)use.size();
 			rc = to_device(pl, use, &g.d_tiles);
@@ -1018,7 +1032,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 			g.max_elems = grp_max_elems[lv];
 			rc = to_device(pl, prefix_lists[lv], &g.d_list);
 			if (rc == ACMHIP_OK) {
-				g.carry = carry_wanted(prefix_tiles_carry[lv].size(), (size_t)acmk_plane_grid(dev->cus), (size_t)acmk_plane_tile_rows());
+				g.carry = carry_wanted(prefix_tiles_carry[lv].size(), (size_t)acmk_plane_grid(dev->cus), (size_t)acmk_plane_tile_rows(), flags);
 				const std::vector<AcmTile> &use = g.carry ? prefix_tiles_carry[lv] : prefix_tiles[lv];
 				g.ntiles = (uint32_t)use.size();
 				rc = to_device(pl, use, &g.d_tiles);
@@ -1060,7 +1074,7 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		acmhip_plan_destroy(pl);
 		return rc;
 	}
-	if (pl->fused.size() > 1 && !(getenv("ACM_PLAN_STREAMS") && atoi(getenv("ACM_PLAN_STREAMS")) <= 1)) {
+	if (pl->fused.size() > 1 && !(ACM_TUNING_ENV("ACM_PLAN_STREAMS") && atoi(ACM_TUNING_ENV("ACM_PLAN_STREAMS")) <= 1)) {
 		hipError_t e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
 		for (int k = 0; k < 2 && e == hipSuccess; k++) {
 			e = hipEventCreateWithFlags(&pl->ev_join[k], hipEventDisableTiming);

@@ -3150,7 +3150,9 @@ const Tile2MEntry g_chunk[ACM_K2M_MAX_LEVEL - ACM_K2M_MIN_LEVEL + 1] = {
 };
 inline const Tile2MEntry &tile2m_entry(uint32_t level)
 {
-	static const bool k3 = !(getenv("ACM_K3") && atoi(getenv("ACM_K3")) == 0);
+	/* (tuning builds: ACM_K3=0 puts levels 8-12 back on acm_tile2's three / four-stage matrix build - and on ITS form: process-wide,
+	 * read once, because the staged form follows the kernel, acmhip_mform_group) */
+	static const bool k3 = !(ACM_TUNING_ENV("ACM_K3") && atoi(ACM_TUNING_ENV("ACM_K3")) == 0);
 	if (k3 && g_chunk[level - ACM_K2M_MIN_LEVEL].g0)
 		return g_chunk[level - ACM_K2M_MIN_LEVEL];
 	const Tile2MEntry *row = g_tile2m[level - ACM_K2M_MIN_LEVEL];
@@ -3495,6 +3497,15 @@ inline dim3 sw_grid(uint64_t max_elems, uint32_t nlist)
 
 namespace {
 __global__ void acm_warmup_kernel() {}
+}
+
+extern "C" int acmk_tuning_build(void)
+{
+#ifdef ACM_TUNING
+	return 1;
+#else
+	return 0;
+#endif
 }
 
 extern "C" int acmk_warmup(void *stream)

@@ -747,9 +747,9 @@ extern "C" int acmk_launch_parse_range_mf(const AcmParseJob *d_jobs, uint32_t nj
 	if (mf)
 		wave_max = ACM_PARSE_RANGE_MAX_STREAMS;
 #ifdef ACM_TUNING
-	static const int scan_mode = getenv("ACM_PARSE_SCAN") ? atoi(getenv("ACM_PARSE_SCAN")) : 2;     /* 0 lanes, 1 scalar (r1), 2 wave */
-	if (getenv("ACM_PARSE_WAVE_MAX"))
-		wave_max = (uint32_t)atoi(getenv("ACM_PARSE_WAVE_MAX"));
+	static const int scan_mode = ACM_TUNING_ENV("ACM_PARSE_SCAN") ? atoi(ACM_TUNING_ENV("ACM_PARSE_SCAN")) : 2;     /* 0 lanes, 1 scalar (r1), 2 wave */
+	if (ACM_TUNING_ENV("ACM_PARSE_WAVE_MAX"))
+		wave_max = (uint32_t)atoi(ACM_TUNING_ENV("ACM_PARSE_WAVE_MAX"));
 	if (scan_mode == 0)
 		wave_max = 0;
 	if (nranges > 1)                                        /* block ranges exist in the wave-per-stream walk only */

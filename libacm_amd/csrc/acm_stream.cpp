@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -57,6 +58,7 @@ constexpr uint64_t kWindowSamplesFirst = 64u << 10;     /* first window: keep ti
  * Opened on first use - or ahead of it, on a thread of its own, when the application says it is going to decode
  * (acmhip_prewarm, include/acm_hip.h): bringing the HIP runtime up takes ~0.2 s on these boxes, which is as long as the
  * host parser needs for 40 Msamples.  While the device is still coming up the stream keeps parsing ahead (fill_window). */
+std::atomic<bool> g_seek_index{ true };        /* acmhip_set_seek_index (include/acm_hip.h) */
 std::mutex g_dev_mutex;
 std::condition_variable g_dev_cv;
 acmhip_device *g_dev = nullptr;
@@ -437,6 +439,11 @@ void fill_stage_info(const ACMStream *a, acm_stage_info *info)
 /* core API                                                                  */
 /* ======================================================================== */
 
+extern "C" void acmhip_set_seek_index(int on)
+{
+	g_seek_index.store(on != 0);
+}
+
 extern "C" void acmhip_prewarm(void)
 {
 	start_prewarm();
@@ -659,7 +666,7 @@ extern "C" int acm_seek_pcm(ACMStream *acm, unsigned pcm_pos)
 		const uint64_t target = word_pos / bl;
 		const uint64_t enter = target > halo ? target - halo : 0;
 		const bool indexed = enter >= 1 && enter < hs->mark_bit.size() && enter <= hs->hdr_log.size() &&
-				     bl % acm->info.channels == 0 && getenv("ACM_NO_SEEK_INDEX") == NULL;
+				     bl % acm->info.channels == 0 && g_seek_index.load();
 		uint64_t at = start;
 		if (indexed) {
 			at = hs->mark_bit[enter] >> 3;

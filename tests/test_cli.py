@@ -26,7 +26,7 @@ def norm_err(text):
     return re.sub(r"^[^\n:]*: (invalid option|option requires)", r"PROG: \1", text, flags=re.M)
 
 
-def replay(rec, td):
+def replay(rec, td, env=None):
     g = golden()["F8_cli"]
     for name, src in g["inputs"].items():
         with open(os.path.join(td, name), "wb") as f:
@@ -42,7 +42,7 @@ def replay(rec, td):
             d = bytes(b)
         with open(os.path.join(td, name), "wb") as f:
             f.write(d)
-    r = subprocess.run([tool()] + rec["args"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([tool()] + rec["args"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
     assert r.returncode == rec["rc"], (rec["label"], r.stderr)
     want_out = base64.b64decode(rec["stdout"]) if rec["stdout_b64"] else rec["stdout"].encode("latin1")
     assert r.stdout == want_out, rec["label"]
@@ -66,6 +66,15 @@ def test_cli_without_decoding(rec):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rec", runs(lambda l: l not in CPU_RUNS), ids=lambda r: r["label"])
 def test_cli_decoding(dev, rec):
+    """the decoding transcripts with every stream on the GPU (ACMTOOL_HOST_LIMIT=0: by default streams this short stay on the host)"""
+    with tempfile.TemporaryDirectory() as td:
+        replay(rec, td, env={"ACMTOOL_HOST_LIMIT": "0"})
+
+
+@pytest.mark.parametrize("rec", runs(lambda l: l not in CPU_RUNS), ids=lambda r: r["label"])
+def test_cli_decoding_on_the_host(rec):
+    """the same transcripts with the tool's defaults: short streams are synthesised on the host (acm_host_synth.cpp) - and on a box
+    without a GPU, like the authoring container, everything is (BASELINE.json configs[0])"""
     with tempfile.TemporaryDirectory() as td:
         replay(rec, td)
 

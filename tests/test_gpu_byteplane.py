@@ -15,7 +15,7 @@ LEVELS = [7, 8, 9, 10, 11, 12, 13, 14]
 
 @pytest.fixture
 def force_k2(monkeypatch):
-    monkeypatch.setenv("ACM_K2", "1")
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | capi.PLAN_LEAN_ALWAYS)
 
 
 def tile_rows(level):
@@ -357,7 +357,7 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
     code at levels 8-12, block heights 2 / 16 / 64 / 700, quiet and loud blocks, stereo; truncated, H1, junk and odd-height files fall back.
     Same PCM and statuses as the oracle; and the same with the int16 staging of the device parser (ACM_BATCH_DEV_MFORM=0)"""
     import oracle_api as O
-    monkeypatch.setenv("ACM_BATCH_RANGES", str(ranges))
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     valid = [0] + list(range(3, 17)) + [17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29]
     files = []
     for j, code in enumerate(valid):
@@ -377,8 +377,7 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
     res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
     # (with block ranges only streams whose blocks are whole tiles of the lean kernel get the form: a range must end on a tile boundary)
     assert tm.device_parsed >= 40 and tm.packed_streams >= (25 if ranges == 1 else 15), (tm.device_parsed, tm.packed_streams)
-    monkeypatch.setenv("ACM_BATCH_DEV_MFORM", "0")
-    res0, tm0 = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    res0, tm0 = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=False)      # ACM_BATCH_STAGE_INT16: every row as int16
     assert tm0.packed_streams == 0
     for k, f in enumerate(files):
         o = O.Oracle(f)
@@ -398,7 +397,7 @@ def test_device_parser_walk_that_stops_inside_a_range(dev, monkeypatch, ranges):
     entries from the block that failed on: a GPU memory fault, profiles/byteplane_fuzz.py seed 2718 batch 133).  The host reader's
     redo delivers what the reference delivers"""
     import oracle_api as O
-    monkeypatch.setenv("ACM_BATCH_RANGES", str(ranges))
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     whole = make_stream(500842608, 12, 8, 3, channels=1, cut=5, pwr_min=7, pwr_max=7, val_max=65535)
     files = [whole[:36185]]
     for k, (lv, rows, nb) in enumerate(((12, 8, 7), (9, 16, 12), (10, 8, 9), (11, 4, 11), (8, 32, 6))):
@@ -431,7 +430,7 @@ def test_plan_says_which_rows_it_reads_from_the_second_form(dev, monkeypatch):
 
 
 def test_byteplane_without_the_chunk_kernel():
-    """ACM_K3=0 (read once per process, so this runs in a child): no level goes to the chunk kernel, every level's byte-plane tiles run
+    """ACM_K3=0 in a tuning build (read once per process, so this runs in a child): no level goes to the chunk kernel, every level's byte-plane tiles run
     acm_tile2's matrix build (three or four stages on the matrix cores: the one depth per level the library ships) on the form that goes
     with it - parity with the oracle over levels 7-14, even, odd and single block heights, 16-bit indices"""
     import os
@@ -446,7 +445,7 @@ from libacm_amd import capi
 dev = capi.Device(0)
 bad = 0
 for level in range(7, 15):
-    assert capi.lib().acmhip_mform_group(level) == (16 if level >= 10 else 8)
+    assert capi.lib().acmk_tuning_build() == 1 and capi.lib().acmhip_mform_group(level) == (16 if level >= 10 else 8)
     tr = max(capi.lib().acmhip_mform_tile_rows(level), capi.lib().acmk_tile2_rows(level), 4)
     for rows, pm in ((16, 12), (1, 9), (3, 6), (17, 15)):
         f = make_stream(28000 + level * 100 + rows, level, rows, (5 * tr + rows - 1) // rows + 1, cut=3, pwr_min=min(4, pm), pwr_max=pm,
@@ -457,6 +456,9 @@ for level in range(7, 15):
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (os.path.dirname(os.path.abspath(__file__)),)
-    env = dict(os.environ, ACM_K2="1", ACM_K3="0")
+    # the shipped library reads no kernel-selection switch from the environment; its -DACM_TUNING twin (libacm_amd/lib/exp/tuning.so, built
+    # by _build.build_all) does - loaded here through ACM_HIP_LIB
+    from libacm_amd import _build
+    env = dict(os.environ, ACM_K2="1", ACM_K3="0", ACM_HIP_LIB=_build.build_tuning())
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_k2(monkeypatch):
-    monkeypatch.setenv("ACM_K2", "1")
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | capi.PLAN_LEAN_ALWAYS)
 
 
 def check_packed(dev, files, fmt=capi.FMT_S16LE, force_chans=0):

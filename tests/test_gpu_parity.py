@@ -42,8 +42,8 @@ def capi_tile_rows(level):
 
 @pytest.fixture
 def force_k2(monkeypatch):
-    """ACM_K2=1: the lean tile kernel (acm_tile2) takes every whole tile, however small the plan (default: big plans only)"""
-    monkeypatch.setenv("ACM_K2", "1")
+    """ACMHIP_PLAN_LEAN_ALWAYS: the lean tile kernel (acm_tile2) takes every whole tile, however small the plan (default: big plans only)"""
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | capi.PLAN_LEAN_ALWAYS)
 
 
 @pytest.mark.parametrize("level", [6, 7, 8, 9, 10, 11, 12])
@@ -110,7 +110,7 @@ def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows, carry, monkey
     """levels above the tile kernel's: the first level - 12 stages (acm_sw_prefix) into a scaled plane, then the level-12 tile
     kernel, halo and carry flavour, on the plane (decode.c:566-571: the later stages of level L are the cascade of level
     L - j on the same sample sequence)"""
-    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | (capi.PLAN_FORCE_CARRY if carry == "1" else capi.PLAN_FORCE_HALO))
     f = make_stream(8000 + level * 10 + rows, level, rows, 3, cut=7, val_max=65535, pwr_max=15)
     g = make_stream(8100 + level * 10 + rows, level, rows, 2, channels=2)
     st = check_streams(dev, [f, g])
@@ -123,7 +123,7 @@ def test_levels_13_to_15_prefix_plus_tile_kernel(dev, level, rows, carry, monkey
 @pytest.mark.parametrize("level,rows,blocks", [(13, 5, 30), (14, 3, 27), (15, 2, 35)])
 def test_levels_13_to_15_long_streams(dev, level, rows, blocks, carry, monkeypatch):
     """more rows than one chunk of the prefix sweep (64) and than one tile of the plane kernel; windows that start inside"""
-    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | (capi.PLAN_FORCE_CARRY if carry == "1" else capi.PLAN_FORCE_HALO))
     f = make_stream(8400 + level, level, rows, blocks, cut=11)
     check_streams(dev, [f])
     s = capi.stage_file(f)
@@ -138,7 +138,7 @@ def test_levels_13_to_15_long_streams(dev, level, rows, blocks, carry, monkeypat
 @pytest.mark.parametrize("carry", ["0", "1"])
 def test_level_13_window_and_patches(dev, carry, monkeypatch):
     """the prefix path with a window that starts inside the stream, and with H1 patches (scaled like the plane)"""
-    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | (capi.PLAN_FORCE_CARRY if carry == "1" else capi.PLAN_FORCE_HALO))
     f = make_stream(8300, 13, 2, 5)
     s = capi.stage_file(f)
     want, _ = oracle_pcm(f)
@@ -160,7 +160,7 @@ def test_header_extremes(dev, level, rows, blocks, carry, monkeypatch):
     """acm_rows is a 12-bit field (decode.c:748-750) and acm_level a 4-bit one (:747): rows 1 and 4095 through every
     kernel family the planner picks (tile kernels with and without carries, register kernel, prefix + plane kernel), and
     levels 14 / 15 with as many rows as the stress configuration has; both bit parsers"""
-    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | (capi.PLAN_FORCE_CARRY if carry == "1" else capi.PLAN_FORCE_HALO))
     f = make_stream(88000 + level * 7 + rows, level, rows, blocks, channels=1 + level % 2, cut=11)
     st = check_streams(dev, [f])
     assert st.fused_streams == 1 and st.stagewise_streams == 0
@@ -520,7 +520,7 @@ def test_batch_block_ranges(dev, ranges, monkeypatch):
     read-back of range r overlap the walk of range r + 1, PCM arenas range-major): forced on a small batch - streams with
     fewer blocks than ranges, ragged ends, stereo, levels with and without the lean kernel, a truncated file and streams
     with out-of-range indices (the device flags them: fix-up through the host reader), something that is not ACM"""
-    monkeypatch.setenv("ACM_BATCH_RANGES", ranges)
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     files = []
     for i in range(41):
         lv = [7, 9, 5, 3, 11, 0, 13, 8][i % 8]
@@ -589,7 +589,7 @@ def test_batch_striped_upload_uneven_bit_rate(dev, ranges, monkeypatch):
     all of its bits in its first blocks needs bytes that are not there yet - its walk stops (as if the data had run out) and
     the host reader takes the stream; a stream with the bits at the end never gets near the limit; neighbours are not affected"""
     from helpers import handmade_stream
-    monkeypatch.setenv("ACM_BATCH_RANGES", ranges)
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     loud, quiet = (12, 200, 13), (3, 7, 0)                          # 13-bit linear columns against empty ones
     front = handmade_stream(6, 32, [loud] * 6 + [quiet] * 18, seed=1)
     back = handmade_stream(6, 32, [quiet] * 18 + [loud] * 6, seed=2)
@@ -673,7 +673,7 @@ def test_batch_device_resident_output(dev):
 def test_random_batch_fuzz(dev, ranges, monkeypatch):
     """200 random shapes (level 0-14, rows 1-70, 1-5 blocks, mono/stereo, ragged ends, WAVC, all four formats) in one
     batch: host parse, device parse (one walk, and block ranges) and the oracle agree stream by stream"""
-    monkeypatch.setenv("ACM_BATCH_RANGES", ranges)
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     rng = np.random.default_rng(0xACD)
     files = []
     for i in range(200):
@@ -698,10 +698,10 @@ def test_random_batch_fuzz(dev, ranges, monkeypatch):
 
 @pytest.mark.parametrize("carry", ["0", "1"])
 def test_tile_kernel_flavours(dev, carry, monkeypatch):
-    """the halo kernel and the carry-mode kernel (ACM_K1_CARRY forces either) give the oracle's PCM: long streams
+    """the halo kernel and the carry-mode kernel (ACMHIP_PLAN_FORCE_HALO / _CARRY force either) give the oracle's PCM: long streams
     (many tiles per stream, lead-in tiles where a workgroup's run starts mid-stream), ragged ends, stereo, every fused
     level, windows that start at row_begin > 0, all four output formats"""
-    monkeypatch.setenv("ACM_K1_CARRY", carry)
+    monkeypatch.setattr(capi, "PLAN_EXTRA", capi.PLAN_EXTRA | (capi.PLAN_FORCE_CARRY if carry == "1" else capi.PLAN_FORCE_HALO))
     files = [make_stream(9500 + lv, lv, rows, nb, channels=1 + lv % 2, cut=7 * lv)
              for lv, rows, nb in ((5, 16, 700), (6, 7, 300), (7, 16, 120), (8, 33, 40), (9, 16, 30), (10, 5, 20), (11, 64, 3))]
     for fmt in (capi.FMT_S16LE, capi.FMT_U16BE):

@@ -72,7 +72,7 @@ def test_seek_and_discard_bookkeeping():
 def test_random_seek_walk_matches_reference(shape, monkeypatch):
     """a walk of forward/backward acm_seek_pcm / acm_seek_time calls and discard reads: return values, acm_pcm_tell,
     acm_raw_tell and acm_time_tell equal the reference's at every step - with the block index (backward seeks re-enter
-    the stream near the target) and without it (ACM_NO_SEEK_INDEX: rewind and re-parse, as the reference does)"""
+    the stream near the target) and without it (acmhip_set_seek_index(0): rewind and re-parse, as the reference does)"""
     import numpy as np
     from libacm_amd import synth
     level, rows, nb, ch, wavc = shape
@@ -82,7 +82,7 @@ def test_random_seek_walk_matches_reference(shape, monkeypatch):
     reads_with_index = None
     for no_index in (False, True):
         if no_index:
-            monkeypatch.setenv("ACM_NO_SEEK_INDEX", "1")
+            seek_index(False, monkeypatch)
         rng = np.random.default_rng(level * 100 + rows)
         r = O.LibacmStream(O.ref_lib(), f)
         s = ours(f)
@@ -192,6 +192,28 @@ def test_corrupt_streams_discard():
     s = ours(golden_file(gl["file"]))
     assert [s.read(4096, discard=True, loop=True)[0] for _ in range(3)] == gl["rc"]
     s.close()
+
+
+def seek_index(on, monkeypatch):
+    """acmhip_set_seek_index (include/acm_hip.h) for the rest of the test: monkeypatch undoes it through the property's setter"""
+    monkeypatch.setattr(_SEEK, "on", on)
+
+
+class _SeekState:
+    def __init__(self):
+        object.__setattr__(self, "_on", True)
+
+    @property
+    def on(self):
+        return self._on
+
+    @on.setter
+    def on(self, v):
+        object.__setattr__(self, "_on", v)
+        capi.lib().acmhip_set_seek_index(1 if v else 0)        # monkeypatch's undo sets it back through here
+
+
+_SEEK = _SeekState()
 
 
 # ------------------------------------------------------------------ PCM: on the device (-m gpu) and on the host
@@ -381,7 +403,7 @@ def test_seek_walk_on_a_stale_table_stream(side, no_index, monkeypatch):
     import numpy as np
     from libacm_amd import synth
     if no_index:
-        monkeypatch.setenv("ACM_NO_SEEK_INDEX", "1")
+        seek_index(False, monkeypatch)
     level, rows, nb = 6, 5, 200
     total = nb * (rows << level) - 3
     f = synth.generate(seed=synth.BASE_SEED + 4400, level=level, rows=rows, nblocks=nb, total_values=total, mix=1,
