@@ -228,27 +228,44 @@ int  acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream_desc *str
 int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chunks, const uint8_t *d_blob);
 
 /* ------------------------------------------------------------------------
- * Byte-plane staged form: the staged indices in the order the matrix cores take them, every row pair at the narrowest of
- * 4 / 8 / 16 bits per index that holds it.
+ * Byte-plane staged form: the staged indices in the order the matrix cores take them, every row pair at the narrowest
+ * width class that holds it.
  *
  * The first stages of the cascade (decode.c:527-590) are linear; over one residue class of the columns (columns
- * c + q * cols/G, q < G, G = acmhip_mform_group(level) = 8 or 16) the first three / four of them are one banded integer
- * matrix per row pair, and a level whose lean-kernel build starts that way (acmhip_mform_tile_rows(level) != 0) has a
- * build that runs the matrix on v_mfma_i32_16x16x32_i8 / 16x16x64_i8 instead of the vector ALU: its operands are the
- * staged indices themselves (the multiply by the block's val moves behind the matrix), as bytes.  A block's indices lie
- * in [-2^pwr, 2^pwr) (decode.c:592-600: the amplitude table has 2^(pwr+1) entries), so quiet blocks need fewer bits:
+ * c + q * cols/G, q < G, G = acmhip_mform_group(level)) the first log2(G) of them are one banded integer matrix over
+ * rows, and a level that has such a build (acmhip_mform_tile_rows(level) != 0: levels 7-14) runs it on
+ * v_mfma_i32_16x16x32_i8 / 16x16x64_i8 instead of the vector ALU: its operands are the staged indices themselves (the
+ * multiply by the block's val moves behind the matrix), as signed bytes.  A block's indices lie in [-2^pwr, 2^pwr)
+ * (decode.c:592-600: the amplitude table has 2^(pwr+1) entries), so quiet blocks need fewer bits.
  *
  *   stream -> a pair of zero rows (what the cascade sees in front of row 0), then its row pairs (rows 2P, 2P + 1), each at
- *             its own width class (a pair takes 64 bytes or a multiple: levels >= 7); acmhip_mform_pair k of the stream =
- *             where pair k - 1 starts (64-byte units from the arena's base) << 2 | class;
- *   pair   -> its two rows, each row = cols/G residues c, each residue = the G indices of columns c, c + cols/G, ...:
+ *             its own width class, back to back (a pair takes 64 bytes or a multiple); acmhip_mform_pair k of the stream =
+ *             where pair k - 1 starts (64-byte units from the arena's base) << 2 | class code;
+ *   pair   -> its two rows, each row = cols/G residues c, each residue = the G indices of columns c, c + cols/G, ...
+ *
+ * G = 64, levels 8-14 (six stages on the matrix cores: acm_chunk at levels 8-12, acm_tile2 at 13 / 14).  The pair in front is
+ * at 8 bits.  Per residue:
+ *             ACMHIP_BP_BYTE  (2)  64 bytes: idx itself (every index of the pair in [-128, 127])
+ *             ACMHIP_BP_NIB12 (1)  levels 8-12 only: idx = 256 hi + lo with lo a signed byte and hi a signed NIBBLE (every index of
+ *                                  the pair in [-2176, 1919]): 64 low bytes, then 32 bytes of high nibbles in the order the kernel's
+ *                                  lanes read them - lane ks < 4 (columns q = 16 ks .. 16 ks + 15 of the class) takes the 8 bytes
+ *                                  at 64 + 8 ks: dword d < 2 holds its elements 8 d .. 8 d + 7, element 8 d + b (b < 4) in the HIGH
+ *                                  nibble of byte b, element 8 d + 4 + b in the low one (x & 0xf0f0f0f0 and (x << 4) & 0xf0f0f0f0
+ *                                  are then the matrix operand bytes hi << 4 of elements 8 d .. + 3 and 8 d + 4 .. + 7)
+ *             ACMHIP_BP_WORD  (3)  idx = 256 hi + lo with BOTH bytes signed: 64 low bytes, then 64 high bytes.  That ends at
+ *                                  32 639: a stream with a larger index (it takes pwr 15) cannot be written -
+ *                                  acmhip_mform_rows returns ACMHIP_ERR_RANGE and the stream stays in the int16 form
+ * G = 8, level 7 (three stages, acm_tile2; also levels 8-9, and G = 16 at 10-14, in a -DACM_TUNING build run with ACM_K3=0).  The
+ * pair in front is at 4 bits.  Per residue:
  *             ACMHIP_BP_WORD    G low bytes ((idx & 0xff) ^ 0x80: signed bytes, the kernel adds the 128 back through the
  *                               accumulator), then G high bytes (idx >> 8)
  *             ACMHIP_BP_BYTE    G bytes (idx itself; every index of the pair in [-128, 127])
  *             ACMHIP_BP_NIBBLE  G / 2 bytes (every index in [-8, 7]): per dword eight indices plus 8 each, index 8 j + i in
  *                               nibble 2 i, index 8 j + 4 + i in nibble 2 i + 1 (i < 4)
  *
- * Only whole tiles are staged this way, the ragged tail of a stream stays int16 (as with the packed form).
+ * Only whole tiles are staged this way, the ragged tail of a stream stays int16 (as with the packed form).  Whoever writes the
+ * form (acmhip_mform_rows, acm_stage_file_mform, the device parser) and the kernel that reads it are the same library build: the
+ * form of a level follows the kernel the build ships for it.
  * ---------------------------------------------------------------------- */
 typedef uint32_t acmhip_mform_pair;
 #define ACMHIP_BP_NIBBLE 1u
@@ -256,8 +273,8 @@ typedef uint32_t acmhip_mform_pair;
 #define ACMHIP_BP_BYTE   2u
 #define ACMHIP_BP_WORD   3u
 int  acmhip_mform_tile_rows(uint32_t level);     /* rows per tile of the matrix-core build, 0 if the level has none */
-int  acmhip_mform_group(uint32_t level);         /* columns of a residue class kept side by side: 8 (a three-stage first pass) or 16 (four) */
-uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);     /* upper bound of the bytes nrows rows take (incl. the pair in front and read slack) */
+int  acmhip_mform_group(uint32_t level);         /* columns of a residue class kept side by side: 64 (levels 8-14, a six-stage first pass), 8 (level 7: three); 0 if none */
+uint64_t acmhip_mform_bytes(uint32_t level, uint64_t nrows);     /* upper bound of the bytes nrows rows take (every pair at 16 bits, + the pair in front and 64 bytes of read slack) */
 uint64_t acmhip_mform_pairs(uint64_t nrows);                     /* pair-table entries of nrows rows: nrows / 2 + 1 */
 /*
  * Host stager, byte-plane half: idx[row * cols + col] (as acm_stage_file writes them; nrows even) -> out[0 .. *bytes_used) and

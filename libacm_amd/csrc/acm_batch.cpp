@@ -1307,16 +1307,17 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	auto upload_spans = [&](uint8_t *d_base, const uint8_t *h_base, std::vector<Span> &spans) -> hipError_t {
 		constexpr uint64_t JOIN = 256u << 10;
 		for (size_t k = 0; k < spans.size();) {
-			uint64_t at = spans[k].at, end = spans[k].at + spans[k].len;
+			uint64_t at = spans[k].at, end = spans[k].at + spans[k].len, payload = spans[k].len;
 			size_t j = k + 1;
 			while (j < spans.size() && spans[j].at >= at && spans[j].at <= end + JOIN) {
 				end = std::max(end, spans[j].at + spans[j].len);
+				payload += spans[j].len;
 				j++;
 			}
 			const hipError_t e = hipMemcpyAsync(d_base + at, h_base + at, end - at, hipMemcpyHostToDevice, st_main);
 			if (e != hipSuccess)
 				return e;
-			tm.h2d_bytes += end - at;
+			tm.h2d_bytes += std::min(payload, end - at);      /* what the plans read; the gaps a joined transfer carries along are nobody's */
 			k = j;
 		}
 		spans.clear();
@@ -1399,9 +1400,14 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 						BTRY(acmhip_plan_form_rows(ch.plan, at, &rows2));
 						if (s.mf_fused && rows2 != (uint64_t)s.pk_ntiles * (uint64_t)acmhip_mform_tile_rows(s.info.level)) {
 							/* the parsing pass wrote only the int16 rows behind the tiles it put into the form: a plan that reads fewer of
-							 * them from the form would decode rows that were never staged (cannot happen for the levels it is used at) */
-							fprintf(stderr, "acm_batch_decode: stream %zu: the plan reads %llu rows from the byte-plane form, %llu were staged that way\n",
-								i, (unsigned long long)rows2, (unsigned long long)s.pk_ntiles * (unsigned long long)acmhip_mform_tile_rows(s.info.level));
+							 * them from the form would decode rows that were never staged.  Stager and planner cut by the same tile
+							 * geometry of the same library build, and the shipped build reads no kernel-selection switch from the
+							 * environment any more (ACM_K1_VARIANT made the two disagree), so this is an internal error,
+							 * reported as text, not a condition to recover from */
+							char msg[200];
+							snprintf(msg, sizeof(msg), "acm_batch_decode: stream %zu: the plan reads %llu rows from the byte-plane form, %llu were staged that way",
+								 i, (unsigned long long)rows2, (unsigned long long)s.pk_ntiles * (unsigned long long)acmhip_mform_tile_rows(s.info.level));
+							acmhip_set_error_text(msg);
 							rc = ACMHIP_ERR_ARG;
 							cleanup();
 							return rc;

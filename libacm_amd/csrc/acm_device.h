@@ -134,7 +134,8 @@ void acmhip_arena_unlock(acmhip_device *dev);
 int acmhip_copy_stream(acmhip_device *dev, void **out);          /* second stream for overlapped read-back */
 #define ACM_AUX_STREAMS 2
 int acmhip_aux_stream(acmhip_device *dev, int k, void **out);    /* batch pipeline: 0 = device bit parsing, 1 = file uploads */
-int acmhip_report_hip(int hip_error, const char *what);          /* records the text, returns ACMHIP_ERR_HIP */
+int acmhip_report_hip(int hip_error, const char *what);
+void acmhip_set_error_text(const char *text);                    /* what acmhip_last_error() returns on this thread */          /* records the text, returns ACMHIP_ERR_HIP */
 
 /* launchers implemented in acm_kernels.hip; `stream` is a hipStream_t */
 int acmk_tuning_build(void);                                     /* 1 if the library was built with -DACM_TUNING (its environment switches are live) */

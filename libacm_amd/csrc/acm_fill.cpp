@@ -520,8 +520,20 @@ int parse_block(ACMStream *s, TableHistory *tab, int16_t *const out, acmhip_blkh
 	 * scratch of the thread's whose rows are a cache line further apart, and copied out row by row. */
 	const size_t row_bytes = (size_t)cols * sizeof(int16_t);
 	const unsigned pitch_padded = cols + 32;
-	const bool padded = row_bytes >= 512 && (uint64_t)rows * row_bytes / 4096 > 6 && (uint64_t)rows * pitch_padded * sizeof(int16_t) <= (8u << 20);
+	/* (from 1024 columns on - rows 2 KB apart, every row of a column in one of two cache sets - and with more rows than those sets have
+	 * ways: the shapes the measurement covers.  Narrower blocks spread over enough sets and keep the direct write: ADVICE r5) */
+	const bool padded = row_bytes >= 2048 && (uint64_t)rows * row_bytes / 4096 > 6 && (uint64_t)rows * pitch_padded * sizeof(int16_t) <= (8u << 20);
+	/* the scratch stays with the thread up to 1 MB (level 12 x 64 rows takes 528 KB); what a giant block needed beyond that goes back
+	 * to the allocator when the block is done */
 	static thread_local std::vector<int16_t> scratch;
+	struct ScratchTrim {
+		std::vector<int16_t> &v;
+		~ScratchTrim()
+		{
+			if (v.capacity() * sizeof(int16_t) > (1u << 20))
+				std::vector<int16_t>().swap(v);
+		}
+	} trim{ scratch };
 	if (padded && scratch.size() < (size_t)rows * pitch_padded)
 		scratch.resize((size_t)rows * pitch_padded);
 	int16_t *const idx = padded ? scratch.data() : out;

@@ -30,6 +30,14 @@ void set_err(const char *fmt, ...)
 	va_end(ap);
 }
 
+} // namespace
+/* (for the other translation units of the library: the text acmhip_last_error() returns on this thread) */
+extern "C" void acmhip_set_error_text(const char *text)
+{
+	set_err("%s", text);
+}
+namespace {
+
 int hip_fail(hipError_t e, const char *what)
 {
 	set_err("%s: %s", what, hipGetErrorString(e));
@@ -52,6 +60,7 @@ struct acmhip_device {
 	/* pinned staging ring of the table uploads: a copy out of pinned memory returns when it is queued, so a plan waits once for all its
 	 * tables (or not at all: ACMHIP_PLAN_UPLOAD_ASYNC) instead of once per table */
 	uint8_t *up_ring = nullptr;
+	bool up_ring_failed = false;            /* pinning the ring failed once: tables go up straight from where they are */
 	size_t up_at = 0;
 	static constexpr size_t UP_RING_BYTES = (size_t)32 << 20;
 	int cus = 0;                            /* compute units, sizes the persistent grids */
@@ -121,6 +130,7 @@ struct acmhip_plan {
 	 * instead of leaving the chip half empty three times (fork / join by events on the device stream) */
 	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
 	hipEvent_t ev_upload = nullptr;         /* ACMHIP_PLAN_UPLOAD_ASYNC: the tables are on the device once this has happened */
+	bool tables_settled = false;            /* upload_done() has run: waited for, or covered by ev_upload */
 	bool form_only = false;                 /* ACMHIP_PLAN_FORM_ONLY: no int16 twin of the byte-plane records */
 };
 
@@ -417,8 +427,14 @@ int to_device(acmhip_plan *pl, const std::vector<T> &v, T **out)
 		HIPTRY(hipStreamCreateWithFlags(&dev->upload, hipStreamNonBlocking));
 	/* (the ring is pinned when the first table of 256 KB or more comes by: a handle that only ever decodes a file or two - acmtool -d -
 	 * does not pay for 32 MB of pinned memory, its few small tables go up straight from where they are) */
-	if (!dev->up_ring && bytes >= ((size_t)256 << 10) && bytes <= acmhip_device::UP_RING_BYTES)
-		HIPTRY(hipHostMalloc((void **)&dev->up_ring, acmhip_device::UP_RING_BYTES, hipHostMallocDefault));
+	if (!dev->up_ring && !dev->up_ring_failed && bytes >= ((size_t)256 << 10) && bytes <= acmhip_device::UP_RING_BYTES) {
+		/* (no pinned memory to be had is not a reason to fail the plan: "no ring", the direct copy below does the same job - ADVICE r5) */
+		if (hipHostMalloc((void **)&dev->up_ring, acmhip_device::UP_RING_BYTES, hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			dev->up_ring = nullptr;
+			dev->up_ring_failed = true;
+		}
+	}
 	if (!dev->up_ring || bytes > acmhip_device::UP_RING_BYTES) {
 		HIPTRY(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, dev->upload));
 		HIPTRY(hipStreamSynchronize(dev->upload));
@@ -439,14 +455,18 @@ int upload_done(acmhip_plan *pl, bool async)
 {
 	acmhip_device *dev = pl->dev;
 	std::lock_guard<std::mutex> g(dev->upload_mutex);
-	if (!dev->upload)
+	if (!dev->upload) {
+		pl->tables_settled = true;
 		return ACMHIP_OK;
+	}
 	if (!async) {
 		HIPTRY(hipStreamSynchronize(dev->upload));
+		pl->tables_settled = true;
 		return ACMHIP_OK;
 	}
 	HIPTRY(hipEventCreateWithFlags(&pl->ev_upload, hipEventDisableTiming));
 	HIPTRY(hipEventRecord(pl->ev_upload, dev->upload));
+	pl->tables_settled = true;
 	return ACMHIP_OK;
 }
 
@@ -498,6 +518,12 @@ extern "C" void acmhip_plan_destroy(acmhip_plan *plan)
 	if (plan->dev) {
 		(void)hipSetDevice(plan->dev->ordinal);
 		(void)hipStreamSynchronize(plan->dev->stream);   /* the launches of this plan are done with its tables (side streams join the device stream) */
+		if (!plan->tables_settled && plan->dev->upload) {
+			/* a plan whose creation failed half way has tables queued on the upload stream and no event that says when they have gone:
+			 * wait for the stream itself before its blocks are handed on or freed */
+			std::lock_guard<std::mutex> g(plan->dev->upload_mutex);
+			(void)hipStreamSynchronize(plan->dev->upload);
+		}
 	}
 	if (plan->ev_upload) {
 		(void)hipEventSynchronize(plan->ev_upload);      /* (a plan dropped before it was launched: its blocks may be handed on) */
@@ -604,6 +630,14 @@ extern "C" int acmhip_plan_create_packed(acmhip_device *dev, const acmhip_stream
 		 * 32-bit division - rows < 2^32 - and room in the vectors made per stream, not per record) */
 		const uint64_t first = row0 ? row0 - T2 : 0, ntile = (row0 + rows2 - first) / T2;
 		const uint64_t lead_rows = mf ? (uint64_t)T2M * (uint64_t)acmk_tile2m_lead_in(s.level) : 0;      /* (<= T2: two rows more at most) */
+		if (row0 && lead_rows > T2) {
+			/* the records of a window's lead-in are cut from ONE tile in front of it; a build whose first pass needs more rows than
+			 * that in front (level 14: two tiles of two rows) cannot take a window - its streams only ever come here from row 0
+			 * (refused loudly instead of decoded wrong, should a caller ever ask) */
+			set_err("stream %zu: a window on the lean kernel of level %u needs %llu rows in front, a tile has %u", i, s.level,
+				(unsigned long long)lead_rows, T2);
+			return ACMHIP_ERR_ARG;
+		}
 		const uint32_t pk_slots = pk ? (uint32_t)acmk_tile2p_slots(s.level) : 0;
 		const bool twin = !(mf && (flags & ACMHIP_PLAN_FORM_ONLY));
 		/* (room for this stream's records in one step - doubling, or every stream would move the whole table) */

@@ -2203,7 +2203,8 @@ struct FirstPassZ {
 	static constexpr int NSW = TR / RR;                     /* rows a walker walks */
 	static constexpr int NX = NSW + 2;                      /* rows a lane loads per group: its walk and the two rows in front of it */
 	static constexpr int NSET = NSW * NG;                   /* matrix "sets" (sixteen instances x 64 outputs) per chunk: 2048 / 1024 */
-	static constexpr int NE = ((1 + (RR - 1) * NSW + NX - 1) >> 1) + 1;     /* pair-table entries a chunk may read, from the pair in front of it on */
+	static constexpr int NE = (((TR & 1) + (RR - 1) * NSW + NX - 1) >> 1) + 1;      /* pair-table entries a chunk may read, from the pair in front of it on
+										 * (a chunk of one row may start on the second row of a pair) */
 	static constexpr int NM = QN / 16;                      /* output tiles per row */
 	static_assert(NSW * RR == TR && NSET * 1024 == NELEM, "a chunk is whole sets");
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;          /* a P stage leaves odd positions negated */
