@@ -452,13 +452,18 @@ def precondition(dev, plan, bufs, seconds):
     return n
 
 
-def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1, packed=True):
+def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verify=256, channels=1, packed=True, corpus_files=0):
     """kernel-only rate of another configuration (configs[1] is level 7; the stress config is level 11) on every staged form its
     level has: the byte-plane form where there is one (that is the entry's own rate), the int16 form, the packed form.  The PCM
     each set of timed launches leaves behind is compared with the CPU oracle on the first `verify` streams (CRC-32 each)."""
     import oracle_api as O
     from concurrent.futures import ThreadPoolExecutor
-    b = workload.build_uniform(streams, level, rows, blocks, channels=channels, seed0=1 << 20, keep_files=verify)
+    if corpus_files:
+        # configs[2]: the 4000-file corpus (levels 7-9, mono / stereo, ragged) in ONE plan; the first `verify` files are checked
+        b = workload.build_corpus(corpus_files, keep_files=verify, threads=workload.usable_cpus())
+        level, rows, blocks, streams, channels, packed = 9, 16, 0, corpus_files, 0, False
+    else:
+        b = workload.build_uniform(streams, level, rows, blocks, channels=channels, seed0=1 << 20, keep_files=verify)
     bufs = b.upload(dev)
     mf = d_mf = None
     if capi.lib().acmhip_mform_tile_rows(level) > 0:
@@ -496,6 +501,11 @@ def side_measure(dev, capi, workload, level, rows, blocks, streams, steps, verif
                 "frac_hbm": round(rate * ALGO_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(ms / steps, 4),
                 "verified_streams": check()}
     out = {"level": level, "rows": rows, "streams": streams, "blocks": blocks, "channels": channels, "steps": steps, "tiles": int(tiles)}
+    if corpus_files:
+        out.update(level="7-9", blocks="ragged", channels="1|2", msamples_per_launch=round(b.samples / 1e6, 1),
+                   config="BASELINE.json configs[2]: %d-file corpus in one plan" % corpus_files)
+        form = sum(min(plan.form_rows(i) << d.level, d.n_emit) for i, d in enumerate(b.descs))
+        out["samples_from_byteplane_form"] = round(form / max(1, int(b.samples)), 5)
     int16 = timed(plan)
     if mf is not None:
         plan.bind_mform(*d_mf)
@@ -869,6 +879,24 @@ def main():
                      # the same launch on the bytes it really moved (task 6): `achieved` / `frac` price SURVEY's canonical 4 B/sample
                      "achieved_real_gbs": round(traffic / (launch_ms * 1e-3) / 1e9, 1) if traffic else None},
     }
+    # which kernel family decodes what share of the samples (task 3): rows a plan reads from the byte-plane form go to
+    # acm_chunk (levels 8-12) / acm_tile2's matrix builds (7, 13, 14); everything else - ragged tails, streams the form could not take -
+    # is read as int16 by acm_fused_tile and friends.  Asked of the plan stream by stream (acmhip_plan_form_rows), not assumed.
+    if mf and rank == 0:
+        by_level, form_total = {}, 0
+        for i, d in enumerate(batch.descs):
+            fr = plan.form_rows(i) << d.level
+            fr = min(fr, d.n_emit)
+            e = by_level.setdefault(int(d.level), [0, 0])
+            e[0] += fr
+            e[1] += d.n_emit
+            form_total += fr
+        out["config"]["kernel_share"] = {
+            "samples_from_byteplane_form": round(form_total / max(1, int(batch.samples)), 5),
+            "samples_from_int16_form": round(1.0 - form_total / max(1, int(batch.samples)), 5),
+            "by_level": {str(lv): round(a / max(1, b), 5) for lv, (a, b) in sorted(by_level.items())},
+            "note": "byte-plane rows: acm_chunk (levels 8-12) or acm_tile2's matrix build (7, 13, 14); int16 rows: ragged tails and streams "
+                    "without a form (odd block heights, H1 patches) on acm_fused_tile / the register and stage-wise kernels"}
     if args.share_device or args.control == "gloo":
         out["rehearsal"] = ("every rank on GPU 0, control and gather through gloo: the N > 1 plumbing (rank spawn, CPU slices, per-rank lines, "
                             "gather leg) is exercised, the numbers mean nothing")
@@ -951,6 +979,10 @@ def main():
                         extra[-1]["config"] = "BASELINE.json configs[4] at full size"
                 except Exception as e:   # a side measurement must never sink the headline line
                     extra.append({"level": lv, "error": str(e)[:200]})
+            try:
+                extra.append(side_measure(dev, capi, workload, 0, 0, 0, 0, 20, verify=512, corpus_files=4000))
+            except Exception as e:
+                extra.append({"level": "corpus", "error": str(e)[:200]})
             out["other_levels_kernel_only"] = extra
             # ... and their key figures inside `roofline`, which the driver's record keeps whole (task 4): fraction of the 8 TB/s
             # roofline at 4 B/sample, the launch's duration from HIP events, and how many streams' PCM was CRC-compared with the oracle's
@@ -958,12 +990,15 @@ def main():
             for e in extra:
                 if "frac_hbm" not in e:
                     continue
-                name = ("configs4_65536_stereo_streams_level11_rows64" if e.get("config") else
+                name = ("configs2_corpus_4000_files_levels7to9" if str(e.get("config", "")).startswith("BASELINE.json configs[2]") else
+                        "configs4_65536_stereo_streams_level11_rows64" if e.get("config") else
                         "configs1_1024_streams_level7_rows16" if (e["level"], e["rows"], e["blocks"]) == (7, 16, 1000) else
                         "level%d_rows%d_%dstreams" % (e["level"], e["rows"], e["streams"]))
                 oc[name] = {"frac": e["frac_hbm"], "launch_ms": e.get("launch_ms"), "verified_streams": e.get("verified_streams"),
                             "staged_form": e.get("staged_form"), "staged_bytes_per_sample": e.get("staged_bytes_per_sample"),
                             "frac_int16_form": (e.get("int16_form") or {}).get("frac_hbm")}
+                if "samples_from_byteplane_form" in e:
+                    oc[name]["samples_from_byteplane_form"] = e["samples_from_byteplane_form"]
             out["roofline"]["other_configs"] = oc
         if not args.no_extra and not args.no_cpu and len(batch.files) > 4:
             # informational: file bytes -> PCM in host memory through acm_batch_decode (bit parsing on the host pool

@@ -1167,19 +1167,27 @@ extern "C" int acmhip_plan_launch(acmhip_plan *pl, const int16_t *d_idx, const a
 		for (int k = 0; k < 2; k++)
 			HIPTRY(hipStreamWaitEvent(pl->dev->side[k], pl->ev_fork, 0));
 	}
+	/* The lean kernels of every level group, ONE BEHIND THE OTHER on the device stream: each of them fills the chip by itself (the planner
+	 * hands a level's tiles to them only from eight per workgroup on), and the chunk kernel's workgroup IS a CU - two of them overlapping
+	 * on separate streams share the CUs between them and both run at half rate until the shorter one ends, with whatever comes third
+	 * waiting for a whole CU's LDS (the configs[2] corpus, levels 7-9 in one plan: 1.78 ms a step with the groups spread over three
+	 * streams, round 6).  What IS spread over the side streams are the small kernels behind them - the ragged tails on acm_fused_tile -
+	 * which fill the gaps the big ones leave */
+	for (const LevelGroup &g : pl->fused) {
+		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, st));
+		if (pl->pk_chunks)
+			LAUNCHTRY(acmk_launch_tile2p(g.level, pl->dev->cus, g.d_tiles2p, g.ntiles2p, pl->pk_chunks, pl->pk_blob, d_hdr, d_pcm, pl->d_sink, fmt, st));
+		else
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, st));
+		if (pl->mform)
+			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, pl->mform_pairs, d_hdr, d_pcm, pl->d_sink, fmt, st));
+		else
+			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m_plain, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, st));
+	}
 	size_t gi = 0;
 	for (const LevelGroup &g : pl->fused) {
 		void *gs = (!spread || gi % 3 == 0) ? st : (void *)pl->dev->side[gi % 3 - 1];
 		gi++;
-		LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2, g.ntiles2, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
-		if (pl->pk_chunks)
-			LAUNCHTRY(acmk_launch_tile2p(g.level, pl->dev->cus, g.d_tiles2p, g.ntiles2p, pl->pk_chunks, pl->pk_blob, d_hdr, d_pcm, pl->d_sink, fmt, gs));
-		else
-			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2p_plain, g.ntiles2p, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
-		if (pl->mform)
-			LAUNCHTRY(acmk_launch_tile2m(g.level, pl->dev->cus, g.d_tiles2m, g.ntiles2m, pl->mform, pl->mform_pairs, d_hdr, d_pcm, pl->d_sink, fmt, gs));
-		else
-			LAUNCHTRY(acmk_launch_tile2(g.level, pl->dev->cus, g.d_tiles2m_plain, g.ntiles2m_plain, d_idx, d_hdr, d_pcm, pl->d_sink, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, g.carry, pl->d_streams, g.d_tiles, g.ntiles, d_idx, d_hdr, d_pcm, fmt, gs));
 		LAUNCHTRY(acmk_launch_fused(g.level, pl->variant, pl->dev->cus, 0, pl->d_streams, g.d_tiles_extra, g.ntiles_extra, d_idx, d_hdr, d_pcm, fmt, gs));
 	}

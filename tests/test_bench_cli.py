@@ -59,3 +59,26 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert j["gather_c2"]["bytes_into_rank0"] > 0 and j["gather_c2"]["seconds"] > 0
     assert "rehearsal" in j and "multi_gpu" not in j
     assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_the_sharded_corpus():
+    """VERDICT r5, task 7: the STRONG-scaling leg - `--workload corpus` sharded over two ranks (longest first by header weight), still on
+    one GPU through gloo: the shards differ (imbalance just above 1), every stream of both shards is verified against the oracle,
+    the gather leg moves two ragged PCM arenas of different sizes, and the line says which share of the samples the byte-plane
+    kernels decode"""
+    import json
+    r = run_bench(["--gpus", "2", "--control", "gloo", "--share-device", "--workload", "corpus", "--files", "120", "--steps", "3", "--warmup", "1",
+                   "--no-extra", "--no-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["verified_vs_oracle"] is True and j["verified_streams"] == 120
+    assert [p["rank"] for p in j["per_rank"]] == [0, 1] and sum(p["streams"] for p in j["per_rank"]) == 120
+    assert 1.0 <= j["imbalance"]["samples_max_over_mean"] <= 1.05                  # ragged shards that longest-first cutting keeps close
+    assert all(p["streams"] > 0 and p["launch_ms"] > 0 for p in j["per_rank"])
+    assert j["gather_c2"]["bytes_into_rank0"] > 0 and j["gather_c2"]["seconds"] > 0
+    ks = j["config"]["kernel_share"]
+    assert set(ks["by_level"]) == {"7", "8", "9"} and ks["samples_from_byteplane_form"] > 0.9
+    assert "rehearsal" in j
