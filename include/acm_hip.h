@@ -128,7 +128,9 @@ int  acmhip_memset(acmhip_device *dev, void *dptr, int byte, size_t bytes);     
  * value = idx * val, the cascade of decode.c:508-577, the four writers of :617-655, bit-exact.  It is what acm_read() (include/libacm.h)
  * runs on a box without a usable HIP device, and for streams shorter than acmhip_host_synth_limit() samples while no device handle is
  * open in the process (bringing the HIP runtime up costs more than such a stream's whole decode).  The plan and batch calls never use it.
- * limit: default 8 Msamples; 0 = the host path only where no device exists; UINT64_MAX = never the device from acm_read().
+ * limit: default 128 Msamples (2^27) - measured, not guessed: through acmtool -d on an MI355X box a 41-Msample stream takes 0.16 s on the
+ * host path (a few threads over independent tiles), 0.37 - 0.43 s through the GPU (the runtime comes up, the window crosses PCIe twice)
+ * and 0.27 s in the reference; at 164 Msamples the two paths meet (0.56 s; the reference: 1.0 s).  0 = the host path only where no device exists; UINT64_MAX = never the device from acm_read().
  */
 int  acmhip_host_synth(const acmhip_stream_desc *stream, const int16_t *idx, const acmhip_blkhdr *hdr,
 		       const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm);

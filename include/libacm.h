@@ -30,7 +30,7 @@
  * window whose blocks were bit-parsed on the host and synthesised
  * (amplitude-table unpack, subband synthesis, 16-bit write-out) on the GPU -
  * or, where no usable HIP device exists, and for streams shorter than
- * acmhip_host_synth_limit() samples (include/acm_hip.h; 8 M by default) while
+ * acmhip_host_synth_limit() samples (include/acm_hip.h; 128 M by default) while
  * no device is open in the process, by the library's own host synthesis
  * (csrc/acm_host_synth.cpp): like the reference, this API decodes anywhere.
  */

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <vector>
 
 #if defined(__x86_64__)
@@ -34,7 +35,7 @@
 
 namespace {
 
-std::atomic<uint64_t> g_host_limit{ 8ull << 20 };
+std::atomic<uint64_t> g_host_limit{ 1ull << 27 };    /* where the two paths meet for ONE stream through acm_read(): include/acm_hip.h */
 
 /* one stage over n samples in place; w[-2 s .. -1] must be readable (the rows in front, or zeros) */
 void stage_scalar(uint32_t *w, size_t n, size_t s)
@@ -142,41 +143,60 @@ extern "C" int acmhip_host_synth(const acmhip_stream_desc *s, const int16_t *idx
 	std::sort(ps.begin(), ps.end(), [](const acmhip_patch &a, const acmhip_patch &b) { return a.sample < b.sample; });
 
 	/* tile = T rows + the two in front of them, about a megabyte of int32 (the level-2 cache); `cols` zeros in front of the buffer are what
-	 * the first two rows of a stream see where their inputs would be */
+	 * the first two rows of a stream see where their inputs would be.  Tiles are independent (that is the point of the formulation): a
+	 * long window is shared out among a few threads, tile by tile */
 	const size_t T = std::max<size_t>(2, ((size_t)256 << 10) / cols);
-	std::vector<uint32_t> buf(cols + (T + 2) * cols);
-	uint32_t *const base = buf.data() + cols;
-
-	for (uint64_t r0 = s->row_begin; r0 < s->row_begin + rows_out; r0 += T) {
-		const uint64_t r1 = std::min<uint64_t>(r0 + T, s->row_begin + rows_out);
-		const uint64_t rh = r0 >= 2 ? r0 - 2 : 0;               /* first row of the tile's input */
-		const size_t n = (size_t)(r1 - rh) * cols;
-		/* unpack: value = idx * val of the row's block (decode.c:592-600, :174-177) */
-		for (uint64_t r = rh; r < r1; r++) {
-			const uint32_t val = h[r / s->rows].val;
-			const int16_t *x = src + (r << level);
-			uint32_t *w = base + (size_t)(r - rh) * cols;
-			for (size_t c = 0; c < cols; c++)
-				w[c] = (uint32_t)((int32_t)x[c] * (int32_t)val);
+	const uint64_t row_end = s->row_begin + rows_out;
+	const uint64_t ntiles = (rows_out + T - 1) / T;
+	std::atomic<uint64_t> next{ 0 };
+	auto work = [&]() {
+		std::vector<uint32_t> buf(cols + (T + 2) * cols);
+		uint32_t *const base = buf.data() + cols;
+		for (uint64_t t = next.fetch_add(1); t < ntiles; t = next.fetch_add(1)) {
+			const uint64_t r0 = s->row_begin + t * T;
+			const uint64_t r1 = std::min<uint64_t>(r0 + T, row_end);
+			const uint64_t rh = r0 >= 2 ? r0 - 2 : 0;               /* first row of the tile's input */
+			const size_t n = (size_t)(r1 - rh) * cols;
+			/* unpack: value = idx * val of the row's block (decode.c:592-600, :174-177) */
+			for (uint64_t r = rh; r < r1; r++) {
+				const uint32_t val = h[r / s->rows].val;
+				const int16_t *x = src + (r << level);
+				uint32_t *w = base + (size_t)(r - rh) * cols;
+				for (size_t c = 0; c < cols; c++)
+					w[c] = (uint32_t)((int32_t)x[c] * (int32_t)val);
+			}
+			if (!ps.empty()) {
+				const uint64_t lo = rh << level, hi = r1 << level;
+				auto it = std::lower_bound(ps.begin(), ps.end(), lo, [](const acmhip_patch &p, uint64_t v) { return p.sample < v; });
+				for (; it != ps.end() && it->sample < hi; ++it)
+					base[it->sample - lo] = (uint32_t)it->value;
+			}
+			memset(buf.data(), 0, cols * sizeof(uint32_t));
+			size_t st = cols >> 1;
+			for (unsigned k = 0; k < level; k++, st >>= 1) {
+				run_stage(base, n, st);
+				if (k == 0)
+					for (size_t m = 0; m < n; m += cols / 2)       /* decode.c:561-564 */
+						base[m] += 1u;
+			}
+			const size_t skip = (size_t)(r0 - rh) * cols;
+			const uint64_t first = (r0 - s->row_begin) << level;
+			const size_t want = (size_t)std::min<uint64_t>((r1 - r0) << level, s->n_emit - first);
+			emit(base + skip, want, level, fmt, dst + first);
 		}
-		if (!ps.empty()) {
-			const uint64_t lo = rh << level, hi = r1 << level;
-			auto it = std::lower_bound(ps.begin(), ps.end(), lo, [](const acmhip_patch &p, uint64_t v) { return p.sample < v; });
-			for (; it != ps.end() && it->sample < hi; ++it)
-				base[it->sample - lo] = (uint32_t)it->value;
-		}
-		memset(buf.data(), 0, cols * sizeof(uint32_t));
-		size_t st = cols >> 1;
-		for (unsigned k = 0; k < level; k++, st >>= 1) {
-			run_stage(base, n, st);
-			if (k == 0)
-				for (size_t m = 0; m < n; m += cols / 2)       /* decode.c:561-564 */
-					base[m] += 1u;
-		}
-		const size_t skip = (size_t)(r0 - rh) * cols;
-		const uint64_t first = (r0 - s->row_begin) << level;
-		const size_t want = (size_t)std::min<uint64_t>((r1 - r0) << level, s->n_emit - first);
-		emit(base + skip, want, level, fmt, dst + first);
+	};
+	/* (a thread per 2 Msamples, eight at most, never more than the machine has; short windows - the first ones of every stream - stay on
+	 * the caller's thread) */
+	unsigned nthreads = (unsigned)std::min<uint64_t>({ 8, s->n_emit >> 21, ntiles, std::max(1u, std::thread::hardware_concurrency()) });
+	if (nthreads <= 1) {
+		work();
+	} else {
+		std::vector<std::thread> pool;
+		for (unsigned k = 1; k < nthreads; k++)
+			pool.emplace_back(work);
+		work();
+		for (std::thread &th : pool)
+			th.join();
 	}
 	return ACMHIP_OK;
 }

@@ -798,8 +798,8 @@ extern "C" int acm_stage_file(const uint8_t *data, size_t len, int force_chans,
  * (16 KB at level 9: the first-level cache, where the column scatter of the parser costs nothing), its row pairs go to the byte-plane
  * writer from there, and only the rows the int16 kernels still read - from two rows in front of the ragged tail on - are copied to
  * idx.  Against acm_stage_file + acmhip_mform_rows this drops the 2 B per sample written to and read back from the int16 arena.
- * *mf_rows = rows [0, *mf_rows) are in the form (whole tiles of the lean kernel); 0: the stream has none (a level without the form, an
- * odd acm_rows, H1 patches, an index beyond the form's range, a file that ends early) and idx holds every row as acm_stage_file
+ * *mf_rows = rows [0, *mf_rows) are in the form (whole tiles of the lean kernel); 0: the stream has none (a level without the form,
+ * H1 patches, an index beyond the form's range, a file that ends early) and idx holds every row as acm_stage_file
  * leaves it - except that with patches (info->npatches != 0) the caller stages once more with room for them.
  */
 #include "acm_device.h"
@@ -823,7 +823,7 @@ extern "C" int acm_stage_file_mform(const uint8_t *data, size_t len, int force_c
 	const int T2 = acmk_tile2_rows(level), TM = acmhip_mform_tile_rows(level);
 	/* (levels 13 / 14: whether a plan takes such a stream's form is known only from the whole plan - acmhip_plan_form_rows - so its
 	 * int16 rows may all be needed: the plain way) */
-	if (!mf_out || !pairs || T2 <= 0 || TM <= 0 || (rows & 1) || T2 % TM || level > ACM_K1_MAX_LEVEL)
+	if (!mf_out || !pairs || T2 <= 0 || TM <= 0 || T2 % TM || level > ACM_K1_MAX_LEVEL)
 		return plain();
 	const size_t bl = c.a.block_len, cols = (size_t)1 << level;
 	const uint64_t need = ((uint64_t)c.a.total_values + bl - 1) / bl;
@@ -845,7 +845,7 @@ extern "C" int acm_stage_file_mform(const uint8_t *data, size_t len, int force_c
 	if (rows2 == 0)
 		return plain();
 	const uint64_t tail_from = rows2 >= 2 ? rows2 - 2 : 0;
-	std::vector<int16_t> block(bl);
+	std::vector<int16_t> block(bl), straddle((rows & 1) ? 2 * cols : 0);
 	AcmMformWriter w;
 	if (acm_mform_begin(&w, level, mf_out, mf_base, pairs) != ACMHIP_OK)
 		return plain();
@@ -863,9 +863,25 @@ extern "C" int acm_stage_file_mform(const uint8_t *data, size_t len, int force_c
 		if (!found.empty())
 			return plain();                 /* H1: the stream keeps the int16 form (and the caller stages again, for the patches) */
 		const uint64_t r0 = b * rows;
-		for (uint32_t r = 0; r < rows; r += 2)
-			if (r0 + r < rows2 && acm_mform_put_pair(&w, block.data() + (size_t)r * cols) != ACMHIP_OK)
+		/* row pairs count from the stream's row 0: with an odd acm_rows every other block starts on the second row of a pair, whose
+		 * first row is the last one of the block before (kept in `straddle`) */
+		for (uint32_t r = 0; r < rows && r0 + r < rows2;) {
+			const int16_t *two = block.data() + (size_t)r * cols;
+			if ((r0 + r) & 1) {
+				memcpy(straddle.data() + cols, two, cols * sizeof(int16_t));
+				two = straddle.data();
+				r += 1;
+			} else if (r + 1 < rows) {
+				r += 2;
+			} else {
+				if (straddle.empty())
+					straddle.resize(2 * cols);
+				memcpy(straddle.data(), two, cols * sizeof(int16_t));
+				break;
+			}
+			if (acm_mform_put_pair(&w, two) != ACMHIP_OK)
 				return plain();         /* an index beyond the form's range */
+		}
 		if (r0 + rows > tail_from) {
 			const uint32_t from = r0 >= tail_from ? 0u : (uint32_t)(tail_from - r0);
 			memcpy(idx + (r0 + from) * cols, block.data() + (size_t)from * cols, (size_t)(rows - from) * cols * sizeof(int16_t));

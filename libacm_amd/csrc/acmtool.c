@@ -846,7 +846,7 @@ int main(int argc, char *argv[])
 	if (optind == argc)
 		usage(1);
 	detach_teardown();              /* from here on this is the child: nothing has touched the GPU yet */
-	/* ACMTOOL_HOST_LIMIT=<samples>: streams shorter than this are synthesised on the host (the library's default: 8 M; 0 = every
+	/* ACMTOOL_HOST_LIMIT=<samples>: streams shorter than this are synthesised on the host (the library's default: 128 M; 0 = every
 	 * stream on the GPU where there is one) */
 	if (getenv("ACMTOOL_HOST_LIMIT"))
 		acmhip_set_host_synth_limit(strtoull(getenv("ACMTOOL_HOST_LIMIT"), NULL, 10));

@@ -19,7 +19,7 @@ def dev():
     from libacm_amd import capi
     d = capi.Device(0)
     # GPU tests test the GPU: acm_read() of the drop-in API goes to the device whatever the stream's length (by default streams below
-    # 8 Msamples are synthesised on the host while no device is open: include/acm_hip.h, acmhip_set_host_synth_limit)
+    # 128 Msamples are synthesised on the host while no device is open: include/acm_hip.h, acmhip_set_host_synth_limit)
     L = capi.lib()
     prev = L.acmhip_host_synth_limit()
     L.acmhip_set_host_synth_limit(0)

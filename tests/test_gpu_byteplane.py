@@ -330,6 +330,27 @@ def test_batch_decode_stages_byteplanes(dev, prestage):
             assert np.array_equal(res[k][1], oracle_pcm(f)[0]), k
 
 
+@pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
+def test_batch_stages_odd_block_heights(dev, level):
+    """VERDICT r5, task 3 (ii): streams whose acm_rows is odd - row pairs that straddle block boundaries, a val change INSIDE a pair - get
+    the byte-plane form from the host parsing pass itself (acm_stage_file_mform) and are decoded from it by the chunk kernel: block
+    heights 1, 3, 17, 33, mono and stereo, ragged ends, all three width classes"""
+    files = [make_stream(33000 + 50 * level + i, level, rows, max(3, (9 * plan_rows(level) + rows - 1) // rows + i), channels=1 + i % 2, cut=i,
+                         pwr_min=[4, 8, 6, 12][i % 4], pwr_max=[12, 10, 9, 12][i % 4])
+             for i, rows in enumerate([1, 3, 17, 33, 3, 1, 33, 17])]
+    res, tm = capi.batch_decode(dev, files, threads=4)
+    assert tm.packed_streams == len(files), tm.packed_streams               # every one of them travelled in the form
+    plain, tm0 = capi.batch_decode(dev, files, threads=4, byteplane=False)
+    assert tm0.packed_streams == 0 and tm.h2d_bytes < tm0.h2d_bytes
+    for k, f in enumerate(files):
+        want, wst = oracle_pcm(f)
+        assert res[k][0] == wst and np.array_equal(res[k][1], want), (level, k)
+        assert np.array_equal(plain[k][1], want), (level, k)
+    # and through the plan API, with the form staged in two passes (acm_stage_file + acmhip_mform_rows): tiles really come from the form
+    st = check(dev, files[:4])
+    assert st.mform_tiles >= 4 * 9
+
+
 def test_batch_first_call_on_a_fresh_device_with_small_high_level_streams():
     """a byte-plane batch must not rely on int16 rows an EARLIER call left in the device arena.  A few level-13 / 14 streams are
     too few tiles for the lean kernel (the plan sends them to the prefix + plane pair, which reads the int16 arena from row 0): their

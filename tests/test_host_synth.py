@@ -91,7 +91,7 @@ def test_argument_checks():
     d.n_emit = 64
     assert L.acmhip_host_synth(C.byref(d), s.idx.ctypes.data, s.hdr.ctypes.data, None, 0, 7, out.ctypes.data) == capi.ERR_ARG      # no such format
     assert L.acmhip_host_synth(C.byref(d), s.idx.ctypes.data, s.hdr.ctypes.data, None, 0, 0, out.ctypes.data) == 0
-    assert L.acmhip_host_synth_limit() == 8 << 20       # the default: streams below 8 Msamples stay on the host while no device is open
+    assert L.acmhip_host_synth_limit() == 1 << 27       # the default: streams below 128 Msamples stay on the host while no device is open
 
 
 def test_acm_read_takes_the_host_path_for_short_streams_by_default():
