@@ -255,8 +255,12 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  *                                  nibble of byte b, element 8 d + 4 + b in the low one (x & 0xf0f0f0f0 and (x << 4) & 0xf0f0f0f0
  *                                  are then the matrix operand bytes hi << 4 of elements 8 d .. + 3 and 8 d + 4 .. + 7)
  *             ACMHIP_BP_WORD  (3)  idx = 256 hi + lo with BOTH bytes signed: 64 low bytes, then 64 high bytes.  That ends at
- *                                  32 639: a stream with a larger index (it takes pwr 15) cannot be written -
- *                                  acmhip_mform_rows returns ACMHIP_ERR_RANGE and the stream stays in the int16 form
+ *                                  32 639; a pair with a larger index (it takes pwr 15) is written as
+ *             ACMHIP_BP_WORDU (0)  levels 8-12 only: idx = 256 hi + lo with hi = idx >> 8 (signed) and lo the UNSIGNED low byte,
+ *                                  stored minus 128 ((idx & 0xff) ^ 0x80: a signed byte for the matrix instruction; the kernel
+ *                                  adds 128 x val x the coefficient row sums of such rows back): the whole int16 range, same
+ *                                  64 + 64 bytes.  At levels 13 / 14 (acm_tile2, which knows no such class) acmhip_mform_rows
+ *                                  returns ACMHIP_ERR_RANGE for such a stream and it stays in the int16 form
  * G = 8, level 7 (three stages, acm_tile2; also levels 8-9, and G = 16 at 10-14, in a -DACM_TUNING build run with ACM_K3=0).  The
  * pair in front is at 4 bits.  Per residue:
  *             ACMHIP_BP_WORD    G low bytes ((idx & 0xff) ^ 0x80: signed bytes, the kernel adds the 128 back through the
@@ -270,6 +274,7 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  * form of a level follows the kernel the build ships for it.
  * ---------------------------------------------------------------------- */
 typedef uint32_t acmhip_mform_pair;
+#define ACMHIP_BP_WORDU  0u     /* the six-stage form of levels 8-12: 16 bits over the WHOLE int16 range (see above) */
 #define ACMHIP_BP_NIBBLE 1u
 #define ACMHIP_BP_NIB12  1u     /* the same code in the six-stage form of levels 8-12 (which has no 4-bit class): 12 bits, see above */
 #define ACMHIP_BP_BYTE   2u

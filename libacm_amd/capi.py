@@ -336,7 +336,8 @@ class MformArena:
         return self.data.nbytes + self.pairs.nbytes
 
     def class_counts(self):
-        """row pairs per width class (index 1: 4 bits, 2: 8 bits, 3: 16 bits per index)"""
+        """pair-table entries per class code: 1 = 12 bits at levels 8-12 (4 bits in level 7's form), 2 = 8 bits, 3 = 16 bits as two signed
+        bytes; 0 = 16 bits over the whole int16 range at levels 8-12 - and the table's 32 entries of read slack, which are zeros"""
         return np.bincount(self.pairs & 3, minlength=4)
 
 

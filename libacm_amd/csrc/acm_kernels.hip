@@ -2234,6 +2234,8 @@ struct FirstPassZ {
 	struct Tables {
 		v4i_t coef[3][NM][64];          /* [j][mt][lane]: T_j[16 mt + lane % 16][16 (lane / 16) .. + 15] */
 		int32_t bias[3][2][QN];         /* [rows in front that exist][lane owns residue 0: 0, else 1][q], scaled */
+		int32_t rsum[3][QN];            /* [j][q]: 128 x the sum of row q of T_j - what a row stored with its low bytes minus 128
+						 * (ACMHIP_BP_WORDU) is short of, per unit of val */
 	};
 
 	static __device__ __forceinline__ void fill_tables(Tables &t, const int tid, const int nthreads)
@@ -2246,6 +2248,12 @@ struct FirstPassZ {
 		for (int k = tid; k < 3 * 2 * QN; k += nthreads) {
 			const int var = k / (2 * QN), par = (k / QN) & 1, q = k % QN;
 			t.bias[var][par][q] = par ? 0 : ACM_TZ6_BIAS[VARIANT][var][q] * ONE;
+		}
+		for (int k = tid; k < 3 * QN; k += nthreads) {
+			int32_t sum = 0;
+			for (int c = 0; c < 64; c++)
+				sum += ACM_TZ6[VARIANT][k / QN][k % QN][c];
+			t.rsum[k / QN][k % QN] = 128 * sum;
 		}
 	}
 
@@ -2326,9 +2334,9 @@ struct FirstPassZ {
 	 */
 	static constexpr int JM = (TR & 1) ? 1 : TR / 2;         /* pair-table entries 0 .. JM hold the rows in reach of a chunk */
 	static_assert(JM + 1 <= NE, "entries in reach are entries fetched");
-	/* HALF-bytes per index of a width class: ACMHIP_BP_NIB12 (1) 3, _BYTE (2) 2, _WORD (3) 4; a row of a pair takes COLS / 2 times that many
+	/* HALF-bytes per index of a width class: ACMHIP_BP_WORDU (0) 4, _NIB12 (1) 3, _BYTE (2) 2, _WORD (3) 4; a row of a pair takes COLS / 2 times that many
 	 * bytes, the QN indices of a residue class QN / 2 times (their low bytes first, the high bytes - or nibbles - 64 bytes on) */
-	static __device__ __forceinline__ uint32_t half_bytes(const uint32_t cls) { return (0x4230u >> (4u * cls)) & 15u; }
+	static __device__ __forceinline__ uint32_t half_bytes(const uint32_t cls) { return (0x4234u >> (4u * cls)) & 15u; }
 	/* J0: the first entry whose rows the chunk's loads ask for (1 where the rows in front stay in registers).
 	 * Returns the mode: 0 general; else fast with every pair in reach at 8 (1), 16 (2) or 12 bits (3) */
 	template <int J0>
@@ -2496,9 +2504,13 @@ struct FirstPassZ {
 	 * FAST (mode_of): one val, below 2^16 as scaled, over every row in reach - the scalar sval; hvs is not looked at.  No differences,
 	 * no branches per set, the multipliers are scalar operands: per output ONE instruction per plane. */
 	/* NIB (FAST only): the high plane's rows are 12-bit rows in N form (expand_nib): scaled by val << 4, a signed multiply */
+	/* wordu (general path): some row in reach is stored with its low bytes minus 128 (ACMHIP_BP_WORDU: idx = 256 hi + (lo + 128)): such a row's
+	 * share of an output is short of 128 x val x the row sum of its matrix.  Which rows: from the pair-table entries *dd, for the walker
+	 * whose OUTPUTS the lane receives */
 	template <bool WORDS, bool FAST, bool NIB = false>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const uint32_t hvs,
-						     const uint32_t in_front, const uint32_t sval)
+						     const uint32_t in_front, const uint32_t sval, const bool wordu = false, const Desc *dd = nullptr,
+						     const uint32_t odd = 0u)
 	{
 		static_assert(!NIB || (WORDS && FAST), "rows in N form are a fast-path matter; the general path takes them to bytes first");
 		const v4i_t zero = { 0, 0, 0, 0 };
@@ -2650,6 +2662,22 @@ struct FirstPassZ {
 					for (int v = 0; v < 4; v++)
 						y[v] += __mul24(l1[v], dv1[s][v / NVH]);
 				}
+				if constexpr (WORDS && NH == 1) {
+					if (wordu) {
+						/* rows of the whole-range 16-bit class in reach: 128 x val of the row x the row sum of its matrix, per output q */
+						const int32_t *rs = &t.rsum[0][0] + 16 * mt + (int)qd;
+						bool urow[3];
+#pragma unroll
+						for (int j = 0; j < 3; j++)
+							urow[j] = (entry_of(*dd, (TR & 1 ? odd : 0u) + rrd[0] * NSW + (uint32_t)(s + j)) & 3u) == ACMHIP_BP_WORDU;
+						/* (row values are below 2^22 as scaled, the sums below 2^18: 24-bit multiplies, exact mod 2^32) */
+						const int32_t v0 = val[s][0], v1 = v0 + dv2[s][0], v2 = v1 + dv1[s][0];
+						const int32_t add = __mul24(urow[2] ? v0 : 0, rs[0]) + __mul24(urow[1] ? v1 : 0, rs[QN]) + __mul24(urow[0] ? v2 : 0, rs[2 * QN]);
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							y[v] += add;
+					}
+				}
 				if constexpr (WORDS) {
 					const v4i_t h1 = mfma(hi[g][s], cf2, zero);
 					const v4i_t h2 = mfma(hi[g][s + 1], cf1, h1);
@@ -2758,12 +2786,14 @@ struct FirstPassZ {
 				run_t<false, true>(raw, tile, t, lane, 0u, in_front, sval);
 			return;
 		}
-		uint32_t any_word = 0, any_nib = 0;
+		uint32_t any_word = 0, any_nib = 0, any_wordu = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++) {
 			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
 			any_nib |= (d.e[j] & 3u) == ACMHIP_BP_NIB12 ? 1u : 0u;
+			any_wordu |= (d.e[j] & 3u) == ACMHIP_BP_WORDU ? 1u : 0u;
 		}
+		any_word |= any_wordu;
 		const uint32_t rr = RR == 1 ? 0u : ((uint32_t)lane & 15u) / SIGMA;
 		if (any_nib) {
 			/* the rows just loaded that are 12-bit rows: to N form (before a partner lane takes them as its history) */
@@ -2796,7 +2826,7 @@ struct FirstPassZ {
 						raw.hi[g][k] = sra4(raw.hi[g][k]);
 				}
 			}
-			run_t<true, false>(raw, tile, t, lane, hvs, in_front, 0u);
+			run_t<true, false>(raw, tile, t, lane, hvs, in_front, 0u, any_wordu != 0, &d, odd);
 			if (any_nib && KEEPS_ROWS) {
 #pragma unroll
 				for (int k = NSW; k < NX; k++)

@@ -272,6 +272,8 @@ inline uint32_t pair_bytes(uint32_t level, uint32_t cls)
 {
 	if (cls == ACMHIP_BP_NIB12 && split_form((size_t)acmhip_mform_group(level)))
 		return 3u << level;                     /* two rows of 1.5 bytes per index */
+	if (cls == ACMHIP_BP_WORDU)
+		return 4u << level;                     /* (16 bits, the low byte unsigned) */
 	return (4u << level) >> (3 - cls);             /* two rows of 2 / 1 / 0.5 bytes per index */
 }
 #if defined(__SSE2__)
@@ -396,6 +398,12 @@ void get_row_nib12(const uint8_t *src, size_t sigma, int16_t *dst)
 /* one row at width class cls: per residue c < sigma the qn indices of columns c + q * sigma */
 void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, uint8_t *dst)
 {
+	if (split && cls == ACMHIP_BP_WORDU) {
+		/* the whole int16 range: the low byte unsigned, stored minus 128 - byte for byte what the 8 / 16-column forms write as their
+		 * 16-bit class */
+		cls = ACMHIP_BP_WORD;
+		split = false;
+	}
 #if defined(__SSE2__)
 	if (put_row_sse(src, sigma, qn, cls, split, dst))
 		return;
@@ -439,6 +447,10 @@ void put_row(const int16_t *src, size_t sigma, size_t qn, uint32_t cls, bool spl
 }
 void get_row(const uint8_t *src, size_t sigma, size_t qn, uint32_t cls, bool split, int16_t *dst)
 {
+	if (split && cls == ACMHIP_BP_WORDU) {
+		cls = ACMHIP_BP_WORD;
+		split = false;
+	}
 	if (split && cls == ACMHIP_BP_NIB12) {
 		get_row_nib12(src, sigma, dst);
 		return;
@@ -517,10 +529,12 @@ int acm_mform_put_pair(AcmMformWriter *w, const int16_t *src)
 		hi = src[m] > hi ? src[m] : hi;
 	}
 #endif
-	if (w->split && hi >= 32640)
-		return ACMHIP_ERR_RANGE;          /* 256 hi + lo with two signed bytes ends at 32639: such a stream stays in the int16 form */
+	/* 256 hi + lo with two signed bytes ends at 32639.  At the chunk kernel's own levels a pair beyond that is written with the unsigned
+	 * low byte (class 0: the kernel's general path puts the 128 back); at levels 13 / 14 such a stream stays in the int16 form */
+	if (w->split && hi >= 32640 && !w->nib12)
+		return ACMHIP_ERR_RANGE;
 	const uint32_t cls = (!w->split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE :
-			     (w->nib12 && lo >= -2176 && hi <= 1919) ? ACMHIP_BP_NIB12 : ACMHIP_BP_WORD;
+			     (w->nib12 && lo >= -2176 && hi <= 1919) ? ACMHIP_BP_NIB12 : (w->split && hi >= 32640) ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
 	if (((w->blob_base + w->at) >> 6) >= (1ull << 30))
 		return ACMHIP_ERR_ARG;
 	w->pairs[w->npairs++] = (acmhip_mform_pair)(((w->blob_base + w->at) >> 6) << 2 | cls);
@@ -544,7 +558,7 @@ int acm_mform_get_pair(uint32_t level, const uint8_t *blob, acmhip_mform_pair en
 		return ACMHIP_ERR_ARG;
 	const size_t cols = (size_t)1 << level, sigma = cols / qn;
 	const uint32_t cls = entry & 3;
-	if (cls < ((split_form(qn) && !nib12_level(level)) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE) || cls > ACMHIP_BP_WORD)
+	if (cls > ACMHIP_BP_WORD || cls < (nib12_level(level) ? ACMHIP_BP_WORDU : split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE))
 		return ACMHIP_ERR_ARG;
 	const uint8_t *src = blob + ((uint64_t)(entry >> 2) << 6);
 	const size_t rowb = pair_bytes(level, cls) / 2;

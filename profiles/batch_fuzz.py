@@ -38,7 +38,7 @@ with capi.Device(0) as dev:
             files.append(f)
         mode = int(rng.integers(0, 3))
         R = int(rng.choice([1, 2, 3, 5, 8, 16]))
-        os.environ["ACM_BATCH_RANGES"] = str(R)
+        capi.BATCH_EXTRA = capi.batch_ranges(R)
         res, tm = capi.batch_decode(dev, files, threads=int(rng.integers(1, 9)), pinned=bool(rng.integers(0, 2)),
                                     parse=capi.PARSE_DEVICE if mode == 1 else capi.PARSE_HOST, prestage=mode == 2)
         flagged += tm.host_parsed if mode == 1 else 0

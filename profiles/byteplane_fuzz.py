@@ -19,7 +19,7 @@ from libacm_amd import capi  # noqa: E402
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 bad = streams = packed_tiles = packed_streams = 0
-os.environ["ACM_K2"] = "1"
+capi.PLAN_EXTRA = capi.PLAN_LEAN_ALWAYS            # (what ACM_K2=1 used to ask for: the lean kernels for small plans too)
 with capi.Device(0) as dev:
     for b in range(batches):
         if os.environ.get("ACM_FUZZ_TRACE"):
@@ -31,7 +31,7 @@ with capi.Device(0) as dev:
             rows = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 64, 70]))
             tr = max(2, 8192 >> lv)
             nb = int(rng.integers(1, max(2, min(400, (int(rng.integers(1, 9)) * tr) // rows + 3))))
-            pm = int(rng.choice([3, 5, 7, 9, 12, 15]))
+            pm = int(rng.choice([3, 5, 7, 8, 9, 10, 11, 12, 15]))         # (8-10: the 12-bit class of levels 8-12; 11: just beyond it)
             pmin = int(rng.choice([3, min(4, pm), pm]))
             kw = dict(channels=int(rng.integers(1, 3)), cut=int(rng.integers(0, 7)), pwr_min=min(pmin, pm), pwr_max=pm,
                       val_max=65535 if rng.random() < 0.3 else 255)
@@ -77,12 +77,13 @@ with capi.Device(0) as dev:
                     print("batch %d (plan API, fmt %d): stream differs" % (b, fmt), flush=True)
         # (b) batch front end
         mode = int(rng.integers(0, 3))             # host parsing, host parsing ahead of the call, device parsing in 1 ... 16 block ranges
-        os.environ["ACM_BATCH_RANGES"] = str(int(rng.choice([1, 2, 3, 5, 8, 16])))
+        ranges_now = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        capi.BATCH_EXTRA = capi.batch_ranges(ranges_now)
         threads, pinned = int(rng.integers(1, 9)), bool(rng.integers(0, 2))
         if "b" not in part:
             continue
         if only is not None:
-            print("  batch half: mode %d ranges %s threads %d pinned %s" % (mode, os.environ["ACM_BATCH_RANGES"], threads, pinned), flush=True)
+            print("  batch half: mode %d ranges %s threads %d pinned %s" % (mode, ranges_now, threads, pinned), flush=True)
         res, tm = capi.batch_decode(dev, files, threads=threads, pinned=pinned, prestage=mode == 1,
                                     parse=capi.PARSE_DEVICE if mode == 2 else capi.PARSE_HOST, byteplane=True if mode == 1 else None)
         packed_streams += tm.packed_streams

@@ -42,8 +42,8 @@ def test_round_trip(level, rows, pwr_max):
     split = qn == 64                                     # the chunk kernel's form: 8 and 16 bits only, idx = 256 hi + lo with both bytes signed
     s = capi.stage_file(make_stream(41000 + level * 100 + rows, level, rows, nblocks, pwr_min=min(2, pwr_max), pwr_max=pwr_max,
                                     val_max=65535 if pwr_max == 15 else 255))
-    if split and int(s.idx.max()) >= 32640:
-        s.idx[s.idx >= 32640] = 32639                    # (beyond that the form has no place for an index: test_split_form_range)
+    if split and level >= 13 and int(s.idx.max()) >= 32640:
+        s.idx[s.idx >= 32640] = 32639                    # (beyond that the form of levels 13 / 14 has no place for an index: test_split_form_range)
     cols = 1 << level
     d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows * cols, level=level, rows=rows,
                         nrows=s.info.blocks * rows, row_begin=0)
@@ -65,9 +65,9 @@ def test_round_trip(level, rows, pwr_max):
     lo, hi = rowsv.min(axis=1), rowsv.max(axis=1)
     nib12 = split and level <= 12                        # the chunk kernel's own levels: a 12-bit class (signed low byte + signed high nibble)
     want_cls = np.where((lo >= -8) & (hi <= 7) & (not split), 1, np.where((lo >= -128) & (hi <= 127), 2,
-                        np.where((lo >= -2176) & (hi <= 1919) & nib12, 1, 3)))
+                        np.where((lo >= -2176) & (hi <= 1919) & nib12, 1, np.where((hi >= 32640) & nib12, 0, 3))))
     assert np.array_equal(cls[1:], want_cls)
-    size = np.array([0, 3 * cols if nib12 else cols, 2 * cols, 4 * cols])[cls]
+    size = np.array([4 * cols, 3 * cols if nib12 else cols, 2 * cols, 4 * cols])[cls]
     assert np.array_equal(off[1:], off[:-1] + size[:-1])
     assert off[-1] + size[-1] + 64 <= mf.data.size <= capi.lib().acmhip_mform_bytes(level, nrows) + 256
     back = capi.mform_unrows(level, mf.data, pairs, nrows)
@@ -80,7 +80,10 @@ def test_round_trip(level, rows, pwr_max):
         x = int(s.idx[(2 * p + r) * cols + c + q * sigma])
         k = int(cls[p + 1])
         at = int(off[p + 1]) + r * int(size[p + 1]) // 2
-        if k == 3 and split:
+        if k == 0:
+            # levels 8-12, a pair with an index beyond 32639: the low byte unsigned, stored minus 128; the arithmetic high byte
+            assert split and mf.data[at + 2 * qn * c + q] == (x & 0xFF) ^ 0x80 and mf.data[at + 2 * qn * c + qn + q] == (x >> 8) & 0xFF
+        elif k == 3 and split:
             lo_s = ((x & 0xFF) ^ 0x80) - 0x80
             assert mf.data[at + 2 * qn * c + q] == lo_s & 0xFF and mf.data[at + 2 * qn * c + qn + q] == ((x - lo_s) >> 8) & 0xFF
             assert -128 <= (x - lo_s) >> 8 <= 127
@@ -142,15 +145,17 @@ def test_twelve_bit_class():
 
 
 def test_split_form_range():
-    """the chunk kernel's form writes a 16-bit index as two SIGNED bytes, 256 hi + lo: that ends at 32639, and a stream with a larger index
-    is refused (ACMHIP_ERR_RANGE: it stays in the int16 form) instead of being written wrong"""
+    """the six-stage form writes a 16-bit index as two SIGNED bytes, 256 hi + lo: that ends at 32639.  At levels 8-12 (acm_chunk) a pair with
+    a larger index is written in the whole-range class instead (code 0: the low byte unsigned, stored minus 128) and reads back exactly;
+    at levels 13 / 14 (acm_tile2 knows no such class) the stream is refused (ACMHIP_ERR_RANGE: it stays in the int16 form)"""
     L = capi.lib()
     levels = [lv for lv in LEVELS if L.acmhip_mform_group(lv) == 64]
     assert levels
     for level in levels:
         cols, tr = 1 << level, L.acmhip_mform_tile_rows(level)
         nrows = 2 * max(tr, 2)
-        for top, ok in ((32639, True), (32640, False), (32767, False)):
+        whole = level <= 12
+        for top, ok in ((32639, True), (32640, whole), (32767, whole)):
             idx = np.zeros(nrows * cols, dtype=np.int16)
             idx[5], idx[cols + 9], idx[3 * cols - 1] = top, -32768, -129
             buf = np.zeros(L.acmhip_mform_bytes(level, nrows) + 256, dtype=np.uint8)
@@ -160,8 +165,9 @@ def test_split_form_range():
             assert rc == (0 if ok else capi.ERR_RANGE), (level, top, rc)
             if ok:
                 assert np.array_equal(capi.mform_unrows(level, buf, pairs, nrows), idx)
+                assert int(pairs[1]) & 3 == (0 if top >= 32640 else 3)          # the first pair holds `top`
         d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=nrows * cols, level=level, rows=1, nrows=nrows, row_begin=0)
-        assert capi.mform_streams(idx, [d]).streams[0].ntiles == 0           # (idx still holds 32767)
+        assert (capi.mform_streams(idx, [d]).streams[0].ntiles == 0) == (not whole)           # (idx still holds 32767)
 
 
 def test_width_classes_follow_the_blocks():
@@ -340,12 +346,10 @@ def test_fused_staging_equals_the_two_pass_staging(level, rows, blocks, cut):
 
 
 def test_fused_staging_falls_back():
-    """no form for: a level without one, H1 patches (npatches says so), an index the chunk kernel's form cannot hold,
-    a file that ends early, levels 13 / 14 - each time idx holds every row as acm_stage_file leaves it.  (Odd block heights - row pairs
+    """no form for: a level without one, H1 patches (npatches says so), a file that ends early, levels 13 / 14 - each time idx holds every row as acm_stage_file leaves it.  (Odd block heights - row pairs
     that straddle blocks - were on this list until round 6: test_fused_staging_equals_the_two_pass_staging has them now)"""
     cases = [make_stream(46500, 5, 16, 9), make_stream(46501, 4, 3, 40),
              make_stream(46502, 9, 16, 12, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6),
-             make_stream(46503, 9, 16, 8, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535),
              make_stream(46504, 9, 16, 9)[:9000], make_stream(46505, 13, 4, 6)]
     for k, f in enumerate(cases):
         s = capi.stage_file(f)
@@ -354,7 +358,10 @@ def test_fused_staging_falls_back():
         assert info.blocks == s.info.blocks and info.end_status == s.info.end_status and info.npatches == s.info.npatches, k
         n = info.blocks * info.rows * info.cols
         assert np.array_equal(idx[:n], s.idx[:n]), k
-    assert capi.stage_file(cases[2]).info.npatches > 0 and int(capi.stage_file(cases[3]).idx.max()) >= 32640
+    assert capi.stage_file(cases[2]).info.npatches > 0
+    # (an index beyond 32639 kept a level-9 stream out of the form until round 6: now its pairs are written in the whole-range class)
+    wide = make_stream(46503, 9, 16, 8, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=65535)
+    assert int(capi.stage_file(wide).idx.max()) >= 32640 and capi.stage_file_mform(wide)[5] > 0
 
 
 def test_stager_rejects_what_the_kernel_could_not_read():

@@ -52,8 +52,8 @@ def test_byteplane_matrix(dev, force_k2, level, rows, pwr_max):
     f = make_stream(22000 + level * 100 + rows + pwr_max, level, rows, nblocks, cut=5, pwr_min=min(4, pwr_max), pwr_max=pwr_max,
                     val_max=65535 if pwr_max == 15 else 255)
     st = check(dev, [f])
-    if capi.lib().acmhip_mform_group(level) == 64 and int(capi.stage_file(f).idx.max()) >= 32640:
-        assert st.mform_tiles == 0            # the chunk kernel's form ends at 32639 (two signed bytes): such a stream stays int16
+    if level >= 13 and int(capi.stage_file(f).idx.max()) >= 32640:
+        assert st.mform_tiles == 0            # two signed bytes end at 32639: at levels 13 / 14 such a stream stays int16 (levels 8-12 have a whole-range class)
     else:
         assert st.mform_tiles >= 7
     assert st.fused_streams == 1 and st.stagewise_streams == 0
@@ -99,6 +99,29 @@ def test_byteplane_twelve_bit_class(dev, force_k2, level, rows, pwr_min, pwr_max
         assert cc[1] > 0 and cc[3] == 0, cc             # (a pair may happen to fit 8 bits)
     elif pwr_min == 6 and pwr_max == 12 and rows <= 16:
         assert cc[1] > 0, cc
+    st = check(dev, [f])
+    assert st.mform_tiles >= 9
+
+
+@pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("rows,val_max", [(16, 255), (3, 65535), (1, 65535), (64, 255)])
+def test_byteplane_whole_range_class(dev, force_k2, level, rows, val_max):
+    """VERDICT r5, task 3 (iii): an index beyond 32639 (two signed bytes end there; it takes pwr 15) no longer keeps a stream of levels 8-12
+    out of the form: such PAIRS are written with the unsigned low byte (class code 0, stored minus 128) and the chunk kernel's general
+    path adds 128 x val x the coefficient row sums back, row by row.  Blocks of pwr 15 beside quiet ones (every neighbourhood of the
+    whole-range class with 8 / 12 / 16-bit pairs), block boundaries inside a chunk, row values of 8 and of 16 bits"""
+    tr = plan_rows(level)
+    nblocks = max(4, (9 * tr + rows - 1) // rows + 1)
+    f = make_stream(34000 + level * 100 + rows, level, rows, nblocks, cut=1, pwr_min=5, pwr_max=15, val_max=val_max)
+    s = capi.stage_file(f)
+    if int(s.idx.max()) < 32640:
+        f = make_stream(34500 + level * 100 + rows, level, rows, nblocks, cut=1, mix=2, single_code=16, pwr_min=15, pwr_max=15, val_max=val_max)
+        s = capi.stage_file(f)
+    assert int(s.idx.max()) >= 32640
+    d = capi.StreamDesc(idx_off=0, hdr_off=0, pcm_off=0, n_emit=s.info.blocks * rows << level, level=level, rows=rows, nrows=s.info.blocks * rows, row_begin=0)
+    mf = capi.mform_streams(s.idx, [d])
+    npairs = mf.streams[0].ntiles * tile_rows(level) // 2
+    assert npairs > 0 and ((mf.pairs[1:1 + npairs] & 3) == 0).any()
     st = check(dev, [f])
     assert st.mform_tiles >= 9
 
