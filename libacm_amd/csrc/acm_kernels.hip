@@ -1305,7 +1305,8 @@ struct FirstPass2 : FirstPass<C, G, W, ABL, true> {              /* every segmen
 	static constexpr bool SIGNED_ROWVAL = true;              /* odd tile rows carry -val when stage 0 is an N stage; rows in front of a stream weigh 0 */
 	static __device__ __forceinline__ bool fresh_lane(const int tid) { return tid < FP::TPS; }      /* lanes whose two rows in front are missing in a stream's first tile */
 	static __device__ __forceinline__ void fill_tables(Tables &, const int) { }
-	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &, const Desc &)
+	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &, const Desc &,
+						   const uint32_t = 0u)
 	{
 		FP::template compute<true>(raw.r, tile, rowval, fresh_stream ? 0 : 2, tid);
 	}
@@ -1726,7 +1727,7 @@ struct FirstPassM {
 			       (halves_mask >> PPs) & 1u, std::make_integer_sequence<int, UPP>{}), ...);
 	}
 	static __device__ __forceinline__ void run(const Raw &raw, uint32_t *tile, const int32_t *rowval, const bool fresh_stream, const int tid, const Tables &t,
-						   const Desc &d)
+						   const Desc &d, const uint32_t = 0u)
 	{
 		const int lane = tid & 63, rs = lane >> 4, n = lane & 15;
 		const int p0 = pair0(tid), g0 = grp0(tid);
@@ -1762,8 +1763,10 @@ struct FirstPassZW {
 	static constexpr int L = C::L, NT = C::NT, COLS = C::COLS, TR = C::TR, PS = C::PS;
 	static constexpr int G = 6, QN = 1 << G, SIGMA = COLS / QN, NWAVE = NT / 64;
 	static constexpr int NGW = SIGMA / 16 / NWAVE;          /* groups of sixteen classes per wavefront */
-	static constexpr int NSW = TR, NX = TR + 2, NM = QN / 16, NE = NX / 2;
-	static_assert(TR == 2 && NGW >= 1 && NGW * 16 * NWAVE == SIGMA && SIGMA >= 32, "a row pair per tile, whole groups per wavefront");
+	static constexpr int NSW = TR, NX = TR + 2, NM = QN / 16, NE = 2;      /* the pair in front and the tile's own pair */
+	/* a tile is a row pair - or ONE row (round 6: smaller tiles, more workgroups per CU out of phase with each other), which is then the
+	 * first or the second row of its pair (ACM_TILE_ODD) with one row of the stream in front (ACM_TILE_ROW1), none (ACM_TILE_FRESH) or two */
+	static_assert((TR == 2 || TR == 1) && NGW >= 1 && NGW * 16 * NWAVE == SIGMA && SIGMA >= 32, "a row or a row pair per tile, whole groups per wavefront");
 	static constexpr int VARIANT = StageKind<L, G - 1>::N ? 0 : 1;
 	static constexpr bool SIGNED_ROWVAL = false, KEEPS_HISTORY = true;
 	static constexpr uint32_t CB = 16;
@@ -1807,9 +1810,10 @@ struct FirstPassZW {
 		asm("" : "+v"(v));
 		return v;
 	}
-	/* rows k = 0, 1: the pair in front (d.e[0]); 2, 3: the tile's own (d.e[1]) */
+	/* rows k = 0, 1: the pair in front (d.e[0]); 2, 3: the tile's own (d.e[1]).  A tile of one row that is the second row of its pair
+	 * (odd): rows k = 0 .. 2 are rows 1, 2, 3 of those four */
 	template <bool KEEP>
-	static __device__ __forceinline__ void issue_rows(Raw &raw, const uint8_t *arena, const Desc &d, const int tid)
+	static __device__ __forceinline__ void issue_rows(Raw &raw, const uint8_t *arena, const Desc &d, const int tid, const uint32_t odd)
 	{
 		const uint32_t lane = (uint32_t)tid & 63u, i = lane & 15u, ks = lane >> 4;
 		const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (uint32_t)NGW;
@@ -1818,9 +1822,10 @@ struct FirstPassZW {
 		const uint8_t *base = sgpr_u64(reinterpret_cast<uint64_t>(arena) + ((uint64_t)(e0 >> 2) << 6));
 #pragma unroll
 		for (int k = KEEP ? 2 : 0; k < NX; k++) {
-			const uint32_t e = (uint32_t)opaque_s((int32_t)d.e[k >> 1]);
+			const uint32_t u = (TR & 1 ? (uint32_t)__builtin_amdgcn_readfirstlane(odd) : 0u) + (uint32_t)k;        /* (wave-uniform: says so to the compiler) */
+			const uint32_t e = (u >> 1) ? (uint32_t)opaque_s((int32_t)d.e[1]) : (uint32_t)opaque_s((int32_t)d.e[0]);
 			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
-			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((k & 1) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
+			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((u & 1u) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
 #pragma unroll
 			for (int g = 0; g < NGW; g++) {
 				const uint32_t v = row_at + (((group_at(g0 + (uint32_t)g) + c) * (uint32_t)QN) << sh);
@@ -1830,9 +1835,9 @@ struct FirstPassZW {
 		}
 	}
 	/* the first tile of a run: every row, the two in front included (a stream's first tile finds the stager's pair of zeros there) */
-	static __device__ __forceinline__ void issue_all(Raw &raw, const int16_t *idx, const Desc &d, const int tid)
+	static __device__ __forceinline__ void issue_all(Raw &raw, const int16_t *idx, const Desc &d, const int tid, const uint32_t flags)
 	{
-		issue_rows<false>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid);
+		issue_rows<false>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid, (flags & ACM_TILE_ODD) ? 1u : 0u);
 	}
 	/* every other tile (called behind run() of the tile before): that tile's own rows are this one's rows in front - unless this one
 	 * starts a stream (zeros).  (A window's lead-in record - not the successor of the tile before - finds another stream's rows there:
@@ -1848,7 +1853,7 @@ struct FirstPassZW {
 				raw.lo[g][k] = fresh ? z : raw.lo[g][k + NSW];
 				raw.hi[g][k] = fresh ? z : raw.hi[g][k + NSW];
 			}
-		issue_rows<true>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid);
+		issue_rows<true>(raw, reinterpret_cast<const uint8_t *>(idx), d, tid, (r.flags & ACM_TILE_ODD) ? 1u : 0u);
 	}
 	static __device__ __forceinline__ v4i_t mfma(const v4u_t data, const v4i_t coef, const v4i_t acc)
 	{
@@ -1857,8 +1862,9 @@ struct FirstPassZW {
 
 	/* rowval[k] = val << SHIFT of tile row k - 2 (FirstPassZ::run_t, further down, has the algebra: one accumulator chain per output row, the block
 	 * boundaries as multiply-adds of its partial sums) */
+	/* in_front: rows of the stream in front of the tile: 0, 1 (tiles of one row only), or 2 for "two or more" */
 	template <bool WORDS>
-	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const int32_t *rowval, const bool fresh, const int tid, const Tables &t)
+	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const int32_t *rowval, const uint32_t in_front, const int tid, const Tables &t)
 	{
 		const v4i_t zero = { 0, 0, 0, 0 };
 		const uint32_t lane = (uint32_t)tid & 63u, h = lane >> 4, qd = lane & 15u;
@@ -1886,7 +1892,7 @@ struct FirstPassZW {
 				const uint32_t c0 = group_at(g0 + (uint32_t)g) + class_of(4u * h);     /* the lane's four outputs: classes c0 .. c0 + 3 */
 #pragma unroll
 				for (int s = 0; s < NSW; s++) {
-					const uint32_t var = fresh ? (uint32_t)s : 2u;          /* rows of the stream in front of this one: 0, 1, two or more */
+					const uint32_t var = in_front + (uint32_t)s < 2u ? in_front + (uint32_t)s : 2u;        /* rows of the stream in front of this one: 0, 1, two or more */
 					const int32_t b = c0 == 0 ? (&t.bias[0][0])[var * QN + qd + 16u * (uint32_t)mt] : 0;
 					const v4i_t l1 = mfma(raw.lo[g][s], cf2, zero);
 					const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
@@ -1948,8 +1954,11 @@ struct FirstPassZW {
 			cf += 64;
 		}
 	}
-	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const int32_t *rowval, const bool fresh, const int tid, const Tables &t, const Desc &d)
+	static __device__ __forceinline__ void run(Raw &raw, uint32_t *const tile, const int32_t *rowval, const bool, const int tid, const Tables &t, const Desc &d,
+						   const uint32_t flags)
 	{
+		const uint32_t in_front = (flags & ACM_TILE_FRESH) ? 0u : (flags & ACM_TILE_ROW1) ? 1u : 2u;
+		const uint32_t odd = (TR & 1) && ((uint32_t)__builtin_amdgcn_readfirstlane(flags) & ACM_TILE_ODD) ? 1u : 0u;
 		uint32_t any_word = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++)
@@ -1959,14 +1968,15 @@ struct FirstPassZW {
 			 * their registers for the next tile stay what they are) */
 #pragma unroll
 			for (int k = 0; k < NX; k++) {
-				const uint32_t mask = ((uint32_t)opaque_s((int32_t)d.e[k >> 1]) & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+				const uint32_t ek = ((odd + (uint32_t)k) >> 1) ? (uint32_t)opaque_s((int32_t)d.e[1]) : (uint32_t)opaque_s((int32_t)d.e[0]);
+				const uint32_t mask = (ek & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
 #pragma unroll
 				for (int g = 0; g < NGW; g++)
 					raw.hi[g][k] &= mask;
 			}
-			run_t<true>(raw, tile, rowval, fresh, tid, t);
+			run_t<true>(raw, tile, rowval, in_front, tid, t);
 		} else {
-			run_t<false>(raw, tile, rowval, fresh, tid, t);
+			run_t<false>(raw, tile, rowval, in_front, tid, t);
 		}
 	}
 };
@@ -2044,8 +2054,10 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	 * operations; what is loaded is only looked at in finish_val, a whole tile later */
 	const uint32_t lr_fetch = (uint32_t)(tid < TR + 2 ? tid : TR + 1);
 	auto fetch_val = [&](const AcmTile2 &r) -> uint32_t {
-		const bool fr = (r.flags & ACM_TILE_FRESH) != 0;                 /* no rows in front of the stream: they weigh 0 */
-		const uint32_t q = r.rowpos + (fr ? (lr_fetch < 2 ? 0u : lr_fetch - 2) : lr_fetch);     /* rows counted from the record's reference row */
+		/* rows in front of the stream do not exist (they weigh 0): the record counts from the stream's row 0 then (a tile of one row that is
+		 * row 1 of its stream, ACM_TILE_ROW1, has one such row) */
+		const uint32_t missing = (r.flags & ACM_TILE_FRESH) ? 2u : (r.flags & ACM_TILE_ROW1) ? 1u : 0u;
+		const uint32_t q = r.rowpos + (lr_fetch < missing ? 0u : lr_fetch - missing);           /* rows counted from the record's reference row */
 		const uint32_t b = r.magic ? __umulhi(q, r.magic) : q;     /* q / acm_rows (magic = ceil(2^32 / rows), 0 for rows == 1) */
 		const uint32_t *p = &hdr[r.hdr_blk + b].val;
 		uint32_t v;
@@ -2077,7 +2089,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 	typename FP::Raw raw;
 	uint32_t hv = fetch_val(cur);
 	if constexpr (FP::KEEPS_HISTORY)
-		FP::issue_all(raw, idx, dcur, tid);     /* (the rows in front of a tile are the registers of the tile before: not at a run's start) */
+		FP::issue_all(raw, idx, dcur, tid, cur.flags);  /* (the rows in front of a tile are the registers of the tile before: not at a run's start) */
 	else
 		load_tile(raw, cur, dcur);
 	k2_wait<0>();                                   /* first tile of the run: nothing to hide the latency behind yet */
@@ -2104,7 +2116,7 @@ acm_tile2(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 		ACM_STAMP(0);
 		/* history in front of the stream is zeros: no "+1" there (decode.c:561-564 runs on existing rows only) */
 		phase_prio<PRIO, PRIO_FIRST_PASS>();
-		FP::run(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) != 0, tid, fp_tables, dcur);
+		FP::run(raw, tile, rowval[buf], (cur.flags & ACM_TILE_FRESH) != 0, tid, fp_tables, dcur, cur.flags);
 		phase_prio<PRIO, PRIO_IDLE>();
 		ACM_STAMP(1);
 
