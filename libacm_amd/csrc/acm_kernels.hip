@@ -2303,7 +2303,9 @@ struct FirstPassZ {
 #ifndef ACM_K3_DPP_HISTORY
 #define ACM_K3_DPP_HISTORY 1
 #endif
-	static constexpr bool HISTORY_BY_DPP = ACM_K3_DPP_HISTORY && RR == 2 && NSW == 2 && SIGMA == 8;
+	/* (round 6: the same with four walkers of two rows each, level 8 - walker w's rows in front are walker w - 1's own, SIGMA lanes down
+	 * the row of sixteen; walker 0's are the last walker's of the chunk before, 16 - SIGMA lanes up) */
+	static constexpr bool HISTORY_BY_DPP = ACM_K3_DPP_HISTORY && RR >= 2 && NSW == 2 && RR * SIGMA == 16 && SIGMA >= 4;
 	static constexpr bool KEEPS_ROWS = HISTORY_IN_REGISTERS || HISTORY_BY_DPP;
 	template <int CTRL, int BANKS>
 	static __device__ __forceinline__ v4u_t dpp4(const v4u_t old, const v4u_t src)
@@ -2314,22 +2316,24 @@ struct FirstPassZ {
 			r[v] = (uint32_t)__builtin_amdgcn_update_dpp((int)old[v], (int)src[v], CTRL, 0xF, BANKS, false);
 		return r;
 	}
-	/* behind run(): the lanes of walker 0 (instances 0-7) take walker 1's own rows - the chunk's last two - as the rows in front of the next chunk */
+	/* DPP controls: row_shl:N = 0x100 + N, row_shr:N = 0x110 + N; a bank is four lanes of a row of sixteen */
+	static constexpr int DPP_W0_BANKS = (1 << (SIGMA / 4)) - 1;            /* the lanes of walker 0: instances 0 .. SIGMA - 1 */
+	/* behind run(): the lanes of walker 0 take the LAST walker's own rows - the chunk's last two - as the rows in front of the next chunk */
 	static __device__ __forceinline__ void hand_history_on(Raw &raw)
 	{
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
-			raw.lo[0][k] = dpp4<0x108, 0x3>(raw.lo[0][k], raw.lo[0][k + NSW]);      /* row_shl:8 into lanes 0-7 of every row of sixteen */
-			raw.hi[0][k] = dpp4<0x108, 0x3>(raw.hi[0][k], raw.hi[0][k + NSW]);
+			raw.lo[0][k] = dpp4<0x100 + (16 - SIGMA), DPP_W0_BANKS>(raw.lo[0][k], raw.lo[0][k + NSW]);    /* row_shl:(16 - SIGMA) into walker 0's lanes of every row of sixteen */
+			raw.hi[0][k] = dpp4<0x100 + (16 - SIGMA), DPP_W0_BANKS>(raw.hi[0][k], raw.hi[0][k + NSW]);
 		}
 	}
-	/* in front of run(): the lanes of walker 1 take walker 0's own rows of this chunk */
+	/* in front of run(): the lanes of walkers 1 .. take the own rows of the walker below them in this chunk */
 	static __device__ __forceinline__ void take_history_from_partner(Raw &raw)
 	{
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
-			raw.lo[0][k] = dpp4<0x118, 0xC>(raw.lo[0][k], raw.lo[0][k + NSW]);      /* row_shr:8 into lanes 8-15 */
-			raw.hi[0][k] = dpp4<0x118, 0xC>(raw.hi[0][k], raw.hi[0][k + NSW]);
+			raw.lo[0][k] = dpp4<0x110 + SIGMA, 0xF & ~DPP_W0_BANKS>(raw.lo[0][k], raw.lo[0][k + NSW]);     /* row_shr:SIGMA into the other walkers' lanes */
+			raw.hi[0][k] = dpp4<0x110 + SIGMA, 0xF & ~DPP_W0_BANKS>(raw.hi[0][k], raw.hi[0][k + NSW]);
 		}
 	}
 	/*
@@ -2425,11 +2429,21 @@ struct FirstPassZ {
 		for (int k = K0; k < NX; k++)
 #pragma unroll
 			for (int g = 0; g < NG; g++) {
-				asm volatile("global_load_dwordx4 %0, %1, %2" ACM_K3_LD_MOD : "=v"(raw.lo[g][k]) : "v"(va[k][g]), "s"(sb[k][g]) : "memory");
-				asm volatile("s_cmp_eq_u32 %3, 1\n\ts_cbranch_scc1 .Lacm_z8_%=\n\t"
-					     "global_load_dwordx4 %0, %1, %2 offset:64" ACM_K3_LD_MOD "\n"
-					     ".Lacm_z8_%=:"
-					     : "+v"(raw.hi[g][k]) : "v"(vh[k][g]), "s"(sb[k][g]), "s"(smode) : "memory", "scc");
+				/* (non-temporal only where every staged byte is read ONCE: where the rows in front of a walk are re-read by the next
+				 * walker - level 8 - the second reader wants them in the cache: 0.70 -> 0.60 with nt there) */
+				if constexpr (KEEPS_ROWS) {
+					asm volatile("global_load_dwordx4 %0, %1, %2" ACM_K3_LD_MOD : "=v"(raw.lo[g][k]) : "v"(va[k][g]), "s"(sb[k][g]) : "memory");
+					asm volatile("s_cmp_eq_u32 %3, 1\n\ts_cbranch_scc1 .Lacm_z8_%=\n\t"
+						     "global_load_dwordx4 %0, %1, %2 offset:64" ACM_K3_LD_MOD "\n"
+						     ".Lacm_z8_%=:"
+						     : "+v"(raw.hi[g][k]) : "v"(vh[k][g]), "s"(sb[k][g]), "s"(smode) : "memory", "scc");
+				} else {
+					asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw.lo[g][k]) : "v"(va[k][g]), "s"(sb[k][g]) : "memory");
+					asm volatile("s_cmp_eq_u32 %3, 1\n\ts_cbranch_scc1 .Lacm_z8_%=\n\t"
+						     "global_load_dwordx4 %0, %1, %2 offset:64\n"
+						     ".Lacm_z8_%=:"
+						     : "+v"(raw.hi[g][k]) : "v"(vh[k][g]), "s"(sb[k][g]), "s"(smode) : "memory", "scc");
+				}
 			}
 	}
 	/*
@@ -2516,13 +2530,14 @@ struct FirstPassZ {
 	 * FAST (mode_of): one val, below 2^16 as scaled, over every row in reach - the scalar sval; hvs is not looked at.  No differences,
 	 * no branches per set, the multipliers are scalar operands: per output ONE instruction per plane. */
 	/* NIB (FAST only): the high plane's rows are 12-bit rows in N form (expand_nib): scaled by val << 4, a signed multiply */
-	/* wordu (general path): some row in reach is stored with its low bytes minus 128 (ACMHIP_BP_WORDU: idx = 256 hi + (lo + 128)): such a row's
+	/* nform (general path): every row in reach that has a high plane is a 12-bit row, in N form (hi << 4): the plane joins shifted by 4, not 8.
+	 * wordu (general path): some row in reach is stored with its low bytes minus 128 (ACMHIP_BP_WORDU: idx = 256 hi + (lo + 128)): such a row's
 	 * share of an output is short of 128 x val x the row sum of its matrix.  Which rows: from the pair-table entries *dd, for the walker
 	 * whose OUTPUTS the lane receives */
 	template <bool WORDS, bool FAST, bool NIB = false>
 	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const Tables &t, const int lane, const uint32_t hvs,
 						     const uint32_t in_front, const uint32_t sval, const bool wordu = false, const Desc *dd = nullptr,
-						     const uint32_t odd = 0u)
+						     const uint32_t odd = 0u, const bool nform = false)
 	{
 		static_assert(!NIB || (WORDS && FAST), "rows in N form are a fast-path matter; the general path takes them to bytes first");
 		const v4i_t zero = { 0, 0, 0, 0 };
@@ -2701,7 +2716,7 @@ struct FirstPassZ {
 					 * 2^24 * 256 * val = 0 (mod 2^32).  (val << 8 through an opaque copy: or the optimiser folds both planes into one
 					 * 32-bit multiply) */
 					{
-						if (small[s] && !step2[s] && !step1[s]) {
+						if (small[s] && !step2[s] && !step1[s] && !nform) {
 							uint32_t v8[NH];
 #pragma unroll
 							for (int hf = 0; hf < NH; hf++)
@@ -2736,9 +2751,10 @@ struct FirstPassZ {
 						for (int v = 0; v < 4; v++)
 							yh[v] += __mul24(h1[v], w1[v / NVH]);
 					}
+					const uint32_t hs = nform ? 4u : 8u;                    /* (a scalar: one v_lshl_add_u32 either way) */
 #pragma unroll
 					for (int v = 0; v < 4; v++)
-						y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << 8) + (uint32_t)y[v]);
+						y[v] = (int32_t)(((uint32_t)opaque_v(yh[v]) << hs) + (uint32_t)y[v]);
 					}
 				joined:;
 				}
@@ -2821,6 +2837,9 @@ struct FirstPassZ {
 		}
 		if constexpr (HISTORY_BY_DPP)
 			take_history_from_partner(raw);                 /* (a run's first chunk has loaded these rows itself: the same bytes again) */
+		/* 12-bit rows and no 16-bit row in reach (a block boundary between blocks of pwr 8-10, 8-bit pairs beside 12-bit ones): the high plane
+		 * runs on the N form as it stands and joins shifted by 4; only where 12-bit rows meet 16-bit ones are they taken to bytes */
+		const bool nform = any_nib && !any_word;
 		if (any_word | any_nib) {
 			/* in place: the rows that stay in their registers for the next chunk (HISTORY_IN_REGISTERS) stay what they are - 8-bit rows have
 			 * no high bytes (zeros); 12-bit rows go from N form to bytes for ONE high plane over rows of any width, and the rows the next
@@ -2832,14 +2851,14 @@ struct FirstPassZ {
 #pragma unroll
 				for (int g = 0; g < NG; g++)
 					raw.hi[g][k] &= mask;
-				if (any_nib && cls == ACMHIP_BP_NIB12) {
+				if (any_nib && !nform && cls == ACMHIP_BP_NIB12) {
 #pragma unroll
 					for (int g = 0; g < NG; g++)
 						raw.hi[g][k] = sra4(raw.hi[g][k]);
 				}
 			}
-			run_t<true, false>(raw, tile, t, lane, hvs, in_front, 0u, any_wordu != 0, &d, odd);
-			if (any_nib && KEEPS_ROWS) {
+			run_t<true, false>(raw, tile, t, lane, hvs, in_front, 0u, any_wordu != 0, &d, odd, nform);
+			if (any_nib && !nform && KEEPS_ROWS) {
 #pragma unroll
 				for (int k = NSW; k < NX; k++)
 					if ((entry_of(d, (TR & 1 ? odd : 0u) + rr * NSW + k) & 3u) == ACMHIP_BP_NIB12) {
@@ -3735,6 +3754,7 @@ extern "C" int acmk_tile2m_lead_in(uint32_t level)
 	if (level < ACM_K2M_MIN_LEVEL || level > ACM_K2M_MAX_LEVEL || tile2m_entry(level).g0 != 6)
 		return 1;
 	switch (level) {
+	case 8: return FirstPassZ<8>::KEEPS_ROWS ? 1 + (2 + FirstPassZ<8>::NSW - 1) / FirstPassZ<8>::NSW : 1;
 	case 9: return FirstPassZ<9>::KEEPS_ROWS ? 1 + (2 + FirstPassZ<9>::NSW - 1) / FirstPassZ<9>::NSW : 1;
 	case 10: return FirstPassZ<10>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<10>::NSW - 1) / FirstPassZ<10>::NSW : 1;
 	case 11: return FirstPassZ<11>::HISTORY_IN_REGISTERS ? 1 + (2 + FirstPassZ<11>::NSW - 1) / FirstPassZ<11>::NSW : 1;
