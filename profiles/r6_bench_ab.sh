@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/r6f
 ARGS="$*"
-for rep in 1 2 3; do
+for rep in ${REPS:-1 2 3}; do
   for t in r5 r6; do
     if [ $t = r5 ]; then d=.r5tree; else d=.; fi
     ( cd $d && timeout 600 python3 bench.py --no-extra --no-cpu --steps 100 --warmup 20 $ARGS 2>/dev/null | tail -1 ) > gpurun_out/r6f/${t}_$rep.json
