@@ -950,7 +950,7 @@ def main():
                 best = copy_ceiling()
                 if best:
                     out["roofline"]["d2d_copy_gbs"] = best[0]
-                    out["roofline"]["d2d_copy_kernel"] = best[1] + " (profiles/ubench/copy_bw.hip, best of five 16-B-per-lane copy kernels)"
+                    out["roofline"]["d2d_copy_kernel"] = best[1] + " (profiles/ubench/copy_bw.hip, best of eight 16-B-per-lane copy kernels)"
                     out["roofline"]["frac_of_d2d_copy"] = round(achieved / best[0], 4)
                     # ... and the honest one: measured bytes against the copy kernel's measured bytes
                     out["roofline"]["frac_of_d2d_copy_on_measured_traffic"] = (

@@ -121,8 +121,21 @@ extern "C" uint64_t acmhip_host_synth_limit(void)
 	return g_host_limit.load();
 }
 
+static int host_synth(const acmhip_stream_desc *s, const int16_t *idx, const acmhip_blkhdr *hdr,
+		      const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm);
+
 extern "C" int acmhip_host_synth(const acmhip_stream_desc *s, const int16_t *idx, const acmhip_blkhdr *hdr,
 				 const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm)
+{
+	try {
+		return host_synth(s, idx, hdr, patches, npatches, fmt, pcm);
+	} catch (...) {
+		return ACMHIP_ERR_NOMEM;        /* (tile buffers, the patch list, threads: nothing else in there throws) */
+	}
+}
+
+static int host_synth(const acmhip_stream_desc *s, const int16_t *idx, const acmhip_blkhdr *hdr,
+		      const acmhip_patch *patches, size_t npatches, unsigned fmt, int16_t *pcm)
 {
 	if (!s || (!idx && s->nrows) || !hdr || (!pcm && s->n_emit) || (!patches && npatches) || fmt > ACMHIP_FMT_U16BE ||
 	    s->level > 15 || s->rows == 0 || s->rows > 4095)
@@ -149,8 +162,15 @@ extern "C" int acmhip_host_synth(const acmhip_stream_desc *s, const int16_t *idx
 	const uint64_t row_end = s->row_begin + rows_out;
 	const uint64_t ntiles = (rows_out + T - 1) / T;
 	std::atomic<uint64_t> next{ 0 };
+	std::atomic<bool> failed{ false };
 	auto work = [&]() {
-		std::vector<uint32_t> buf(cols + (T + 2) * cols);
+		std::vector<uint32_t> buf;
+		try {
+			buf.resize(cols + (T + 2) * cols);
+		} catch (...) {
+			failed.store(true);             /* (the other workers take the tiles; if none could, the caller hears of it) */
+			return;
+		}
 		uint32_t *const base = buf.data() + cols;
 		for (uint64_t t = next.fetch_add(1); t < ntiles; t = next.fetch_add(1)) {
 			const uint64_t r0 = s->row_begin + t * T;
@@ -192,11 +212,18 @@ extern "C" int acmhip_host_synth(const acmhip_stream_desc *s, const int16_t *idx
 		work();
 	} else {
 		std::vector<std::thread> pool;
-		for (unsigned k = 1; k < nthreads; k++)
-			pool.emplace_back(work);
+		pool.reserve(nthreads);
+		try {
+			for (unsigned k = 1; k < nthreads; k++)
+				pool.emplace_back(work);
+		} catch (...) {
+			/* (no more threads to be had: the ones that started and this one do the job) */
+		}
 		work();
 		for (std::thread &th : pool)
 			th.join();
 	}
+	if (next.load() < ntiles || (failed.load() && next.load() == 0))
+		return ACMHIP_ERR_NOMEM;
 	return ACMHIP_OK;
 }

@@ -37,6 +37,30 @@ __global__ void __launch_bounds__(256) copy_runs(const uint4 *__restrict__ src_,
     for (int k = 0; k < 4; k++) { if (NT_STORE) __builtin_nontemporal_store(v[k], &d[i + 256 * k]); else d[i + 256 * k] = v[k]; }
   }
 }
+/* (round 6: what /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for is "a float4 copy" - the plain shapes, for the record) */
+__global__ void __launch_bounds__(256) copy_oneshot(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  const size_t i = blockIdx.x * 256ull + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) copy_oneshot4(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  const size_t i = blockIdx.x * 1024ull + threadIdx.x;
+  if (i + 768 < n) {
+    const uint4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+  }
+}
+/* one workgroup of 1024 threads per CU, sixteen 16-byte loads in flight per thread */
+__global__ void __launch_bounds__(1024) copy_deep(const uint4 *__restrict__ src_, uint4 *__restrict__ dst_, size_t n) {
+  const v4u *s = reinterpret_cast<const v4u *>(src_); v4u *d = reinterpret_cast<v4u *>(dst_);
+  const size_t stride = (size_t)gridDim.x * 1024;
+  for (size_t i = blockIdx.x * 1024ull + threadIdx.x; i + 15 * stride < n; i += 16 * stride) {
+    v4u v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(&s[i + k * stride]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) __builtin_nontemporal_store(v[k], &d[i + k * stride]);
+  }
+}
 #ifdef COPY_BW_LIB
 /* bench.py's "practical HBM ceiling of this box": the best of the copy kernels above on two fresh buffers of `bytes` each
  * (read + written bytes / time); built into profiles/ubench/libcopybw.so by libacm_amd/_build.py, called through ctypes */
@@ -52,6 +76,7 @@ extern "C" double acm_copy_ceiling_gbs(size_t bytes, char *best_name, size_t bes
     (void)hipEventRecord(e0); for (int r = 0; r < 5; r++) launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double gbs = 5 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    if (getenv("ACM_COPY_BW_VERBOSE")) fprintf(stderr, "copy_bw: %-66s %7.1f GB/s\n", name, gbs);
     if (gbs > best) { best = gbs; if (best_name && best_cap) snprintf(best_name, best_cap, "%s", name); }
   };
   for (int rep = 0; rep < 2; rep++) {
@@ -60,6 +85,9 @@ extern "C" double acm_copy_ceiling_gbs(size_t bytes, char *best_name, size_t bes
     timeit("contiguous runs, 1024 WGs, nt stores", [&]() { hipLaunchKernelGGL((copy_runs<0, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); });
     timeit("contiguous runs, 1024 WGs, nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(1024), dim3(256), 0, 0, a, b, n); });
     timeit("contiguous runs, 2048 WGs, nt both", [&]() { hipLaunchKernelGGL((copy_runs<1, 1>), dim3(2048), dim3(256), 0, 0, a, b, n); });
+    timeit("one 16-byte element per thread, one-shot grid", [&]() { hipLaunchKernelGGL(copy_oneshot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n); });
+    timeit("four elements per thread, one-shot grid", [&]() { hipLaunchKernelGGL(copy_oneshot4, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, a, b, n); });
+    timeit("one 1024-thread workgroup per CU, sixteen loads in flight, nt", [&]() { hipLaunchKernelGGL(copy_deep, dim3(256), dim3(1024), 0, 0, a, b, n); });
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
   return best;
