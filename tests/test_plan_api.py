@@ -126,3 +126,25 @@ def test_launch_is_graph_capturable(dev):
     assert np.array_equal(t_pcm.cpu().numpy().view(np.uint16)[:want.size], want)
     plan.destroy()
     d2.close()
+
+
+def test_kernel_selection_is_by_flag_not_by_environment(dev, monkeypatch):
+    """what ACM_K2 / ACM_K1_CARRY used to switch through the environment are plan flags now (include/acm_hip.h): ACMHIP_PLAN_LEAN_ALWAYS
+    puts a handful of whole tiles on the lean kernels (and so on the byte-plane form), ACMHIP_PLAN_NO_LEAN keeps everything off them,
+    _FORCE_HALO / _FORCE_CARRY pick acm_fused_tile's flavour - same PCM every way - and the environment variables of earlier rounds change
+    nothing in the shipped library"""
+    files = [make_stream(61000 + i, lv, 16, 3 * (8192 >> lv) // 16 + 2, cut=i) for i, lv in enumerate((7, 8, 9, 10, 11))]
+    staged = [capi.stage_file(f) for f in files]
+    want = [oracle_pcm(f)[0] for f in files]
+    seen = {}
+    for name, flags in (("auto", capi.PLAN_AUTO), ("lean", capi.PLAN_LEAN_ALWAYS), ("no_lean", capi.PLAN_NO_LEAN),
+                        ("halo", capi.PLAN_FORCE_HALO), ("carry", capi.PLAN_FORCE_CARRY), ("stagewise", capi.PLAN_STAGEWISE)):
+        got, st = capi.synth(dev, staged, flags=flags, return_stats=True, mform=True)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), name
+        seen[name] = st.mform_tiles
+    assert seen["lean"] > 0 and seen["no_lean"] == 0 and seen["stagewise"] == 0
+    assert capi.lib().acmk_tuning_build() == 0
+    for var, val in (("ACM_K2", "0"), ("ACM_K3", "0"), ("ACM_K1_CARRY", "1"), ("ACM_PREFIX", "0")):
+        monkeypatch.setenv(var, val)
+    got, st = capi.synth(dev, staged, flags=capi.PLAN_LEAN_ALWAYS, return_stats=True, mform=True)
+    assert st.mform_tiles == seen["lean"] and all(np.array_equal(g, w) for g, w in zip(got, want))
