@@ -3051,7 +3051,11 @@ acm_chunk(const AcmTile2 *__restrict__ tiles, const uint32_t ntiles, const int16
 				const int vec = lane + k * 64;
 				const uint32_t *q = tile + lds_at<C::PS>((vec / PER_OWNER) * NJ_LAST) + (vec % PER_OWNER) * park_piece<NJ_LAST>();
 				const v4u o = { q[0], q[1], q[2], q[3] };
+#ifdef ACM_K3_ST_MOD            /* (A/B builds: another cache policy for the PCM stores - "", " sc1", " sc0 sc1", " sc1 nt" ...; the shipped one is nt) */
+				asm volatile("global_store_dwordx4 %0, %1, %2" ACM_K3_ST_MOD :: "v"((uint32_t)(vec * 16)), "v"(o), "s"(sgpr_u64(reinterpret_cast<uint64_t>(out))) : "memory");
+#else
 				__builtin_nontemporal_store(o, &out[vec]);
+#endif
 			}
 		}
 		ACM_STAMP(5);
