@@ -363,8 +363,9 @@ int  acm_stage_file(const uint8_t *data, size_t len, int force_chans,
  * instead of by a second pass over idx: rows [0, *mf_rows) - whole tiles of the lean kernel - go to mf_out (pairs / mf_base /
  * *mf_bytes as acmhip_mform_rows writes them; room for acmhip_mform_bytes() / acmhip_mform_pairs() of every row the header
  * promises) and idx receives only the rows from *mf_rows - 2 on, which is all the int16 kernels read of such a stream.
- * *mf_rows = 0: the stream has no form (level, odd acm_rows, H1 patches - then info->npatches says so and the caller stages again
- * with room for them -, an index the form cannot hold, a file that ends early) and idx holds every row.
+ * *mf_rows = 0: the stream has no form (its level, H1 patches - then info->npatches says so and the caller stages again
+ * with room for them -, at levels 13 / 14 an index the form cannot hold, a file that ends early) and idx holds every row.  Any block
+ * height: a row pair may lie across two blocks.
  */
 int  acm_stage_file_mform(const uint8_t *data, size_t len, int force_chans, int16_t *idx, acmhip_blkhdr *hdr, size_t max_blocks,
 			  acm_stage_info *info, uint8_t *mf_out, uint64_t mf_base, acmhip_mform_pair *pairs, uint64_t *mf_rows,

@@ -890,9 +890,10 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			if (dev_mform && s.mf_rows_cap) {
 				/* rows [0, mf_rows) - the whole tiles of the lean kernel, as the plan will cut them - are staged in the byte-plane form.
 				 * With block ranges every range must end on a tile boundary (it does when a block is whole tiles), or its ragged end
-				 * would need int16 rows nobody writes */
+				 * would need int16 rows nobody writes - which also keeps the row pairs of an odd block height, every other one of which
+				 * lies across two blocks, inside one range: such streams are staged with one range only */
 				const int T2 = acmk_tile2_rows(s.info.level), TM = acmk_tile2m_rows(s.info.level);
-				if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && !(s.info.rows & 1) && s.info.level <= ACM_K1_MAX_LEVEL &&
+				if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && s.info.level <= ACM_K1_MAX_LEVEL &&
 				    (R == 1 || s.info.rows % (uint32_t)T2 == 0)) {
 					const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
 					const uint64_t words = deliverable_words(s.info.total_values, bl, s.info.channels, s.need_blocks);

@@ -188,7 +188,8 @@ int acmk_launch_parse_range(const AcmParseJob *d_jobs, uint32_t njobs, const uin
 			    acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,
 			    uint32_t stripes_up, void *stream);
 /* the same with byte-plane staging for the jobs that ask for it (mf_rows != 0): d_mf = the byte-plane arena, d_pairs = its pair table,
- * d_blkoff = one word per block (indexed like d_hdr): where the block starts in its stream's region, in 64-byte units.  Streams are walked
+ * d_blkoff = one word per block (indexed like d_hdr): where the row pair that holds the block's first row starts in its stream's region, in
+ * 64-byte units (blocks of an odd height: every other one begins inside a pair).  Streams are walked
  * by the wave-per-stream kernel only (njobs <= ACM_PARSE_RANGE_MAX_STREAMS) */
 int acmk_launch_parse_range_mf(const AcmParseJob *d_jobs, uint32_t njobs, const uint8_t *d_files, uint32_t *d_colpos, int16_t *d_idx,
 			       acmhip_blkhdr *d_hdr, AcmParseResult *d_res, uint32_t *d_flags, uint64_t max_columns, uint32_t r, uint32_t R,

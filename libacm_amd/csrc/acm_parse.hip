@@ -110,6 +110,32 @@ __device__ __forceinline__ uint32_t code_class(uint32_t code)
 	return (uint32_t)(((code & 16) ? hi : lo) >> (3 * (code & 15))) & 7u;
 }
 
+/* ---- byte-plane staging: the width class of a block from its pwr alone ----
+ * An index of a block lies in [-2^pwr, 2^pwr) (decode.c:592-600; anything else is hazard H1 and goes back to the host), so the class of
+ * include/acm_hip.h that holds the block is known before a single column is decoded - which is what lets the walk place every block:
+ * 8 bits up to pwr 7, then at the chunk kernel's levels 12 bits up to pwr 10 (the class ends at 1919), two signed bytes up to pwr 14 and the
+ * whole-range class for pwr 15 (the two-byte class ends at 32 639); at levels 13 / 14 two signed bytes from pwr 8 on, and a stream with
+ * an index beyond 32 639 is flagged for the host.  (The host stager, acm_pack.cpp, looks at the indices themselves and may pick narrower.) */
+__device__ __forceinline__ uint32_t bp_class(uint32_t pwr, uint32_t level)
+{
+	if (pwr < 8u)
+		return ACMHIP_BP_BYTE;
+	if (level > 12u)
+		return ACMHIP_BP_WORD;
+	return pwr <= 10u ? ACMHIP_BP_NIB12 : pwr == 15u ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
+}
+/* bytes per index, times two (WORDU 4, NIB12 3, BYTE 2, WORD 4) */
+__device__ __forceinline__ uint32_t bp_half_bytes(uint32_t cls)
+{
+	return (0x4234u >> (4u * cls)) & 15u;
+}
+/* the class that holds both (a row pair that straddles two blocks takes the wider of theirs): BYTE < NIB12 < WORD < WORDU */
+__device__ __forceinline__ uint32_t bp_wider(uint32_t a, uint32_t b)
+{
+	const uint32_t ra = (0x2013u >> (4u * a)) & 15u, rb = (0x2013u >> (4u * b)) & 15u;
+	return ra >= rb ? a : b;
+}
+
 /* k-fillers: the first three bits of a symbol fix its length and whether it stands for two rows ("0" of the
  * x3/x4/x5 family, decode.c:217-398).  One nibble per 3-bit prefix: len | two << 3. */
 constexpr uint32_t k_prefix_table(int code)
@@ -397,8 +423,12 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges), b_hi = (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges);
 	uint32_t bit = job.data_start * 8u;
 	/* byte-plane staging (job.mf_rows != 0): where block b starts in the stream's region - behind the pair of zeros, every block at
-	 * one or two bytes per index by its pwr (an index lies in [-2^pwr, 2^pwr): decode.c:592-600) - is a running sum only this walk knows */
+	 * 1, 1.5 or 2 bytes per index by its pwr (bp_class) - is a running sum only this walk knows */
 	uint32_t mf_at = (2u * cols) >> 6;
+	/* a block height that is odd: every other block starts with the second row of a pair that began in the block before it.  Such a pair
+	 * takes the wider class of the two blocks, so its size is known only here, at the second one; str_at is where it lies, str_cls the
+	 * class the first block asked for.  (Block ranges never cut such a pair: acm_batch.cpp stages odd heights with one range only.) */
+	uint32_t str_at = 0, str_cls = ACMHIP_BP_BYTE;
 	/* Byte-plane staging and block ranges: the synthesis of a range is queued behind its walk without the host looking at the result, on
 	 * a plan cut from what the headers promised.  A stream whose walk stops early leaves the pair-table entries of the blocks it did not
 	 * reach unwritten - and an entry is a PLACE: the chunk kernel would load from wherever the garbage points.  Those entries are
@@ -465,12 +495,26 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 			if (lane < n)
 				cp[c0 + lane] = cpv;
 		}
-		if (lane == 0) {
-			hdr[job.hdr_off + b] = acmhip_blkhdr{ h20 >> 4, h20 & 15u };
-			if (blkoff)
-				blkoff[job.hdr_off + b] = mf_at;
+		{
+			/* blkoff[b]: where the row pair that holds the block's first row lies */
+			const uint32_t cls = bp_class(h20 & 15u, job.level);
+			uint32_t inner = rows, first_at = mf_at;
+			if ((b * rows) & 1u) {
+				first_at = str_at;
+				mf_at = str_at + ((cols * bp_half_bytes(bp_wider(str_cls, cls))) >> 6);
+				inner = rows - 1u;
+			}
+			if (lane == 0) {
+				hdr[job.hdr_off + b] = acmhip_blkhdr{ h20 >> 4, h20 & 15u };
+				if (blkoff)
+					blkoff[job.hdr_off + b] = first_at;
+			}
+			mf_at += (inner >> 1) * ((cols * bp_half_bytes(cls)) >> 6);
+			if (inner & 1u) {
+				str_at = mf_at;
+				str_cls = cls;
+			}
 		}
-		mf_at += ((rows * cols) >> 6) << ((h20 & 15u) >= 8u ? 1 : 0);
 		cp += cols;
 		done++;
 	}
@@ -587,8 +631,8 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 	const uint64_t bl = (uint64_t)rows << level;
 	const uint32_t *base = reinterpret_cast<const uint32_t *>(files + job.file_off);
 	uint32_t bad = 0;
-	/* byte-plane staging (the chunk kernel's form, include/acm_hip.h: 64 columns of a residue class side by side, 8 or 16 bits per
-	 * index, a 16-bit index as two signed bytes): rows [0, mf_rows) go there, only the rows from mf_rows - 2 on to the int16 arena.
+	/* byte-plane staging (the chunk kernel's form, include/acm_hip.h: 64 columns of a residue class side by side, 8, 12 or 16 bits per
+	 * index by the block's pwr - bp_class): rows [0, mf_rows) go there, only the rows from mf_rows - 2 on to the int16 arena.
 	 * A wavefront takes 64 columns of ONE class - thread t of it column class + SIGMA t - so that its stores of a row are 64
 	 * consecutive bytes */
 	const uint32_t mf_rows = mf && mf_pairs && blkoff ? job.mf_rows : 0u;
@@ -602,17 +646,37 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 		const int lim = 1 << pwr;
 		int16_t *out = idx + job.idx_off + (uint64_t)b * bl + c;
 		const uint32_t row0 = b * rows;                 /* stream row of the block's first row (blocks * rows < 2^32: acmk_parse_supported) */
-		const uint32_t wide = pwr >= 8u ? 1u : 0u;      /* two bytes per index */
+		/* The block's rows in the byte-plane form.  Local pair j = the j-th row pair that has a row in this block; all of them have the
+		 * block's own class (bp_class) except a first one that began in the block before (row0 odd) and a last one that ends in the block
+		 * behind (the block's end odd): those take the wider class of the two blocks.  Places: blkoff[b] (from the walk) is local pair 0,
+		 * the others follow back to back. */
+		const uint32_t cls_b = bp_class(pwr, level);
+		const uint32_t odd0 = row0 & 1u, npair = (odd0 + rows + 1u) >> 1;
+		uint32_t cls_head = cls_b, cls_tail = cls_b;    /* classes of local pair 0 and of the last local pair */
 		uint8_t *mo = nullptr;
+		uint64_t at = 0;
 		if (row0 < mf_rows) {
-			const uint64_t at = (uint64_t)blkoff[job.hdr_off + b] << 6;
-			mo = region + at + (((uint64_t)(cg >> 6) * 64u) << wide) + (cg & 63u);
-			/* the block's pair-table entries (entry k of a stream = where row pair k - 1 starts; entry 0: the pair of zeros in front),
-			 * written by the block's first threads */
-			for (uint32_t p = cg; p < rows / 2u; p += cols)
-				if (row0 + 2u * p < mf_rows)
-					mf_pairs[job.mf_pair_off + 1u + row0 / 2u + p] =
-						(uint32_t)(((job.mf_off + at + (((uint64_t)p * 2u * cols) << wide)) >> 6) << 2) | (wide ? ACMHIP_BP_WORD : ACMHIP_BP_BYTE);
+			if (odd0)
+				cls_head = bp_wider(cls_b, bp_class(hdr[job.hdr_off + b - 1u].pwr, level));
+			if (((row0 + rows) & 1u) && row0 + rows < mf_rows) {      /* (an even mf_rows: the partner row is staged too, its block was walked) */
+				cls_tail = bp_wider(cls_b, bp_class(hdr[job.hdr_off + b + 1u].pwr, level));
+				if (npair == 1u)
+					cls_head = cls_tail;
+			}
+			if (npair == 1u)
+				cls_tail = cls_head;
+			at = (uint64_t)blkoff[job.hdr_off + b] << 6;
+			mo = region + at;
+			/* the pair-table entries (entry k of a stream = where row pair k - 1 starts; entry 0: the pair of zeros in front) of the pairs
+			 * that BEGIN in this block, written by the block's first threads */
+			for (uint32_t j = odd0 + cg; j < npair; j += cols) {
+				const uint32_t first_row = row0 + 2u * j - odd0;
+				if (first_row < mf_rows) {
+					const uint32_t cj = j == 0u ? cls_head : j + 1u == npair ? cls_tail : cls_b;
+					const uint64_t pj = j == 0u ? 0u : (uint64_t)cols * bp_half_bytes(cls_head) + (uint64_t)(j - 1u) * cols * bp_half_bytes(cls_b);
+					mf_pairs[job.mf_pair_off + 1u + first_row / 2u] = (uint32_t)(((job.mf_off + at + pj) >> 6) << 2) | cj;
+				}
+			}
 			if (b == 0 && cg == 0)
 				mf_pairs[job.mf_pair_off] = (uint32_t)((job.mf_off >> 6) << 2) | ACMHIP_BP_BYTE;
 			if (b == 0 && cg < cols / 8u)
@@ -652,13 +716,33 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 			bad |= (v >= lim) | (v < -lim);                 /* hazard H1: the host resolves stale-table reads */
 			const uint32_t row = row0 + r;
 			if (row < mf_rows) {
-				const int lo = (int)(int8_t)(uint8_t)v;         /* idx = 256 hi + lo, both signed bytes */
-				uint8_t *const at = mo + ((((uint64_t)(r >> 1) * 2u + (r & 1u)) * cols) << wide);
-				at[0] = (uint8_t)lo;
-				if (wide) {
-					at[64] = (uint8_t)((v - lo) >> 8);
-					bad |= v >= 32640;                      /* beyond the form's range: the host stages the stream as int16 */
+				/* the row's place: local pair j, first or second row of it; inside a row 64 columns of a residue class side by side
+				 * (this wavefront's: class cg / 64, thread t of it column t), 64 / 96 / 128 bytes per class and row */
+				const uint32_t j = (r + odd0) >> 1, second = (r + odd0) & 1u;
+				const uint32_t cj = j == 0u ? cls_head : j + 1u == npair ? cls_tail : cls_b;
+				const uint32_t hb = bp_half_bytes(cj);
+				const uint64_t pj = j == 0u ? 0u : (uint64_t)cols * bp_half_bytes(cls_head) + (uint64_t)(j - 1u) * cols * bp_half_bytes(cls_b);
+				uint8_t *const chunk = mo + pj + ((second * cols * hb) >> 1) + (cg >> 6) * (32u * hb);
+				const uint32_t q = cg & 63u;
+				const int lo = (int)(int8_t)(uint8_t)v;         /* idx = 256 hi + lo, both signed */
+				const int hi = (v - lo) >> 8;
+				if (cj == ACMHIP_BP_WORDU) {
+					/* the whole int16 range: the low byte unsigned, stored minus 128 (the kernel adds 128 val x the matrices' row sums back) */
+					chunk[q] = (uint8_t)((uint32_t)v ^ 0x80u);
+					chunk[64u + q] = (uint8_t)((uint32_t)v >> 8);
+				} else {
+					chunk[q] = (uint8_t)lo;
+					if (cj == ACMHIP_BP_WORD) {
+						chunk[64u + q] = (uint8_t)hi;
+						bad |= v >= 32640;                      /* (levels 13 / 14 only) beyond the class's range: the host stages the stream as int16 */
+					}
 				}
+				/* 12 bits: the high NIBBLES of columns q and q ^ 4 share a byte, the lower column's in the high half (acm_pack.cpp
+				 * put_row_nib12: x & 0xf0f0f0f0 and (x << 4) & 0xf0f0f0f0 are the matrix operand bytes).  The wavefront is in step here -
+				 * its 64 columns are one block's, whatever their filler codes - so the partner's nibble comes by a lane exchange */
+				const int hp = __shfl_xor(hi, 4);
+				if (cj == ACMHIP_BP_NIB12 && !(q & 4u))
+					chunk[64u + 8u * (q >> 4) + 4u * ((q >> 3) & 1u) + (q & 3u)] = (uint8_t)(((hi & 15) << 4) | (hp & 15));
 			}
 			if (row + 2u >= mf_rows)
 				out[(uint64_t)r << level] = (int16_t)v;

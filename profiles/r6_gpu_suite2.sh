@@ -1,0 +1,9 @@
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+( timeout 1700 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ) > gpurun_out/r6_pytest_e.txt 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > gpurun_out/r6_smoke_e.txt 2>&1
+: > gpurun_out/r6_fuzz_e.txt
+for seed in 77001 77002 77003; do
+  timeout 900 python3 profiles/byteplane_fuzz.py 700 $seed 2>&1 | grep -v amdgpu.ids | tail -4 >> gpurun_out/r6_fuzz_e.txt
+done
+cat gpurun_out/r6_pytest_e.txt gpurun_out/r6_smoke_e.txt gpurun_out/r6_fuzz_e.txt

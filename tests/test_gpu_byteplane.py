@@ -433,6 +433,47 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
         assert res0[k][0] == res[k][0] and np.array_equal(res0[k][1], want), k
 
 
+def test_device_parser_stages_every_width_class_and_odd_block_heights(dev, monkeypatch):
+    """The column kernel of the device parser writes the form's four width classes - 8 bits, 12 bits (pwr 8-10 at levels 8-12), two
+    signed bytes, and the whole-range class for pwr 15 blocks at levels 8-12 (no host redo for an index beyond 32 639 there) - and
+    block heights that are ODD: every other block begins inside a row pair, which takes the wider class of the two blocks and whose
+    second row is written by the next block's threads (acm_parse.hip bp_class / bp_wider; one block range only).  Same PCM as the
+    oracle, and the streams really travel in the form"""
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(1))
+    files = []
+    for j, (lv, rows) in enumerate(((8, 1), (8, 3), (9, 5), (9, 17), (10, 3), (10, 33), (11, 1), (11, 7), (12, 3), (12, 9), (13, 3), (13, 5), (14, 1), (14, 3),
+                                    (9, 16), (10, 8), (12, 4), (8, 64), (11, 2), (9, 2))):
+        tr = capi.lib().acmk_tile2_rows(lv)
+        nblocks = max(4, (5 * tr + rows - 1) // rows + 2 + j % 3)
+        loud = j % 4 == 1 and lv <= 12                  # pwr 15 with 16-bit values: indices beyond 32 639 occur
+        files.append(make_stream(36000 + j, lv, rows, nblocks, channels=1 + j % 2, cut=j % 5, pwr_min=[4, 13, 8, 6][j % 4],
+                                 pwr_max=15 if loud else [12, 15, 10, 11][j % 4] if lv <= 12 else [12, 14, 10, 11][j % 4],
+                                 val_max=65535 if j % 3 == 0 else 255))
+    res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    assert tm.device_parsed == len(files) and tm.host_parsed == 0, (tm.device_parsed, tm.host_parsed)
+    for k, f in enumerate(files):
+        want, wst = oracle_pcm(f)
+        assert res[k][0] == wst and np.array_equal(res[k][1], want), k
+    # (the level-13 / 14 streams of a batch this small are below what the lean kernels take: they are staged as int16, like on the host route)
+    assert tm.packed_streams >= 16, tm.packed_streams
+
+
+@pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
+def test_device_parser_stages_odd_block_heights(dev, monkeypatch, level):
+    """the same batches as test_batch_stages_odd_block_heights, parsed AND staged on the device: every stream travels in the form, same PCM
+    as the oracle.  (Levels 13 / 14: both fused stagers - this one and acm_stage_file_mform - keep the int16 form, because a plan too small
+    for the lean kernel reads int16 rows from row 0 on; acm_batch.cpp, acm_stream.cpp.)"""
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(1))
+    files = [make_stream(33000 + 50 * level + i, level, rows, max(3, (9 * plan_rows(level) + rows - 1) // rows + i), channels=1 + i % 2, cut=i,
+                         pwr_min=[4, 8, 6, 12][i % 4], pwr_max=[12, 10, 9, 12][i % 4])
+             for i, rows in enumerate([1, 3, 17, 33, 3, 1, 33, 17])]
+    res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
+    assert tm.device_parsed == len(files) and tm.host_parsed == 0 and tm.packed_streams == len(files), (tm.device_parsed, tm.host_parsed, tm.packed_streams)
+    for k, f in enumerate(files):
+        want, wst = oracle_pcm(f)
+        assert res[k][0] == wst and np.array_equal(res[k][1], want), (level, k)
+
+
 @pytest.mark.parametrize("ranges", [2, 3, 5])
 def test_device_parser_walk_that_stops_inside_a_range(dev, monkeypatch, ranges):
     """A truncated stream whose walk gets through SOME blocks of a block range and stops in a later one: the column kernel then skips the
