@@ -168,6 +168,7 @@ struct Slot {
 	uint64_t mf_off = 0, mf_rows_cap = 0, mf_used = 0;
 	bool mf_fused = false;                          /* the form was written by the parsing pass itself (acm_stage_file_mform) */
 	uint64_t mf_pair_off = 0;       /* its first entry in the pair table */
+	uint32_t range_unit = 1;        /* device parsing in block ranges: the stream's ranges are cut at multiples of this many blocks (acmk_range_bound) */
 };
 
 /* Blocks a file can possibly hold: the header promises total_values, but arenas are sized by this - a block costs at
@@ -583,6 +584,24 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 	std::vector<uint64_t> piece_off, piece_len, rbase;      /* [r * n + i]: where range r of stream i sits in the PCM arenas, words */
 	uint64_t pcm_arena_words = pcm_total;
 	if (R > 1) {
+		/* where a stream may travel in the byte-plane form a range has to end on a whole tile of the lean kernel (the plan of a range is a
+		 * window; its ragged end would need int16 rows nobody writes) - which also keeps the row pairs of an odd block height, every
+		 * other one of which lies across two blocks, inside one range.  Blocks that are whole tiles: unit 1, ranges as ever */
+		for (size_t i = 0; i < n; i++) {
+			Slot &s = slots[i];
+			if (!s.ok)
+				continue;
+			const int T2 = acmk_tile2_rows(s.info.level), TM = acmk_tile2m_rows(s.info.level);
+			if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && s.info.level <= ACM_K1_MAX_LEVEL) {
+				uint32_t a = s.info.rows, b = (uint32_t)T2;
+				while (b) {
+					const uint32_t t = a % b;
+					a = b;
+					b = t;
+				}
+				s.range_unit = (uint32_t)T2 / a;
+			}
+		}
 		piece_off.assign(R * n, 0);
 		piece_len.assign(R * n, 0);
 		rbase.assign(R + 1, 0);
@@ -595,7 +614,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 					continue;
 				const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
 				const uint64_t words = deliverable_words(s.info.total_values, bl, s.info.channels, s.need_blocks);
-				const uint64_t lo = std::min(words, s.need_blocks * r / R * bl), hi = std::min(words, s.need_blocks * (r + 1) / R * bl);
+				const uint64_t lo = std::min(words, (uint64_t)acmk_range_bound((uint32_t)s.need_blocks, (uint32_t)r, (uint32_t)R, s.range_unit) * bl);
+				const uint64_t hi = std::min(words, (uint64_t)acmk_range_bound((uint32_t)s.need_blocks, (uint32_t)r + 1u, (uint32_t)R, s.range_unit) * bl);
 				piece_off[r * n + i] = at;
 				piece_len[r * n + i] = hi - lo;
 				at += round_up(hi - lo, 64);
@@ -885,16 +905,13 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			j.level = s.info.level;
 			j.rows = s.info.rows;
 			j.blocks = (uint32_t)s.need_blocks;
-			j.pad = 0;
+			j.range_unit = s.range_unit;
 			j.mf_off = j.mf_pair_off = j.mf_rows = 0;
 			if (dev_mform && s.mf_rows_cap) {
 				/* rows [0, mf_rows) - the whole tiles of the lean kernel, as the plan will cut them - are staged in the byte-plane form.
-				 * With block ranges every range must end on a tile boundary (it does when a block is whole tiles), or its ragged end
-				 * would need int16 rows nobody writes - which also keeps the row pairs of an odd block height, every other one of which
-				 * lies across two blocks, inside one range: such streams are staged with one range only */
+				 * With block ranges every range ends on a tile boundary (Slot::range_unit, above) */
 				const int T2 = acmk_tile2_rows(s.info.level), TM = acmk_tile2m_rows(s.info.level);
-				if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && s.info.level <= ACM_K1_MAX_LEVEL &&
-				    (R == 1 || s.info.rows % (uint32_t)T2 == 0)) {
+				if (acmk_tile2m_stages(s.info.level) == 6 && T2 > 0 && TM > 0 && T2 % TM == 0 && s.info.level <= ACM_K1_MAX_LEVEL) {
 					const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
 					const uint64_t words = deliverable_words(s.info.total_values, bl, s.info.channels, s.need_blocks);
 					const uint64_t rows2 = std::min<uint64_t>(s.need_blocks * s.info.rows, words >> s.info.level) / (uint64_t)T2 * (uint64_t)T2;
@@ -1027,7 +1044,7 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			/* the piece starts where the stream's earlier ranges end (they are whole blocks); a stream the device flags
 			 * later is decoded again from the host reader's staging and copied out whole (fix-up, below) */
 			const uint64_t bl = (uint64_t)s.info.rows * s.info.cols;
-			const uint64_t lo = s.need_blocks * piece / R * bl, len = piece_len[piece * n + i];
+			const uint64_t lo = (uint64_t)acmk_range_bound((uint32_t)s.need_blocks, (uint32_t)piece, (uint32_t)R, s.range_unit) * bl, len = piece_len[piece * n + i];
 			if (lo >= items[i].pcm_cap || len == 0)
 				return;
 			memcpy(items[i].pcm + lo, h_pcm + piece_off[piece * n + i], std::min<uint64_t>(len, items[i].pcm_cap - lo) * sizeof(int16_t));
@@ -1108,8 +1125,8 @@ extern "C" int acm_batch_decode(acmhip_device *dev, acm_batch_item *items, size_
 			d.pcm_off = piece_off[r * n + i];
 			d.level = s.info.level;
 			d.rows = s.info.rows;
-			d.nrows = (uint32_t)(s.need_blocks * (r + 1) / R) * s.info.rows;
-			d.row_begin = (uint32_t)(s.need_blocks * r / R) * s.info.rows;
+			d.nrows = acmk_range_bound((uint32_t)s.need_blocks, (uint32_t)r + 1u, (uint32_t)R, s.range_unit) * s.info.rows;
+			d.row_begin = acmk_range_bound((uint32_t)s.need_blocks, (uint32_t)r, (uint32_t)R, s.range_unit) * s.info.rows;
 			d.n_emit = piece_len[r * n + i];
 			descs.push_back(d);
 		}

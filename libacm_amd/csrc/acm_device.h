@@ -73,8 +73,8 @@ struct AcmParseJob {
 	uint32_t level;
 	uint32_t rows;
 	uint32_t blocks;       /* blocks to parse */
-	uint32_t pad;
-	/* byte-plane staging by the device parser (the chunk kernel's form: levels whose acmk_tile2m_stages is 6, even acm_rows): rows
+	uint32_t range_unit;   /* block ranges of this stream are cut at multiples of this many blocks (0 / 1: anywhere): acmk_range_bound */
+	/* byte-plane staging by the device parser (the chunk kernel's form: levels whose acmk_tile2m_stages is 6): rows
 	 * [0, mf_rows) of the stream are written into the byte-plane arena at mf_off (bytes; the pair of zeros first), their pair-table
 	 * entries from mf_pair_off on; only the rows from mf_rows - 2 on are written to the int16 arena.  mf_rows = 0: int16 throughout */
 	uint64_t mf_off;
@@ -200,6 +200,8 @@ int acmk_launch_parse_range_mf(const AcmParseJob *d_jobs, uint32_t njobs, const 
  * still on their way up (PCIe runs both directions at once).  stripes_up (0 = the whole file is there) tells the walk of a
  * range how many stripes it may read: a stream that needs more stops with a status and goes to the host reader. */
 uint32_t acmk_stripe_bound(uint32_t file_len, uint32_t s, uint32_t S);
+/* first block of block range r of R (r == R: the end) of a stream of `blocks` blocks whose ranges are cut at multiples of `unit` blocks */
+uint32_t acmk_range_bound(uint32_t blocks, uint32_t r, uint32_t R, uint32_t unit);
 int acmk_launch_scatter_stripe(const AcmParseJob *d_jobs, uint32_t njobs, const uint64_t *d_stripe_at, const uint8_t *d_stage,
 			       uint8_t *d_files, uint32_t s, uint32_t S, void *stream);
 int acmk_launch_small(uint32_t level, const AcmDevStream *d_streams, const uint32_t *d_list, uint32_t nlist, uint64_t max_emit,

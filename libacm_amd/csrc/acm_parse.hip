@@ -183,6 +183,17 @@ __host__ __device__ __forceinline__ uint32_t acm_stripe_bound(uint32_t file_len,
 	return s >= S ? slot : (uint32_t)(((uint64_t)slot * s / S) & ~15ull);
 }
 
+/* first block of block range r of R of a stream of `blocks` blocks (r == R: its end).  Ranges are cut at multiples of `unit` blocks (0 / 1:
+ * anywhere; acm_batch.cpp asks for whole tiles of the lean kernel where a stream has the byte-plane form, which also keeps every row pair
+ * of an odd block height inside one range); a short stream may have empty ranges */
+__host__ __device__ __forceinline__ uint32_t acm_range_bound(uint32_t blocks, uint32_t r, uint32_t R, uint32_t unit)
+{
+	if (r >= R)
+		return blocks;
+	const uint32_t b = (uint32_t)((uint64_t)blocks * r / R);
+	return unit > 1u ? b / unit * unit : b;
+}
+
 /* payload bits of a column by filler code for `rows` rows; K_WALK = step through it, BAD_CODE = stop */
 __device__ __forceinline__ uint32_t column_bits(uint32_t code, uint32_t rows)
 {
@@ -420,14 +431,14 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 	ww.maxdw = (job.file_len + 15u) / 4u;
 	ww.lane = lane;
 	/* block range `range` of `nranges` (1 of 1: the whole stream): a later range resumes where the one before stopped */
-	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges), b_hi = (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges);
+	const uint32_t b_lo = acm_range_bound(job.blocks, range, nranges, job.range_unit), b_hi = acm_range_bound(job.blocks, range + 1u, nranges, job.range_unit);
 	uint32_t bit = job.data_start * 8u;
 	/* byte-plane staging (job.mf_rows != 0): where block b starts in the stream's region - behind the pair of zeros, every block at
 	 * 1, 1.5 or 2 bytes per index by its pwr (bp_class) - is a running sum only this walk knows */
 	uint32_t mf_at = (2u * cols) >> 6;
 	/* a block height that is odd: every other block starts with the second row of a pair that began in the block before it.  Such a pair
 	 * takes the wider class of the two blocks, so its size is known only here, at the second one; str_at is where it lies, str_cls the
-	 * class the first block asked for.  (Block ranges never cut such a pair: acm_batch.cpp stages odd heights with one range only.) */
+	 * class the first block asked for.  (Block ranges never cut such a pair: job.range_unit makes them end on whole tiles.) */
 	uint32_t str_at = 0, str_cls = ACMHIP_BP_BYTE;
 	/* Byte-plane staging and block ranges: the synthesis of a range is queued behind its walk without the host looking at the result, on
 	 * a plan cut from what the headers promised.  A stream whose walk stops early leaves the pair-table entries of the blocks it did not
@@ -615,8 +626,8 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 		return;                                         /* the host redoes the whole stream */
 	const uint32_t rows = job.rows, level = job.level, cols = 1u << level;
 	/* the columns of the blocks the walk has just covered (block range `range` of `nranges`) */
-	const uint32_t b_lo = (uint32_t)((uint64_t)job.blocks * range / nranges);
-	const uint32_t b_hi = min(rs.blocks_done, (uint32_t)((uint64_t)job.blocks * (range + 1) / nranges));
+	const uint32_t b_lo = acm_range_bound(job.blocks, range, nranges, job.range_unit);
+	const uint32_t b_hi = min(rs.blocks_done, acm_range_bound(job.blocks, range + 1u, nranges, job.range_unit));
 	const uint32_t ncol = b_hi << level;                    /* blocks * cols < 2^32 (acmk_parse_supported) */
 	/* the grid is sized for the longest stream of the batch: in a batch of ragged streams most workgroups have nothing to do,
 	 * and should find that out before they build the table (a corpus of 4000 files: 1.3 M workgroups, 5.3 ms per launch) */
@@ -788,6 +799,11 @@ acm_scatter_stripe(const AcmParseJob *__restrict__ jobs, const uint32_t njobs, c
 extern "C" uint32_t acmk_stripe_bound(uint32_t file_len, uint32_t s, uint32_t S)
 {
 	return acm_stripe_bound(file_len, s, S);
+}
+
+extern "C" uint32_t acmk_range_bound(uint32_t blocks, uint32_t r, uint32_t R, uint32_t unit)
+{
+	return acm_range_bound(blocks, r, R, unit);
 }
 
 extern "C" int acmk_launch_scatter_stripe(const AcmParseJob *d_jobs, uint32_t njobs, const uint64_t *d_stripe_at, const uint8_t *d_stage,

@@ -419,8 +419,8 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
     files[13] = make_stream(30990, 9, 16, 40, mix=1, allow_out_of_range=1, prime_table=1, pwr_min=0, pwr_max=6)
     files[21] = make_stream(30991, 9, 16, 1)
     res, tm = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=True)
-    # (with block ranges only streams whose blocks are whole tiles of the lean kernel get the form: a range must end on a tile boundary)
-    assert tm.device_parsed >= 40 and tm.packed_streams >= (25 if ranges == 1 else 15), (tm.device_parsed, tm.packed_streams)
+    # (a range ends on a tile boundary of the lean kernel whatever the block height - acmk_range_bound -, so the form does not depend on the range count)
+    assert tm.device_parsed >= 40 and tm.packed_streams >= 25, (tm.device_parsed, tm.packed_streams)
     res0, tm0 = capi.batch_decode(dev, files, threads=4, parse=capi.PARSE_DEVICE, byteplane=False)      # ACM_BATCH_STAGE_INT16: every row as int16
     assert tm0.packed_streams == 0
     for k, f in enumerate(files):
@@ -433,13 +433,14 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
         assert res0[k][0] == res[k][0] and np.array_equal(res0[k][1], want), k
 
 
-def test_device_parser_stages_every_width_class_and_odd_block_heights(dev, monkeypatch):
+@pytest.mark.parametrize("ranges", [1, 4])
+def test_device_parser_stages_every_width_class_and_odd_block_heights(dev, monkeypatch, ranges):
     """The column kernel of the device parser writes the form's four width classes - 8 bits, 12 bits (pwr 8-10 at levels 8-12), two
     signed bytes, and the whole-range class for pwr 15 blocks at levels 8-12 (no host redo for an index beyond 32 639 there) - and
     block heights that are ODD: every other block begins inside a row pair, which takes the wider class of the two blocks and whose
-    second row is written by the next block's threads (acm_parse.hip bp_class / bp_wider; one block range only).  Same PCM as the
-    oracle, and the streams really travel in the form"""
-    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(1))
+    second row is written by the next block's threads (acm_parse.hip bp_class / bp_wider).  Same PCM as the oracle, and the streams
+    really travel in the form - in one piece and in block ranges"""
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     files = []
     for j, (lv, rows) in enumerate(((8, 1), (8, 3), (9, 5), (9, 17), (10, 3), (10, 33), (11, 1), (11, 7), (12, 3), (12, 9), (13, 3), (13, 5), (14, 1), (14, 3),
                                     (9, 16), (10, 8), (12, 4), (8, 64), (11, 2), (9, 2))):
@@ -458,12 +459,14 @@ def test_device_parser_stages_every_width_class_and_odd_block_heights(dev, monke
     assert tm.packed_streams >= 16, tm.packed_streams
 
 
+@pytest.mark.parametrize("ranges", [1, 3, 7])
 @pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
-def test_device_parser_stages_odd_block_heights(dev, monkeypatch, level):
+def test_device_parser_stages_odd_block_heights(dev, monkeypatch, level, ranges):
     """the same batches as test_batch_stages_odd_block_heights, parsed AND staged on the device: every stream travels in the form, same PCM
     as the oracle.  (Levels 13 / 14: both fused stagers - this one and acm_stage_file_mform - keep the int16 form, because a plan too small
-    for the lean kernel reads int16 rows from row 0 on; acm_batch.cpp, acm_stream.cpp.)"""
-    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(1))
+    for the lean kernel reads int16 rows from row 0 on; acm_batch.cpp, acm_stream.cpp.)  In one piece and in block ranges: a stream's
+    ranges are cut where whole tiles end (acmk_range_bound), so no range cuts a row pair or leaves a ragged end inside the form."""
+    monkeypatch.setattr(capi, "BATCH_EXTRA", capi.batch_ranges(ranges))
     files = [make_stream(33000 + 50 * level + i, level, rows, max(3, (9 * plan_rows(level) + rows - 1) // rows + i), channels=1 + i % 2, cut=i,
                          pwr_min=[4, 8, 6, 12][i % 4], pwr_max=[12, 10, 9, 12][i % 4])
              for i, rows in enumerate([1, 3, 17, 33, 3, 1, 33, 17])]
