@@ -111,20 +111,20 @@ __device__ __forceinline__ uint32_t code_class(uint32_t code)
 }
 
 /* ---- byte-plane staging: the width class of a block from its pwr alone ----
- * An index of a block lies in [-2^pwr, 2^pwr) (decode.c:592-600; anything else is hazard H1 and goes back to the host), so the class of
+ * An index of a block lies in [-2^pwr, 2^pwr) (decode.c:592-600; anything else is hazard H1 and goes back to the host), so a class of
  * include/acm_hip.h that holds the block is known before a single column is decoded - which is what lets the walk place every block:
- * 8 bits up to pwr 7, then at the chunk kernel's levels 12 bits up to pwr 10 (the class ends at 1919), two signed bytes up to pwr 14 and the
- * whole-range class for pwr 15 (the two-byte class ends at 32 639); at levels 13 / 14 two signed bytes from pwr 8 on, and a stream with
- * an index beyond 32 639 is flagged for the host.  (The host stager, acm_pack.cpp, looks at the indices themselves and may pick narrower.) */
+ * 8 bits up to pwr 7, two signed bytes up to pwr 14, and at the chunk kernel's levels the whole-range class for pwr 15 (the two-byte class
+ * ends at 32 639; at levels 13 / 14 a stream with an index beyond that is flagged for the host).  The host stager (acm_pack.cpp) looks at
+ * the indices themselves and also has the 12-bit class; here that class was measured and left out (profiles/r6_level9_notes.txt
+ * section 17): its nibble exchange and third store cost the column kernel 21 us per range launch, the synthesis of a range gains nothing
+ * measurable from the bytes it saves. */
 __device__ __forceinline__ uint32_t bp_class(uint32_t pwr, uint32_t level)
 {
 	if (pwr < 8u)
 		return ACMHIP_BP_BYTE;
-	if (level > 12u)
-		return ACMHIP_BP_WORD;
-	return pwr <= 10u ? ACMHIP_BP_NIB12 : pwr == 15u ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
+	return pwr == 15u && level <= 12u ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
 }
-/* bytes per index, times two (WORDU 4, NIB12 3, BYTE 2, WORD 4) */
+/* bytes per index, times two (WORDU 4, NIB12 3 - not written here -, BYTE 2, WORD 4) */
 __device__ __forceinline__ uint32_t bp_half_bytes(uint32_t cls)
 {
 	return (0x4234u >> (4u * cls)) & 15u;
@@ -653,38 +653,65 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 	for (uint32_t g = (b_lo << level) + blockIdx.x * COL_THREADS + threadIdx.x; g < ncol; g += gridDim.x * COL_THREADS) {
 		const uint32_t b = g >> level, cg = g & (cols - 1);
 		const uint32_t c = mf_rows ? (cg >> 6) + sigma * (cg & 63u) : cg;
+		/* the three loads a column starts with travel together: one round trip, then the bit window's */
 		const uint32_t pwr = hdr[job.hdr_off + b].pwr;
+		const uint32_t cpos = colpos[job.col_off + ((uint64_t)b << level) + c];  /* (c: the column this thread decodes - not its place in the grid, see above) */
+		const uint32_t boff = mf_rows ? blkoff[job.hdr_off + b] : 0u;
 		const int lim = 1 << pwr;
 		int16_t *out = idx + job.idx_off + (uint64_t)b * bl + c;
 		const uint32_t row0 = b * rows;                 /* stream row of the block's first row (blocks * rows < 2^32: acmk_parse_supported) */
 		/* The block's rows in the byte-plane form.  Local pair j = the j-th row pair that has a row in this block; all of them have the
 		 * block's own class (bp_class) except a first one that began in the block before (row0 odd) and a last one that ends in the block
 		 * behind (the block's end odd): those take the wider class of the two blocks.  Places: blkoff[b] (from the walk) is local pair 0,
-		 * the others follow back to back. */
-		const uint32_t cls_b = bp_class(pwr, level);
-		const uint32_t odd0 = row0 & 1u, npair = (odd0 + rows + 1u) >> 1;
-		uint32_t cls_head = cls_b, cls_tail = cls_b;    /* classes of local pair 0 and of the last local pair */
-		uint8_t *mo = nullptr;
-		uint64_t at = 0;
-		if (row0 < mf_rows) {
+		 * the others follow back to back.
+		 * A stream with the form has >= 256 columns, so the 64 columns of a wavefront are ONE block's and one residue class's: block,
+		 * classes and row places are said to be wave-uniform (readfirstlane) - scalar registers, scalar branches in the row loop - and
+		 * a thread adds only its lane, q.  rp_*: byte offsets of the wavefront's class in the block's rows, from local pair 0 on (a
+		 * block is < 2^26 bytes): rows of the block's own class follow each other rp_half apart; the first pair and a last pair of
+		 * another class have their own geometry */
+		uint32_t odd0 = 0, mf_cnt = 0;                  /* mf_cnt: the block's first rows that are staged in the form */
+		uint32_t cls_b = ACMHIP_BP_BYTE, cls_head = ACMHIP_BP_BYTE, cls_tail = ACMHIP_BP_BYTE;    /* the block's class, local pair 0's, the last local pair's */
+		uint32_t rp_half = 0, rp_half_head = 0, rp_head = 0, rp_body = 0, rp_tail_t = 0xFFFFFFFFu, rp_tail = 0;
+		const uint32_t q = threadIdx.x & 63u;
+		uint8_t *mo = nullptr;                          /* local pair 0, + q */
+		const uint32_t bu = (uint32_t)__builtin_amdgcn_readfirstlane((int)b), cgu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cg);
+		const uint32_t row0u = bu * rows;               /* (the condition below is a scalar one: what it guards stays in scalar registers) */
+		if (mf_rows && row0u < mf_rows) {
+			const uint32_t cidx = cgu >> 6;
+			odd0 = row0u & 1u;
+			mf_cnt = min(rows, mf_rows - row0u);
+			const uint32_t npair = (odd0 + rows + 1u) >> 1;
+			/* (pwr and blkoff come by the vector loads that travel with the column's bit offset - one wait for the three - and are
+			 * made scalar afterwards: a scalar load here would be a second round trip in front of every column) */
+			const uint32_t at64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)boff);
+			cls_b = cls_head = cls_tail = bp_class((uint32_t)__builtin_amdgcn_readfirstlane((int)pwr), level);
 			if (odd0)
-				cls_head = bp_wider(cls_b, bp_class(hdr[job.hdr_off + b - 1u].pwr, level));
-			if (((row0 + rows) & 1u) && row0 + rows < mf_rows) {      /* (an even mf_rows: the partner row is staged too, its block was walked) */
-				cls_tail = bp_wider(cls_b, bp_class(hdr[job.hdr_off + b + 1u].pwr, level));
+				cls_head = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu - 1u].pwr, level));
+			if (((row0u + rows) & 1u) && row0u + rows < mf_rows) {      /* (an even mf_rows: the partner row is staged too, its block was walked) */
+				cls_tail = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu + 1u].pwr, level));
 				if (npair == 1u)
 					cls_head = cls_tail;
 			}
 			if (npair == 1u)
 				cls_tail = cls_head;
-			at = (uint64_t)blkoff[job.hdr_off + b] << 6;
-			mo = region + at;
+			const uint64_t at = (uint64_t)at64 << 6;
+			mo = region + at + q;
+			const uint32_t hb_b = bp_half_bytes(cls_b), hb_h = bp_half_bytes(cls_head), hb_t = bp_half_bytes(cls_tail);
+			rp_half = (cols * hb_b) >> 1;
+			rp_half_head = (cols * hb_h) >> 1;
+			rp_head = cidx * 32u * hb_h;
+			rp_body = cols * hb_h + cidx * 32u * hb_b - 2u * rp_half;       /* + t * rp_half, t >= 2 (mod 2^32) */
+			if (npair >= 2u && cls_tail != cls_b) {
+				rp_tail_t = 2u * (npair - 1u);
+				rp_tail = cols * hb_h + (npair - 2u) * cols * hb_b + cidx * 32u * hb_t;
+			}
 			/* the pair-table entries (entry k of a stream = where row pair k - 1 starts; entry 0: the pair of zeros in front) of the pairs
 			 * that BEGIN in this block, written by the block's first threads */
 			for (uint32_t j = odd0 + cg; j < npair; j += cols) {
-				const uint32_t first_row = row0 + 2u * j - odd0;
+				const uint32_t first_row = row0u + 2u * j - odd0;
 				if (first_row < mf_rows) {
 					const uint32_t cj = j == 0u ? cls_head : j + 1u == npair ? cls_tail : cls_b;
-					const uint64_t pj = j == 0u ? 0u : (uint64_t)cols * bp_half_bytes(cls_head) + (uint64_t)(j - 1u) * cols * bp_half_bytes(cls_b);
+					const uint64_t pj = j == 0u ? 0u : (uint64_t)cols * hb_h + (uint64_t)(j - 1u) * cols * hb_b;
 					mf_pairs[job.mf_pair_off + 1u + first_row / 2u] = (uint32_t)(((job.mf_off + at + pj) >> 6) << 2) | cj;
 				}
 			}
@@ -694,7 +721,7 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 				reinterpret_cast<uint4 *>(region)[cg] = make_uint4(0u, 0u, 0u, 0u);       /* the pair of zeros: 2 * cols bytes */
 		}
 		DevBits bs;
-		bs.seek(base, colpos[job.col_off + ((uint64_t)b << level) + c]);     /* (c: the column this thread decodes - not its place in the grid, see above) */
+		bs.seek(base, cpos);
 		const uint32_t code = bs.get(5);
 		const uint32_t cls = code_class(code);
 		const bool table = cls >= CLS_TERN;             /* CLS_BAD cannot occur: the scan flagged the stream */
@@ -726,34 +753,23 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 			}
 			bad |= (v >= lim) | (v < -lim);                 /* hazard H1: the host resolves stale-table reads */
 			const uint32_t row = row0 + r;
-			if (row < mf_rows) {
-				/* the row's place: local pair j, first or second row of it; inside a row 64 columns of a residue class side by side
-				 * (this wavefront's: class cg / 64, thread t of it column t), 64 / 96 / 128 bytes per class and row */
-				const uint32_t j = (r + odd0) >> 1, second = (r + odd0) & 1u;
-				const uint32_t cj = j == 0u ? cls_head : j + 1u == npair ? cls_tail : cls_b;
-				const uint32_t hb = bp_half_bytes(cj);
-				const uint64_t pj = j == 0u ? 0u : (uint64_t)cols * bp_half_bytes(cls_head) + (uint64_t)(j - 1u) * cols * bp_half_bytes(cls_b);
-				uint8_t *const chunk = mo + pj + ((second * cols * hb) >> 1) + (cg >> 6) * (32u * hb);
-				const uint32_t q = cg & 63u;
-				const int lo = (int)(int8_t)(uint8_t)v;         /* idx = 256 hi + lo, both signed */
-				const int hi = (v - lo) >> 8;
-				if (cj == ACMHIP_BP_WORDU) {
-					/* the whole int16 range: the low byte unsigned, stored minus 128 (the kernel adds 128 val x the matrices' row sums back) */
-					chunk[q] = (uint8_t)((uint32_t)v ^ 0x80u);
-					chunk[64u + q] = (uint8_t)((uint32_t)v >> 8);
-				} else {
-					chunk[q] = (uint8_t)lo;
-					if (cj == ACMHIP_BP_WORD) {
-						chunk[64u + q] = (uint8_t)hi;
-						bad |= v >= 32640;                      /* (levels 13 / 14 only) beyond the class's range: the host stages the stream as int16 */
-					}
+			if (r < mf_cnt) {
+				/* the row's place (rp_*, above): 64 columns of a residue class side by side - this wavefront's are class cg / 64, thread t
+				 * of it column t -, 64 or 128 bytes per class and row.  Everything here but the thread's lane is wave-uniform: scalar
+				 * selects, one scalar branch */
+				const uint32_t t = r + odd0;            /* row t & 1 of local pair t / 2 */
+				const bool in_head = t < 2u, in_tail = t >= rp_tail_t;
+				const uint32_t cj = in_head ? cls_head : in_tail ? cls_tail : cls_b;
+				const uint32_t off = in_head ? rp_head + (t & 1u) * rp_half_head : in_tail ? rp_tail : rp_body + t * rp_half;
+				const bool whole = cj == ACMHIP_BP_WORDU;
+				uint8_t *const chunk = mo + off;
+				const int lo = (int)(int8_t)(uint8_t)v;         /* two signed bytes: idx = 256 hi + lo */
+				/* (the whole-range class: the low byte unsigned, stored minus 128 - the kernel adds 128 val x the matrices' row sums back) */
+				chunk[0] = (uint8_t)(lo ^ (whole ? 0x80 : 0));
+				if (cj != ACMHIP_BP_BYTE) {
+					chunk[64] = (uint8_t)((v - (whole ? (v & 255) : lo)) >> 8);
+					bad |= v >= (whole ? 0x10000 : 32640);  /* (levels 13 / 14 only) beyond the class's range: the host stages the stream as int16 */
 				}
-				/* 12 bits: the high NIBBLES of columns q and q ^ 4 share a byte, the lower column's in the high half (acm_pack.cpp
-				 * put_row_nib12: x & 0xf0f0f0f0 and (x << 4) & 0xf0f0f0f0 are the matrix operand bytes).  The wavefront is in step here -
-				 * its 64 columns are one block's, whatever their filler codes - so the partner's nibble comes by a lane exchange */
-				const int hp = __shfl_xor(hi, 4);
-				if (cj == ACMHIP_BP_NIB12 && !(q & 4u))
-					chunk[64u + 8u * (q >> 4) + 4u * ((q >> 3) & 1u) + (q & 3u)] = (uint8_t)(((hi & 15) << 4) | (hp & 15));
 			}
 			if (row + 2u >= mf_rows)
 				out[(uint64_t)r << level] = (int16_t)v;

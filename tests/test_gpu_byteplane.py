@@ -435,8 +435,8 @@ def test_device_parser_stages_byteplanes(dev, monkeypatch, ranges):
 
 @pytest.mark.parametrize("ranges", [1, 4])
 def test_device_parser_stages_every_width_class_and_odd_block_heights(dev, monkeypatch, ranges):
-    """The column kernel of the device parser writes the form's four width classes - 8 bits, 12 bits (pwr 8-10 at levels 8-12), two
-    signed bytes, and the whole-range class for pwr 15 blocks at levels 8-12 (no host redo for an index beyond 32 639 there) - and
+    """The column kernel of the device parser writes three of the form's width classes - 8 bits, two signed bytes, and the whole-range
+    class for pwr 15 blocks at levels 8-12 (no host redo for an index beyond 32 639 there) - and
     block heights that are ODD: every other block begins inside a row pair, which takes the wider class of the two blocks and whose
     second row is written by the next block's threads (acm_parse.hip bp_class / bp_wider).  Same PCM as the oracle, and the streams
     really travel in the form - in one piece and in block ranges"""
