@@ -33,7 +33,8 @@ extern "C" {
 #define ACMHIP_ERR_HIP       -102   /* a HIP call failed; see acmhip_last_error() */
 #define ACMHIP_ERR_ARG       -103   /* invalid argument */
 #define ACMHIP_ERR_NOMEM     -104
-#define ACMHIP_ERR_RANGE     -105   /* the input cannot be put into the form asked for (acmhip_mform_rows); nothing is wrong with it */
+#define ACMHIP_ERR_RANGE     -105   /* (rounds 5 / 6: an index a staged form could not hold, acmhip_mform_rows.  Every form holds the whole int16 range now;
+                                       the code is kept for callers that test for it and is no longer returned) */
 
 /* output sample layouts = the four writers of decode.c:617-655 */
 #define ACMHIP_FMT_S16LE 0u
@@ -256,11 +257,10 @@ int  acmhip_plan_bind_packed(acmhip_plan *plan, const acmhip_packed_chunk *d_chu
  *                                  are then the matrix operand bytes hi << 4 of elements 8 d .. + 3 and 8 d + 4 .. + 7)
  *             ACMHIP_BP_WORD  (3)  idx = 256 hi + lo with BOTH bytes signed: 64 low bytes, then 64 high bytes.  That ends at
  *                                  32 639; a pair with a larger index (it takes pwr 15) is written as
- *             ACMHIP_BP_WORDU (0)  levels 8-12 only: idx = 256 hi + lo with hi = idx >> 8 (signed) and lo the UNSIGNED low byte,
- *                                  stored minus 128 ((idx & 0xff) ^ 0x80: a signed byte for the matrix instruction; the kernel
- *                                  adds 128 x val x the coefficient row sums of such rows back): the whole int16 range, same
- *                                  64 + 64 bytes.  At levels 13 / 14 (acm_tile2, which knows no such class) acmhip_mform_rows
- *                                  returns ACMHIP_ERR_RANGE for such a stream and it stays in the int16 form
+ *             ACMHIP_BP_WORDU (0)  idx = 256 hi + lo with hi = idx >> 8 (signed) and lo the UNSIGNED low byte,
+ *                                  stored minus 128 ((idx & 0xff) ^ 0x80: a signed byte for the matrix instruction; the kernels
+ *                                  add 128 x val x the coefficient row sums of such rows back): the whole int16 range, same
+ *                                  64 + 64 bytes.  (Levels 8-14; no stream is refused for its indices any more)
  * G = 8, level 7 (three stages, acm_tile2; also levels 8-9, and G = 16 at 10-14, in a -DACM_TUNING build run with ACM_K3=0).  The
  * pair in front is at 4 bits.  Per residue:
  *             ACMHIP_BP_WORD    G low bytes ((idx & 0xff) ^ 0x80: signed bytes, the kernel adds the 128 back through the

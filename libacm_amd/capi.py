@@ -370,7 +370,7 @@ def mform_streams(idx, descs, threads=1, L=None):
             used = C.c_uint64()
             rc = L.acmhip_mform_rows(d.level, idx[d.idx_off:].ctypes.data, rows[i], buf.ctypes.data, 0, pairs[p_at[i]:].ctypes.data,
                                      C.byref(used))
-            if rc == ERR_RANGE:                 # an index the form cannot hold (>= 32640 at a level of the chunk kernel): the stream stays int16
+            if rc == ERR_RANGE:                 # (libraries of rounds 5 / 6, A/B runs: an index the form could not hold - the stream stays int16)
                 ntiles[i] = 0
                 return
             _check(rc, "acmhip_mform_rows")

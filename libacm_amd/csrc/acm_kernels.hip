@@ -1824,7 +1824,7 @@ struct FirstPassZW {
 		for (int k = KEEP ? 2 : 0; k < NX; k++) {
 			const uint32_t u = (TR & 1 ? (uint32_t)__builtin_amdgcn_readfirstlane(odd) : 0u) + (uint32_t)k;        /* (wave-uniform: says so to the compiler) */
 			const uint32_t e = (u >> 1) ? (uint32_t)opaque_s((int32_t)d.e[1]) : (uint32_t)opaque_s((int32_t)d.e[0]);
-			const uint32_t sh = (e & 3u) - ACMHIP_BP_BYTE;                  /* 0: a byte per index, 1: two */
+			const uint32_t sh = (e & 3u) == ACMHIP_BP_BYTE ? 0u : 1u;       /* 0: a byte per index, 1: two (both 16-bit classes) */
 			const uint32_t row_at = (((e >> 2) - (e0 >> 2)) << 6) + ((u & 1u) ? (uint32_t)COLS << sh : 0u) + 16u * ks;
 #pragma unroll
 			for (int g = 0; g < NGW; g++) {
@@ -1863,8 +1863,13 @@ struct FirstPassZW {
 	/* rowval[k] = val << SHIFT of tile row k - 2 (FirstPassZ::run_t, further down, has the algebra: one accumulator chain per output row, the block
 	 * boundaries as multiply-adds of its partial sums) */
 	/* in_front: rows of the stream in front of the tile: 0, 1 (tiles of one row only), or 2 for "two or more" */
-	template <bool WORDS>
-	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const int32_t *rowval, const uint32_t in_front, const int tid, const Tables &t)
+	/* WHOLE (round 6): some row in reach is of the whole-range class - its low bytes are stored minus 128 (acm_pack.cpp).  What the
+	 * matrices make of the missing 128s is 128 x their row sums, per source row and scaled by that row's val like everything else of the
+	 * row: whole_rows bit k says so for row k, and the row sums come from the matrix cores themselves (the coefficients times a constant
+	 * operand of 64s, twice) - no table, the workgroup's LDS is spoken for to the last byte at level 13 */
+	template <bool WORDS, bool WHOLE = false>
+	static __device__ __forceinline__ void run_t(const Raw &raw, uint32_t *const tile, const int32_t *rowval, const uint32_t in_front, const int tid, const Tables &t,
+						     const uint32_t whole_rows = 0u)
 	{
 		const v4i_t zero = { 0, 0, 0, 0 };
 		const uint32_t lane = (uint32_t)tid & 63u, h = lane >> 4, qd = lane & 15u;
@@ -1873,6 +1878,10 @@ struct FirstPassZW {
 #pragma unroll
 		for (int k = 0; k < NX; k++)
 			rv[k] = __builtin_amdgcn_readfirstlane(rowval[k]);
+		int32_t cw[NX];                 /* 2 val of the rows that miss their 128s, 0 for the others (scalar) */
+#pragma unroll
+		for (int k = 0; k < NX; k++)
+			cw[k] = WHOLE && ((whole_rows >> k) & 1u) ? 2 * rv[k] : 0;
 		int32_t val[NSW], dv2[NSW], dv1[NSW];
 		bool step2[NSW], step1[NSW];
 #pragma unroll
@@ -1887,20 +1896,30 @@ struct FirstPassZW {
 #pragma unroll 1
 		for (int mt = 0; mt < NM; mt++) {
 			const v4i_t cf0 = cf[0], cf1 = cf[NM * 64], cf2 = cf[2 * NM * 64];
+			int32_t r64[3] = { 0, 0, 0 };           /* 64 x the row sums of T0, T1, T2 for this lane's output q (every instance the same) */
+			if constexpr (WHOLE) {
+				const v4u_t c64 = { 0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u };
+				r64[0] = mfma(c64, cf0, zero)[0];
+				r64[1] = mfma(c64, cf1, zero)[0];
+				r64[2] = mfma(c64, cf2, zero)[0];
+			}
 #pragma unroll
 			for (int g = 0; g < NGW; g++) {
 				const uint32_t c0 = group_at(g0 + (uint32_t)g) + class_of(4u * h);     /* the lane's four outputs: classes c0 .. c0 + 3 */
 #pragma unroll
 				for (int s = 0; s < NSW; s++) {
 					const uint32_t var = in_front + (uint32_t)s < 2u ? in_front + (uint32_t)s : 2u;        /* rows of the stream in front of this one: 0, 1, two or more */
-					const int32_t b = c0 == 0 ? (&t.bias[0][0])[var * QN + qd + 16u * (uint32_t)mt] : 0;
+					int32_t b = c0 == 0 ? (&t.bias[0][0])[var * QN + qd + 16u * (uint32_t)mt] : 0;
+					int32_t bw = 0;
+					if constexpr (WHOLE)    /* rows s, s + 1, s + 2 go through T2, T1, T0 (operands below 2^24: val << SHIFT < 2^20, 64 x 1822 < 2^17) */
+						bw = __mul24(r64[2], cw[s]) + __mul24(r64[1], cw[s + 1]) + __mul24(r64[0], cw[s + 2]);
 					const v4i_t l1 = mfma(raw.lo[g][s], cf2, zero);
 					const v4i_t l2 = mfma(raw.lo[g][s + 1], cf1, l1);
 					const v4i_t la = mfma(raw.lo[g][s + 2], cf0, l2);
 					v4i_t y;
 #pragma unroll
 					for (int v = 0; v < 4; v++)
-						y[v] = __mul24(la[v], val[s]) + (v == 0 ? b : 0);
+						y[v] = __mul24(la[v], val[s]) + (v == 0 ? b : 0) + bw;
 					if (step2[s]) {
 #pragma unroll
 						for (int v = 0; v < 4; v++)
@@ -1962,19 +1981,25 @@ struct FirstPassZW {
 		uint32_t any_word = 0;
 #pragma unroll
 		for (int j = 0; j < NE; j++)
-			any_word |= (d.e[j] & 3u) == ACMHIP_BP_WORD ? 1u : 0u;
+			any_word |= (d.e[j] & 3u) != ACMHIP_BP_BYTE ? 1u : 0u;
 		if (any_word) {
 			/* a pair at 8 bits has no high bytes: what was loaded in their place is its neighbour's low ones (in place: the rows that stay in
 			 * their registers for the next tile stay what they are) */
+			uint32_t whole_rows = 0;
 #pragma unroll
 			for (int k = 0; k < NX; k++) {
 				const uint32_t ek = ((odd + (uint32_t)k) >> 1) ? (uint32_t)opaque_s((int32_t)d.e[1]) : (uint32_t)opaque_s((int32_t)d.e[0]);
-				const uint32_t mask = (ek & 3u) == ACMHIP_BP_WORD ? 0xFFFFFFFFu : 0u;
+				const uint32_t mask = (ek & 3u) != ACMHIP_BP_BYTE ? 0xFFFFFFFFu : 0u;
+				whole_rows |= (ek & 3u) == ACMHIP_BP_WORDU ? 1u << k : 0u;
 #pragma unroll
 				for (int g = 0; g < NGW; g++)
 					raw.hi[g][k] &= mask;
 			}
-			run_t<true>(raw, tile, rowval, in_front, tid, t);
+			/* (a pair in front of the stream, or rows of a lead-in that do not exist, are never of that class: zeros are written at 8 bits) */
+			if (__builtin_expect(whole_rows == 0u, 1))
+				run_t<true>(raw, tile, rowval, in_front, tid, t);
+			else
+				run_t<true, true>(raw, tile, rowval, in_front, tid, t, whole_rows);
 		} else {
 			run_t<false>(raw, tile, rowval, in_front, tid, t);
 		}

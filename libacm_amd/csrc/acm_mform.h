@@ -23,7 +23,7 @@ struct AcmMformWriter {
 };
 
 int acm_mform_begin(AcmMformWriter *w, uint32_t level, uint8_t *out, uint64_t blob_base, acmhip_mform_pair *pairs);   /* writes the pair of zeros in front */
-int acm_mform_put_pair(AcmMformWriter *w, const int16_t *two_rows);     /* ACMHIP_OK, ACMHIP_ERR_RANGE (an index the form cannot hold), ACMHIP_ERR_ARG */
+int acm_mform_put_pair(AcmMformWriter *w, const int16_t *two_rows);     /* ACMHIP_OK, ACMHIP_ERR_ARG */
 uint64_t acm_mform_end(AcmMformWriter *w);                               /* read slack behind the last pair; bytes used */
 /* rows [2 * pair - 2 .. ] back into int16: the two rows of pair-table entry `entry` (entry 0 = the pair in front) */
 int acm_mform_get_pair(uint32_t level, const uint8_t *blob, acmhip_mform_pair entry, int16_t *two_rows);

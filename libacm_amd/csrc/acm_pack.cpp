@@ -264,8 +264,9 @@ extern "C" uint64_t acmhip_mform_pairs(uint64_t nrows)
 }
 
 namespace {
-/* the chunk kernel's form (64 columns of a residue class side by side): classes 8 and 16 bits - the 16-bit one as two SIGNED bytes - and,
- * at the levels of acm_chunk itself (8-12; levels 13 / 14 read the same form inside acm_tile2, which knows no third class), 12 bits */
+/* the chunk kernel's form (64 columns of a residue class side by side): classes 8 and 16 bits - the 16-bit one as two SIGNED bytes, or
+ * with an unsigned low byte for the pairs those cannot hold - and, at the levels of acm_chunk itself (8-12; levels 13 / 14 read the same
+ * form inside acm_tile2, which knows no 12-bit class), 12 bits */
 inline bool split_form(size_t qn) { return qn == 64; }
 inline bool nib12_level(uint32_t level) { return acmhip_mform_group(level) == 64 && level <= 12; }
 inline uint32_t pair_bytes(uint32_t level, uint32_t cls)
@@ -529,10 +530,8 @@ int acm_mform_put_pair(AcmMformWriter *w, const int16_t *src)
 		hi = src[m] > hi ? src[m] : hi;
 	}
 #endif
-	/* 256 hi + lo with two signed bytes ends at 32639.  At the chunk kernel's own levels a pair beyond that is written with the unsigned
-	 * low byte (class 0: the kernel's general path puts the 128 back); at levels 13 / 14 such a stream stays in the int16 form */
-	if (w->split && hi >= 32640 && !w->nib12)
-		return ACMHIP_ERR_RANGE;
+	/* 256 hi + lo with two signed bytes ends at 32639: a pair beyond that is written with the unsigned low byte (class 0: the kernels -
+	 * the chunk kernel's general path, FirstPassZW at levels 13 / 14 - put the 128 back) */
 	const uint32_t cls = (!w->split && lo >= -8 && hi <= 7) ? ACMHIP_BP_NIBBLE : (lo >= -128 && hi <= 127) ? ACMHIP_BP_BYTE :
 			     (w->nib12 && lo >= -2176 && hi <= 1919) ? ACMHIP_BP_NIB12 : (w->split && hi >= 32640) ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
 	if (((w->blob_base + w->at) >> 6) >= (1ull << 30))
@@ -558,7 +557,7 @@ int acm_mform_get_pair(uint32_t level, const uint8_t *blob, acmhip_mform_pair en
 		return ACMHIP_ERR_ARG;
 	const size_t cols = (size_t)1 << level, sigma = cols / qn;
 	const uint32_t cls = entry & 3;
-	if (cls > ACMHIP_BP_WORD || cls < (nib12_level(level) ? ACMHIP_BP_WORDU : split_form(qn) ? ACMHIP_BP_BYTE : ACMHIP_BP_NIBBLE))
+	if (cls > ACMHIP_BP_WORD || (split_form(qn) ? (cls == ACMHIP_BP_NIB12 && !nib12_level(level)) : cls < ACMHIP_BP_NIBBLE))
 		return ACMHIP_ERR_ARG;
 	const uint8_t *src = blob + ((uint64_t)(entry >> 2) << 6);
 	const size_t rowb = pair_bytes(level, cls) / 2;

@@ -113,16 +113,13 @@ __device__ __forceinline__ uint32_t code_class(uint32_t code)
 /* ---- byte-plane staging: the width class of a block from its pwr alone ----
  * An index of a block lies in [-2^pwr, 2^pwr) (decode.c:592-600; anything else is hazard H1 and goes back to the host), so a class of
  * include/acm_hip.h that holds the block is known before a single column is decoded - which is what lets the walk place every block:
- * 8 bits up to pwr 7, two signed bytes up to pwr 14, and at the chunk kernel's levels the whole-range class for pwr 15 (the two-byte class
- * ends at 32 639; at levels 13 / 14 a stream with an index beyond that is flagged for the host).  The host stager (acm_pack.cpp) looks at
- * the indices themselves and also has the 12-bit class; here that class was measured and left out (profiles/r6_level9_notes.txt
- * section 17): its nibble exchange and third store cost the column kernel 21 us per range launch, the synthesis of a range gains nothing
- * measurable from the bytes it saves. */
-__device__ __forceinline__ uint32_t bp_class(uint32_t pwr, uint32_t level)
+ * 8 bits up to pwr 7, two signed bytes up to pwr 14 (they end at 32 639), the whole-range class for pwr 15.  The host stager
+ * (acm_pack.cpp) looks at the indices themselves and also has the 12-bit class; here that class was measured and left out
+ * (profiles/r6_level9_notes.txt section 17): its nibble exchange and third store cost the column kernel 21 us per range launch, the
+ * synthesis of a range gains nothing measurable from the bytes it saves. */
+__device__ __forceinline__ uint32_t bp_class(uint32_t pwr)
 {
-	if (pwr < 8u)
-		return ACMHIP_BP_BYTE;
-	return pwr == 15u && level <= 12u ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
+	return pwr < 8u ? ACMHIP_BP_BYTE : pwr == 15u ? ACMHIP_BP_WORDU : ACMHIP_BP_WORD;
 }
 /* bytes per index, times two (WORDU 4, NIB12 3 - not written here -, BYTE 2, WORD 4) */
 __device__ __forceinline__ uint32_t bp_half_bytes(uint32_t cls)
@@ -508,7 +505,7 @@ acm_parse_scan_wave(const AcmParseJob *__restrict__ jobs, uint32_t njobs, const 
 		}
 		{
 			/* blkoff[b]: where the row pair that holds the block's first row lies */
-			const uint32_t cls = bp_class(h20 & 15u, job.level);
+			const uint32_t cls = bp_class(h20 & 15u);
 			uint32_t inner = rows, first_at = mf_at;
 			if ((b * rows) & 1u) {
 				first_at = str_at;
@@ -684,11 +681,11 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 			/* (pwr and blkoff come by the vector loads that travel with the column's bit offset - one wait for the three - and are
 			 * made scalar afterwards: a scalar load here would be a second round trip in front of every column) */
 			const uint32_t at64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)boff);
-			cls_b = cls_head = cls_tail = bp_class((uint32_t)__builtin_amdgcn_readfirstlane((int)pwr), level);
+			cls_b = cls_head = cls_tail = bp_class((uint32_t)__builtin_amdgcn_readfirstlane((int)pwr));
 			if (odd0)
-				cls_head = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu - 1u].pwr, level));
+				cls_head = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu - 1u].pwr));
 			if (((row0u + rows) & 1u) && row0u + rows < mf_rows) {      /* (an even mf_rows: the partner row is staged too, its block was walked) */
-				cls_tail = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu + 1u].pwr, level));
+				cls_tail = bp_wider(cls_b, bp_class(hdr[job.hdr_off + bu + 1u].pwr));
 				if (npair == 1u)
 					cls_head = cls_tail;
 			}
@@ -768,7 +765,6 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 				chunk[0] = (uint8_t)(lo ^ (whole ? 0x80 : 0));
 				if (cj != ACMHIP_BP_BYTE) {
 					chunk[64] = (uint8_t)((v - (whole ? (v & 255) : lo)) >> 8);
-					bad |= v >= (whole ? 0x10000 : 32640);  /* (levels 13 / 14 only) beyond the class's range: the host stages the stream as int16 */
 				}
 			}
 			if (row + 2u >= mf_rows)

@@ -103,12 +103,13 @@ def test_byteplane_twelve_bit_class(dev, force_k2, level, rows, pwr_min, pwr_max
     assert st.mform_tiles >= 9
 
 
-@pytest.mark.parametrize("level", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("level", [8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("rows,val_max", [(16, 255), (3, 65535), (1, 65535), (64, 255)])
 def test_byteplane_whole_range_class(dev, force_k2, level, rows, val_max):
-    """VERDICT r5, task 3 (iii): an index beyond 32639 (two signed bytes end there; it takes pwr 15) no longer keeps a stream of levels 8-12
-    out of the form: such PAIRS are written with the unsigned low byte (class code 0, stored minus 128) and the chunk kernel's general
-    path adds 128 x val x the coefficient row sums back, row by row.  Blocks of pwr 15 beside quiet ones (every neighbourhood of the
+    """VERDICT r5, task 3 (iii): an index beyond 32639 (two signed bytes end there; it takes pwr 15) no longer keeps a stream
+    out of the form: such PAIRS are written with the unsigned low byte (class code 0, stored minus 128) and the kernels - the chunk
+    kernel's general path at levels 8-12, FirstPassZW inside acm_tile2 at 13 / 14 (row sums from the matrix cores themselves) - add
+    128 x val x the coefficient row sums back, row by row.  Blocks of pwr 15 beside quiet ones (every neighbourhood of the
     whole-range class with 8 / 12 / 16-bit pairs), block boundaries inside a chunk, row values of 8 and of 16 bits"""
     tr = plan_rows(level)
     nblocks = max(4, (9 * tr + rows - 1) // rows + 1)
