@@ -387,3 +387,24 @@ def test_stager_rejects_what_the_kernel_could_not_read():
     assert L.acmhip_mform_unrows(level, out.ctypes.data, bad.ctypes.data, 4, back.ctypes.data) != 0
     out[5] = 0x98                                   # an index of 1 in the pair in front of the stream
     assert L.acmhip_mform_unrows(level, out.ctypes.data, pairs.ctypes.data, 4, back.ctypes.data) != 0
+
+
+def test_block_ranges_end_on_whole_tiles():
+    """acmk_range_bound (acm_parse.hip; host and device share it): the block ranges of a device-parsed stream are cut at multiples of
+    T / gcd(rows, T) blocks - the fewest blocks that are whole tiles of T rows - so that every range is a window on a tile boundary and no
+    range cuts a row pair of an odd block height; the ranges tile the stream, short streams have empty ranges, unit 0 / 1 cuts anywhere"""
+    from math import gcd
+    L = capi.lib()
+    L.acmk_range_bound.restype = C.c_uint32
+    L.acmk_range_bound.argtypes = [C.c_uint32] * 4
+    for blocks in (1, 2, 7, 16, 100, 251, 4001):
+        for R in (1, 2, 3, 5, 16, 64):
+            for rows, T in ((16, 16), (1, 16), (3, 32), (5, 8), (6, 4), (17, 2), (700, 16), (33, 4)):
+                unit = T // gcd(rows, T)
+                b = [L.acmk_range_bound(blocks, r, R, unit) for r in range(R + 1)]
+                assert b[0] == 0 and b[R] == blocks and b == sorted(b), (blocks, R, unit, b)
+                assert all(x % unit == 0 and (x * rows) % T == 0 for x in b[:-1])
+                assert all(x <= blocks * r // R for r, x in enumerate(b[:-1]))          # never beyond the even cut: a range needs no more of the file than before
+                plain = [L.acmk_range_bound(blocks, r, R, 1) for r in range(R + 1)]
+                assert plain == [blocks * r // R for r in range(R)] + [blocks]
+                assert plain == [L.acmk_range_bound(blocks, r, R, 0) for r in range(R + 1)]
