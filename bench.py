@@ -896,7 +896,7 @@ def main():
             "samples_from_int16_form": round(1.0 - form_total / max(1, int(batch.samples)), 5),
             "by_level": {str(lv): round(a / max(1, b), 5) for lv, (a, b) in sorted(by_level.items())},
             "note": "byte-plane rows: acm_chunk (levels 8-12) or acm_tile2's matrix build (7, 13, 14); int16 rows: ragged tails and streams "
-                    "without a form (odd block heights, H1 patches) on acm_fused_tile / the register and stage-wise kernels"}
+                    "without a form (H1 patches, levels below 7 and level 15) on acm_fused_tile / the register and stage-wise kernels"}
     if args.share_device or args.control == "gloo":
         out["rehearsal"] = ("every rank on GPU 0, control and gather through gloo: the N > 1 plumbing (rank spawn, CPU slices, per-rank lines, "
                             "gather leg) is exercised, the numbers mean nothing")
