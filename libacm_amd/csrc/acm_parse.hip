@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "acm_device.h"
 
@@ -727,49 +728,63 @@ acm_parse_columns(const AcmParseJob *__restrict__ jobs, const AcmParseResult *__
 		const uint32_t mask = (1u << width) - 1u;
 		const int mid = width ? 1 << (width - 1) : 0;
 		uint32_t pend = 0, npend = 0;
-		for (uint32_t r = 0; r < rows; r++) {
-			int v;
-			if (npend) {
-				v = (int)(pend & 15u) - 8;
-				pend >>= 4;
-				npend--;
-			} else {
-				bs.need(16);
-				const uint32_t raw = (uint32_t)bs.win;
-				if (table) {
-					const uint32_t e = lut[lbase + (raw & 127u)];
-					v = (int)((e >> 5) & 15u) - 8;
-					pend = e >> 9;
-					npend = ((e >> 3) & 3u) - 1;
-					bad |= (e >> 17) & 1u;
-					bs.drop(e & 7u);
-				} else {
-					v = (int)(raw & mask) - mid;
-					bs.drop(width);
-				}
-			}
-			bad |= (v >= lim) | (v < -lim);                 /* hazard H1: the host resolves stale-table reads */
-			const uint32_t row = row0 + r;
-			if (r < mf_cnt) {
-				/* the row's place (rp_*, above): 64 columns of a residue class side by side - this wavefront's are class cg / 64, thread t
-				 * of it column t -, 64 or 128 bytes per class and row.  Everything here but the thread's lane is wave-uniform: scalar
-				 * selects, one scalar branch */
-				const uint32_t t = r + odd0;            /* row t & 1 of local pair t / 2 */
-				const bool in_head = t < 2u, in_tail = t >= rp_tail_t;
-				const uint32_t cj = in_head ? cls_head : in_tail ? cls_tail : cls_b;
-				const uint32_t off = in_head ? rp_head + (t & 1u) * rp_half_head : in_tail ? rp_tail : rp_body + t * rp_half;
-				const bool whole = cj == ACMHIP_BP_WORDU;
-				uint8_t *const chunk = mo + off;
-				const int lo = (int)(int8_t)(uint8_t)v;         /* two signed bytes: idx = 256 hi + lo */
-				/* (the whole-range class: the low byte unsigned, stored minus 128 - the kernel adds 128 val x the matrices' row sums back) */
-				chunk[0] = (uint8_t)(lo ^ (whole ? 0x80 : 0));
-				if (cj != ACMHIP_BP_BYTE) {
-					chunk[64] = (uint8_t)((v - (whole ? (v & 255) : lo)) >> 8);
-				}
-			}
-			if (row + 2u >= mf_rows)
-				out[(uint64_t)r << level] = (int16_t)v;
+		/* plain: every row pair of the block in the form has the block's own class (no first pair that began in the block before, no last
+		 * pair of another class: every block of an even height) - a row is then placed with one multiply-add and its class is the block's.
+		 * Two copies of the row loop: with the per-row selects of the general one in it, the plain blocks paid a fifth more
+		 * (profiles/r6_level9_notes.txt section 17).  (Also plain: every block of a stream without the form, mf_cnt = 0) */
+#define ACM_COLUMN_ROWS(PLAIN)                                                                                                          \
+		for (uint32_t r = 0; r < rows; r++) {                                                                                   \
+			int v;                                                                                                          \
+			if (npend) {                                                                                                    \
+				v = (int)(pend & 15u) - 8;                                                                              \
+				pend >>= 4;                                                                                             \
+				npend--;                                                                                                \
+			} else {                                                                                                        \
+				bs.need(16);                                                                                            \
+				const uint32_t raw = (uint32_t)bs.win;                                                                  \
+				if (table) {                                                                                            \
+					const uint32_t e = lut[lbase + (raw & 127u)];                                                   \
+					v = (int)((e >> 5) & 15u) - 8;                                                                  \
+					pend = e >> 9;                                                                                  \
+					npend = ((e >> 3) & 3u) - 1;                                                                    \
+					bad |= (e >> 17) & 1u;                                                                          \
+					bs.drop(e & 7u);                                                                                \
+				} else {                                                                                                \
+					v = (int)(raw & mask) - mid;                                                                    \
+					bs.drop(width);                                                                                 \
+				}                                                                                                       \
+			}                                                                                                               \
+			bad |= (v >= lim) | (v < -lim);                 /* hazard H1: the host resolves stale-table reads */             \
+			const uint32_t row = row0 + r;                                                                                  \
+			if (r < mf_cnt) {                                                                                               \
+				/* the row's place (rp_*, above): 64 columns of a residue class side by side - this wavefront's are     \
+				 * class cg / 64, thread t of it column t -, 64 or 128 bytes per class and row.  Everything here but    \
+				 * the thread's lane is wave-uniform */                                                                  \
+				const uint32_t t = r + odd0;            /* row t & 1 of local pair t / 2 */                              \
+				uint32_t cj = cls_b, off = rp_body + t * rp_half;                                                       \
+				if (!(PLAIN)) {                                                                                         \
+					const bool in_head = t < 2u, in_tail = t >= rp_tail_t;                                          \
+					cj = in_head ? cls_head : in_tail ? cls_tail : cls_b;                                           \
+					off = in_head ? rp_head + (t & 1u) * rp_half_head : in_tail ? rp_tail : off;                    \
+				}                                                                                                       \
+				const bool whole = cj == ACMHIP_BP_WORDU;                                                               \
+				uint8_t *const chunk = mo + off;                                                                        \
+				const int lo = (int)(int8_t)(uint8_t)v;         /* two signed bytes: idx = 256 hi + lo */                \
+				/* (the whole-range class: the low byte unsigned, stored minus 128 - the kernel adds 128 val x the      \
+				 * matrices' row sums back) */                                                                           \
+				chunk[0] = (uint8_t)(lo ^ (whole ? 0x80 : 0));                                                          \
+				if (cj != ACMHIP_BP_BYTE)                                                                               \
+					chunk[64] = (uint8_t)((v - (whole ? (v & 255) : lo)) >> 8);                                     \
+			}                                                                                                               \
+			if (row + 2u >= mf_rows)                                                                                        \
+				out[(uint64_t)r << level] = (int16_t)v;                                                                 \
 		}
+		if (odd0 == 0u && rp_tail_t == 0xFFFFFFFFu && cls_head == cls_b) {
+			ACM_COLUMN_ROWS(true)
+		} else {
+			ACM_COLUMN_ROWS(false)
+		}
+#undef ACM_COLUMN_ROWS
 	}
 	if (bad)
 		atomicOr(&flags[blockIdx.y], 1u);
