@@ -179,6 +179,15 @@ def test_parse_walk_owns_m0(tmp_path):
                 assert not re.search(r"\bm0\b", code), t
                 assert not t.startswith("scratch_"), t
     assert writes >= 1 and mine == 2 * writes
+    # ... and so must the column kernel: its row loop exists twice (plain blocks / blocks whose first or last row pair has another class);
+    # written as a generic lambda the two copies kept their captures in scratch memory and the kernel ran 8 x slower (profiles/r6_level9_notes.txt 17)
+    m = re.search(r"^(_ZN\S*acm_parse_columns\S*):", asm, re.M)
+    assert m
+    cols = asm[m.end():asm.index(".Lfunc_end", m.end())]
+    assert "scratch_" not in cols and cols.count("global_store_byte") >= 4
+    for kernel in ("acm_parse_columns", "acm_parse_scan_wave"):
+        md = re.search(r"\.amdhsa_kernel \S*" + kernel + r"\S*\n(?:.*\n)*?\s*\.amdhsa_private_segment_fixed_size (\d+)", asm)
+        assert md and md.group(1) == "0", kernel
 
 
 def test_phase_priorities_are_in_the_tile_loop(kernel_asm):
